@@ -1,0 +1,179 @@
+/* include/pine_gpu.h -- C ABI of the MI355X-native PathIntegrator hot path (libpine_gpu.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository wicstas/pine).  The reference exposes the path to scripts through its Context
+ * reflection table (src/pine/core/context.h:235-609, registered in
+ * src/pine/core/program_context.cpp:23-125); INTEGRATION.md shows the thunks a pine maintainer
+ * would register to route `PathIntegrator(...).render(scene)` through this library.
+ *
+ * Conventions: every function returning int returns 0 (or a non-negative id) on success and a
+ * negative value on failure, with a message available from pine_gpu_last_error() (the reference
+ * aborts through SEVERE, src/pine/core/log.h:45-51; nothing aborts across this ABI).  Vectors are
+ * float[3]; matrices are float[16] in the reference's storage order (column vectors,
+ * src/pine/core/vecmath.h:575-640), i.e. m[c*4 + r].  Thread-safety: a scene may be built from one
+ * thread at a time; rendering distinct plans from distinct threads is safe; pine_gpu_progress() may
+ * be polled from any thread (src/cli/pine.cpp:36-40 does exactly that).
+ */
+#ifndef PINE_GPU_H
+#define PINE_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PINE_GPU_ABI_VERSION 1
+
+typedef struct pine_gpu_scene pine_gpu_scene; /* replaces pine::Scene, src/pine/core/scene.h:14-43 */
+typedef struct pine_gpu_plan pine_gpu_plan;   /* a PathIntegrator bound to a scene + device state */
+
+/* ---- errors / progress ------------------------------------------------------------------ */
+const char* pine_gpu_last_error(void);  /* thread-local message of the last failing call */
+float pine_gpu_progress(void);          /* get_progress(), src/pine/core/integrator.cpp:17-19 */
+int pine_gpu_abi_version(void);
+
+/* ---- host math used by scene scripts (PRL builtins) ---------------------------------------
+ * translate/scale/rotate_x|y|z/look_at: src/pine/core/vecmath.h:1102-1180; operator*(mat4,mat4)
+ * :617-624; inverse(mat4): src/pine/core/vecmath.cpp:103-132.  Same operand order, same libm. */
+void pine_gpu_mat4_identity(float out[16]);
+void pine_gpu_mat4_translate(const float v[3], float out[16]);
+void pine_gpu_mat4_scale(const float v[3], float out[16]);
+void pine_gpu_mat4_rotate_x(float rad, float out[16]);
+void pine_gpu_mat4_rotate_y(float rad, float out[16]);
+void pine_gpu_mat4_rotate_z(float rad, float out[16]);
+void pine_gpu_mat4_mul(const float a[16], const float b[16], float out[16]);
+void pine_gpu_mat4_inverse(const float m[16], float out[16]);
+void pine_gpu_mat4_look_at(const float from[3], const float at[3], float out[16]);
+
+/* ---- Scene ---------------------------------------------------------------------------------
+ * Scene(): src/pine/core/scene.cpp:64-79 (`Scene` ctor + `add`/`set` methods). */
+pine_gpu_scene* pine_gpu_scene_create(void);
+void pine_gpu_scene_destroy(pine_gpu_scene* scene);
+
+/* scene.add(name, Material): Scene::add_material src/pine/core/scene.cpp:8-13.  Constant shading
+ * nodes only (Node3f/Nodef literals).  Returns the material id.  A later add with the same name
+ * shadows the earlier one, as the reference's map assignment does. */
+int pine_gpu_scene_add_material_emissive(pine_gpu_scene*, const char* name, const float color[3]);
+                                         /* Emissive(Node3f)   src/pine/core/material.h:18-28  */
+int pine_gpu_scene_add_material_diffuse(pine_gpu_scene*, const char* name, const float albedo[3]);
+                                         /* Diffuse(Node3f)    src/pine/core/material.h:30-37  */
+int pine_gpu_scene_add_material_uber(pine_gpu_scene*, const char* name, const float albedo[3],
+                                     float roughness, float metallic, float transmission, float ior);
+                                         /* Uber(...)          src/pine/core/material.h:80-97  */
+int pine_gpu_scene_add_material_subsurface(pine_gpu_scene*, const char* name, const float albedo[3],
+                                           float roughness, const float sigma_s[3]);
+                                         /* Subsurface(...)    src/pine/core/material.h:99-110 */
+int pine_gpu_scene_find_material(pine_gpu_scene*, const char* name);
+                                         /* Scene::find_material src/pine/core/scene.cpp:49-54 */
+
+/* scene.add(Shape, material): Scene::add_geometry src/pine/core/scene.cpp:14-22 (emissive geometry
+ * becomes an AreaLight automatically).  Returns the geometry index.  Shape constructors:
+ * src/pine/core/geometry.cpp:901-946. */
+int pine_gpu_scene_add_rect(pine_gpu_scene*, const float position[3], const float ex[3],
+                            const float ey[3], int flip_normal, int material);
+                                         /* Rect(vec3,vec3,vec3,bool) geometry.cpp:255-267 */
+int pine_gpu_scene_add_aabb(pine_gpu_scene*, const float lower[3], const float upper[3], int material);
+                                         /* Box(vec3,vec3) = AABB     bbox.h:29-33         */
+int pine_gpu_scene_add_obb(pine_gpu_scene*, const float lower[3], const float upper[3],
+                           const float m[16], int material);
+                                         /* Box(AABB,mat4) = OBB      bbox.cpp:144         */
+int pine_gpu_scene_add_sphere(pine_gpu_scene*, const float center[3], float radius, int material);
+                                         /* Sphere(vec3,float)        geometry.cpp:72      */
+int pine_gpu_scene_add_disk(pine_gpu_scene*, const float position[3], const float normal[3],
+                            float radius, int material);
+                                         /* Disk(vec3,vec3,float)     geometry.cpp:123-127 */
+int pine_gpu_scene_add_cone(pine_gpu_scene*, const float position[3], const float normal[3],
+                            float radius, float height, int material);
+                                         /* Cone(vec3,vec3,float,float) geometry.cpp:409-414 */
+int pine_gpu_scene_add_mesh(pine_gpu_scene*, const float* vertices, int num_vertices,
+                            const uint32_t* indices, int num_triangles, int material);
+                                         /* Mesh(vertices, indices)   geometry.cpp:601-609 */
+
+/* scene.set(ThinLenCamera(Film(size, tonemapper), from, to, fov[, len_radius, focus_distance])):
+ * src/pine/core/camera.cpp:7-16,40-45; Film src/pine/core/film.h:24-27.
+ * tonemapper: 0 = Uncharted2, 1 = ACES (used only by pine_gpu_film_finalize). */
+int pine_gpu_scene_set_camera_thinlens(pine_gpu_scene*, int film_w, int film_h, int tonemapper,
+                                       const float from[3], const float to[3], float fov,
+                                       float len_radius, float focus_distance);
+
+/* Text dump of the scene as it was built (the .pscene exchange format, pine_amd/scene_io.py).
+ * Returns the number of bytes needed (excluding NUL); writes at most `capacity` bytes. */
+int64_t pine_gpu_scene_describe(pine_gpu_scene*, char* buf, int64_t capacity);
+
+/* Host-side accel build only (no GPU): BVH::build src/pine/impl/accel/bvh.cpp:453-495.
+ * Returns node count; optional dumps for tests: nodes as 16 x int32/float32 words each. */
+int pine_gpu_scene_build_accel(pine_gpu_scene*);
+int64_t pine_gpu_scene_accel_dump(pine_gpu_scene*, void* nodes_out, int64_t node_capacity_bytes,
+                                  int32_t* prims_out, int64_t prim_capacity);
+
+/* ---- PathIntegrator ------------------------------------------------------------------------
+ * PathIntegrator(Accel, Sampler, LightSampler, int) + render(Scene&):
+ * src/pine/impl/integrator/path.cpp:7-41, registered program_context.cpp:76-81.  The sampler is
+ * BlueSampler(spp) (src/pine/core/sampler.cpp:115-121: spp rounded up to a power of two, clamped
+ * to 256), the light sampler UniformLightSampler, the accel pine's BVH order.
+ */
+typedef struct {
+  int32_t spp;             /* requested samples per pixel (BlueSampler argument)            */
+  int32_t max_path_length; /* PathIntegrator depth argument (> 0)                           */
+  int32_t device;          /* HIP device ordinal                                            */
+  int32_t shard_rank;      /* this process renders tiles t with t % shard_world == rank     */
+  int32_t shard_world;     /* 1 = whole film                                                */
+  int32_t samples_per_item;/* 0 = auto; work item = this many consecutive samples of a pixel */
+  int32_t flags;           /* PINE_GPU_FLAG_*                                               */
+  int32_t reserved;
+} pine_gpu_render_params;
+
+#define PINE_GPU_FLAG_TIMING 1 /* record per-kernel HIP-event timings for the roofline report */
+
+/* Path to the packed BlueSobol tables (pine_amd/data/bluesobol_u8.bin); call once per process. */
+int pine_gpu_set_table_path(const char* path);
+
+/* One-shot, drop-in form: render into a HOST film of W*H float4 (row 0 first, exactly
+ * Array2d<vec4>, src/pine/core/array.h:51-55); includes upload + download.  Fails if no GPU. */
+int pine_gpu_path_render(pine_gpu_scene*, const pine_gpu_render_params*, float* film_out_host);
+
+/* Resident form (bench / multi-GPU): build device state once, launch many times.
+ * `film_dev` is a DEVICE pointer to W*H float4; `stream` is a hipStream_t (0 = default stream).
+ * Pixels outside this rank's shard are written as zeros, so a sum-reduce over ranks is exact. */
+pine_gpu_plan* pine_gpu_plan_create(pine_gpu_scene*, const pine_gpu_render_params*);
+int pine_gpu_plan_launch(pine_gpu_plan*, void* film_dev, void* stream);
+void pine_gpu_plan_destroy(pine_gpu_plan*);
+
+typedef struct {
+  uint64_t camera_samples;   /* samples this plan renders per launch (its shard)              */
+  uint64_t vertices;         /* radiance() invocations of the last launch    */
+  uint64_t shadow_rays;
+  float trace_ms;            /* last launch: path kernel, HIP events on the launch stream      */
+  float resolve_ms;          /* last launch: ordered per-pixel sum kernel                      */
+  float prepass_ms;          /* last launch: RNG checkpoint kernel                             */
+  int32_t spp_effective;
+  int32_t samples_per_item;
+  int32_t grid_blocks;
+  int32_t block_threads;
+  int32_t lds_bytes;
+  int32_t reserved;
+} pine_gpu_plan_stats;
+/* Blocks until the last launch has finished (needed to read the device-side counters). */
+int pine_gpu_plan_stats_get(pine_gpu_plan*, pine_gpu_plan_stats* out);
+
+/* Per-sample radiance of the last launch: copies spp_eff*W*H float4 (r,g,b,vertices) to host,
+ * layout [(y*W+x)*spp + s].  Test/debug aid. */
+int pine_gpu_plan_read_samples(pine_gpu_plan*, float* out_host, int64_t capacity_floats);
+
+/* Device-side unit-test hooks: run the device implementations on arrays (parity vs oracle). */
+int pine_gpu_test_sampler(int device, int spp, float* out_host, int64_t capacity);  /* layout of oracle_sampler_stream */
+int pine_gpu_test_rng(int device, uint64_t* out_host, int64_t capacity);            /* layout of oracle_rng_stream */
+int pine_gpu_test_sincos(int device, const float* x_host, int64_t n, float* sin_out, float* cos_out);
+int pine_gpu_test_shapes(pine_gpu_scene*, int device, const float* rays_host, int64_t nrays,
+                         float* out_host, int64_t capacity);                        /* layout of oracle_shapes */
+
+/* ---- Film (host side, after the hot path) ----------------------------------------------------
+ * Film::finalize + tone mapping + to_uint8_array: src/pine/core/film.cpp:12-27,66-68,
+ * src/pine/core/color.cpp:6-23, src/pine/core/fileio.cpp:42-54.  rgba_out: W*H*4 bytes, y-flipped. */
+int pine_gpu_film_finalize_u8(const float* film_host, int w, int h, int tonemapper, uint8_t* rgba_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINE_GPU_H */

@@ -1,0 +1,2306 @@
+// oracle/pine_oracle.cpp -- TEST INFRASTRUCTURE ONLY (checker + "port" CPU baseline).
+//
+// A CPU restatement, in this repo's own words, of the algorithm of wicstas/pine's PathIntegrator
+// hot path: per-pixel-sample ray generation, pine's binned-SAH BVH (build + ordered traversal),
+// shape intersection, BSDF evaluation/sampling, next-event estimation with MIS, and the recursive
+// per-level-clamped radiance fold.  It is deliberately written recursively and with pointer-y
+// data structures (close to the reference's shape) so that it is independent of the product's
+// iterative / flattened GPU formulation in pine_amd/csrc.
+//
+// Parity status: PINNED.  In the build container this restatement is checked bit-for-bit against
+// the real reference compiled from /root/reference (oracle/_ref/pine_ref, oracle/Makefile); the
+// outputs of that binary are committed as fixtures under tests/golden/ (tools/make_golden.py), and
+// tests/test_oracle_golden.py re-checks this file against them everywhere.
+//
+// Every function cites the reference file:line it follows (paths relative to /root/reference/).
+// All arithmetic is IEEE binary32 with no contraction (build with -ffp-contract=off), in the
+// operand order of the reference; the two order-unspecified call sites use the g++ (right-to-left)
+// order.
+#include "pine_oracle.h"
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// constants (src/pine/core/math.h:10-16, src/psl/math.h:11-17)
+// ------------------------------------------------------------------------------------------------
+constexpr float Pi = 3.14159265358979323846f;
+constexpr float kEpsilon = 1.1920928955078125e-07f;  // numeric_limits<float>::epsilon()
+constexpr float kOneMinusEps = 0x1.fffffep-1f;
+constexpr float kFloatMax = 3.40282346638528859812e+38f;
+
+// psl::min/max (src/psl/math.h:19-26): a<b?a:b / a>b?a:b -- NaN and tie behaviour matter.
+inline float fmin_(float a, float b) { return a < b ? a : b; }
+inline float fmax_(float a, float b) { return a > b ? a : b; }
+inline float sqr(float v) { return v * v; }
+inline float clampf(float v, float a, float b) { return fmin_(fmax_(v, a), b); }  // math.h:110-112
+
+// ------------------------------------------------------------------------------------------------
+// vectors / matrices (src/pine/core/vecmath.h:160-300, 504-640, 690-800)
+// ------------------------------------------------------------------------------------------------
+struct vec2 {
+  float x = 0, y = 0;
+  vec2() = default;
+  vec2(float x, float y) : x(x), y(y) {}
+  float operator[](int i) const { return (&x)[i]; }
+};
+struct vec3 {
+  float x = 0, y = 0, z = 0;
+  vec3() = default;
+  explicit vec3(float v) : x(v), y(v), z(v) {}
+  vec3(float x, float y, float z) : x(x), y(y), z(z) {}
+  float& operator[](int i) { return (&x)[i]; }
+  float operator[](int i) const { return (&x)[i]; }
+  vec3 operator-() const { return {-x, -y, -z}; }
+  bool is_zero() const { return x == 0 && y == 0 && z == 0; }
+};
+inline vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline vec3 operator*(vec3 a, vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline vec3 operator/(vec3 a, vec3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline vec3 operator*(float s, vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline vec3 operator/(vec3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline vec3& operator+=(vec3& a, vec3 b) { return a = a + b; }
+inline vec2 operator+(vec2 a, vec2 b) { return {a.x + b.x, a.y + b.y}; }
+inline vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
+inline vec2 operator*(vec2 a, vec2 b) { return {a.x * b.x, a.y * b.y}; }
+inline vec2 operator*(vec2 a, float s) { return {a.x * s, a.y * s}; }
+inline vec2 operator*(float s, vec2 a) { return {s * a.x, s * a.y}; }
+
+inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vecmath.h:751
+inline float absdot(vec3 a, vec3 b) { return std::abs(dot(a, b)); }             // :775
+inline vec3 cross(vec3 a, vec3 b) {                                              // :780
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline float length_squared(vec3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }  // :713
+inline float length(vec3 v) { return std::sqrt(length_squared(v)); }               // :722
+inline float distance(vec3 a, vec3 b) { return length(a - b); }
+inline vec3 normalize(vec3 v) {  // :736
+  float len = length(v);
+  if (len == 0) return v;
+  return v / len;
+}
+inline vec3 normalize(vec3 v, float& len) {  // :742
+  len = length(v);
+  if (len == 0) return v;
+  return v / len;
+}
+inline vec3 vmin(vec3 a, vec3 b) { return {fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)}; }
+inline vec3 vmax(vec3 a, vec3 b) { return {fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)}; }
+inline vec3 vabs(vec3 a) { return {std::abs(a.x), std::abs(a.y), std::abs(a.z)}; }
+inline int max_axis(vec3 v) {  // vecmath.h:1263
+  if (v[0] > v[1])
+    return v[0] > v[2] ? 0 : 2;
+  else
+    return v[1] > v[2] ? 1 : 2;
+}
+// lerp(u, v, a, b, c) (vecmath.h:882): (1 - u - v) * a + u * b + v * c
+inline vec3 lerp3(float u, float v, vec3 a, vec3 b, vec3 c) {
+  return (1.0f - u - v) * a + u * b + v * c;
+}
+
+struct vec4 {
+  float x = 0, y = 0, z = 0, w = 0;
+  vec4() = default;
+  vec4(float x, float y, float z, float w) : x(x), y(y), z(z), w(w) {}
+  vec4(vec3 v, float w) : x(v.x), y(v.y), z(v.z), w(w) {}
+  float& operator[](int i) { return (&x)[i]; }
+  float operator[](int i) const { return (&x)[i]; }
+};
+inline vec4 operator+(vec4 a, vec4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline vec4 operator*(vec4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+
+struct mat3 {  // column vectors (vecmath.h:504-572)
+  vec3 x{1, 0, 0}, y{0, 1, 0}, z{0, 0, 1};
+  mat3() = default;
+  mat3(vec3 x, vec3 y, vec3 z) : x(x), y(y), z(z) {}
+  vec3& operator[](int i) { return (&x)[i]; }
+  const vec3& operator[](int i) const { return (&x)[i]; }
+  vec3 row(int i) const { return {x[i], y[i], z[i]}; }
+};
+inline vec3 operator*(const mat3& m, vec3 v) { return m.x * v.x + m.y * v.y + m.z * v.z; }  // :695
+inline mat3 transpose(const mat3& m) { return {m.row(0), m.row(1), m.row(2)}; }
+
+struct mat4 {  // column vectors; scalar ctor takes row-major arguments (vecmath.h:575-585)
+  vec4 x{1, 0, 0, 0}, y{0, 1, 0, 0}, z{0, 0, 1, 0}, w{0, 0, 0, 1};
+  mat4() = default;
+  mat4(float x0, float y0, float z0, float w0, float x1, float y1, float z1, float w1, float x2,
+       float y2, float z2, float w2, float x3, float y3, float z3, float w3)
+      : x(x0, x1, x2, x3), y(y0, y1, y2, y3), z(z0, z1, z2, z3), w(w0, w1, w2, w3) {}
+  mat4(vec4 x, vec4 y, vec4 z, vec4 w) : x(x), y(y), z(z), w(w) {}
+  vec4& operator[](int i) { return (&x)[i]; }
+  const vec4& operator[](int i) const { return (&x)[i]; }
+};
+inline mat3 to_mat3(const mat4& m) {  // vecmath.h:588
+  return {vec3(m.x.x, m.x.y, m.x.z), vec3(m.y.x, m.y.y, m.y.z), vec3(m.z.x, m.z.y, m.z.z)};
+}
+inline vec3 operator*(const mat4& m, vec3 v) {  // affine point transform, vecmath.h:705
+  vec4 r = m.x * v.x + m.y * v.y + m.z * v.z + m.w;
+  return {r.x, r.y, r.z};
+}
+inline mat4 operator*(const mat4& l, const mat4& r) {  // vecmath.h:617
+  mat4 ret(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+  for (int c = 0; c < 4; c++)
+    for (int rr = 0; rr < 4; rr++)
+      for (int i = 0; i < 4; i++) ret[c][rr] += l[i][rr] * r[c][i];
+  return ret;
+}
+mat4 inverse(const mat4& m) {  // vecmath.cpp:103-132
+  mat4 r;
+  float det = 0;
+  for (int i = 0; i < 4; i++)
+    det += (m[(1 + i) % 4][0] *
+                (m[(2 + i) % 4][1] * m[(3 + i) % 4][2] - m[(3 + i) % 4][1] * m[(2 + i) % 4][2]) +
+            m[(2 + i) % 4][0] *
+                (m[(3 + i) % 4][1] * m[(1 + i) % 4][2] - m[(1 + i) % 4][1] * m[(3 + i) % 4][2]) +
+            m[(3 + i) % 4][0] *
+                (m[(1 + i) % 4][1] * m[(2 + i) % 4][2] - m[(2 + i) % 4][1] * m[(1 + i) % 4][2])) *
+           m[i % 4][3] * (i % 2 ? -1 : 1);
+  if (det == 0) return r;
+  for (int v = 0; v < 4; v++)
+    for (int i = 0; i < 4; i++)
+      r[v][i] = (m[(1 + i) % 4][(1 + v) % 4] *
+                     (m[(2 + i) % 4][(2 + v) % 4] * m[(3 + i) % 4][(3 + v) % 4] -
+                      m[(3 + i) % 4][(2 + v) % 4] * m[(2 + i) % 4][(3 + v) % 4]) +
+                 m[(2 + i) % 4][(1 + v) % 4] *
+                     (m[(3 + i) % 4][(2 + v) % 4] * m[(1 + i) % 4][(3 + v) % 4] -
+                      m[(1 + i) % 4][(2 + v) % 4] * m[(3 + i) % 4][(3 + v) % 4]) +
+                 m[(3 + i) % 4][(1 + v) % 4] *
+                     (m[(1 + i) % 4][(2 + v) % 4] * m[(2 + i) % 4][(3 + v) % 4] -
+                      m[(2 + i) % 4][(2 + v) % 4] * m[(1 + i) % 4][(3 + v) % 4])) *
+                ((v + i) % 2 ? 1 : -1);
+  for (int c = 0; c < 4; c++)
+    for (int rr = 0; rr < 4; rr++) r[c][rr] /= det;
+  return r;
+}
+mat3 inverse(const mat3& m) {  // vecmath.cpp:80-102
+  mat3 r;
+  float det = m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) +
+              m[1][0] * (m[2][1] * m[0][2] - m[0][1] * m[2][2]) +
+              m[2][0] * (m[0][1] * m[1][2] - m[1][1] * m[0][2]);
+  if (det == 0) return r;
+  r[0][0] = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+  r[0][1] = m[2][1] * m[0][2] - m[0][1] * m[2][2];
+  r[0][2] = m[0][1] * m[1][2] - m[1][1] * m[0][2];
+  r[1][0] = m[1][2] * m[2][0] - m[2][2] * m[1][0];
+  r[1][1] = m[2][2] * m[0][0] - m[0][2] * m[2][0];
+  r[1][2] = m[0][2] * m[1][0] - m[1][2] * m[0][0];
+  r[2][0] = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+  r[2][1] = m[2][0] * m[0][1] - m[0][0] * m[2][1];
+  r[2][2] = m[0][0] * m[1][1] - m[1][0] * m[0][1];
+  for (int c = 0; c < 3; c++)
+    for (int rr = 0; rr < 3; rr++) r[c][rr] /= det;
+  return r;
+}
+inline mat4 translate(vec3 v) {  // vecmath.h:1113
+  return {1.0f, 0.0f, 0.0f, v.x, 0.0f, 1.0f, 0.0f, v.y, 0.0f, 0.0f, 1.0f, v.z, 0.0f, 0.0f, 0.0f, 1.0f};
+}
+inline mat4 scale(vec3 v) {  // :1131
+  return {v.x, 0.0f, 0.0f, 0.0f, 0.0f, v.y, 0.0f, 0.0f, 0.0f, 0.0f, v.z, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+}
+inline mat4 rotate_z(float r) {  // :1140
+  return mat4{std::cos(r), -std::sin(r), 0, 0, std::sin(r), std::cos(r), 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+}
+inline mat4 rotate_x(float r) {  // :1149
+  return mat4{1, 0, 0, 0, 0, std::cos(r), -std::sin(r), 0, 0, std::sin(r), std::cos(r), 0, 0, 0, 0, 1};
+}
+inline mat4 rotate_y(float r) {  // :1158
+  return mat4{std::cos(r), 0, std::sin(r), 0, 0, 1, 0, 0, -std::sin(r), 0, std::cos(r), 0, 0, 0, 0, 1};
+}
+inline mat4 look_at(vec3 from, vec3 at, vec3 up = vec3(0, 1, 0)) {  // :1172-1180
+  vec3 z = normalize(at - from);
+  if (std::abs(dot(z, up)) > 0.999f) z = normalize(z + vec3(0.0f, 0.0f, 1e-5f));
+  vec3 x = normalize(cross(up, z));
+  vec3 y = cross(z, x);
+  return mat4(vec4(x, 0), vec4(y, 0), vec4(z, 0), vec4(from, 1.0f));
+}
+inline void coordinate_system(vec3 n, vec3& t, vec3& b) {  // :1182-1188
+  if (std::abs(n.x) > std::abs(n.y))
+    t = normalize(cross(n, vec3(0, 1, 0)));
+  else
+    t = normalize(cross(n, vec3(1, 0, 0)));
+  b = cross(n, t);
+}
+inline mat3 coordinate_system(vec3 n) {  // :1190-1195
+  mat3 m;
+  m.z = n;
+  coordinate_system(n, m.x, m.y);
+  return m;
+}
+inline float phi2pi(float x, float y) {  // :1209
+  float phi = std::atan2(y, x);
+  return phi < 0.0f ? Pi * 2 + phi : phi;
+}
+inline vec2 cartesian_to_spherical(vec3 d) { return vec2(phi2pi(d.x, d.y), std::acos(d.z)); }
+inline vec3 spherical_to_cartesian(float phi, float sin_theta, float cos_theta) {  // :1201
+  return vec3(sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta);
+}
+inline vec3 face_same_hemisphere(vec3 v, vec3 ref) { return dot(v, ref) < 0 ? -v : v; }  // :1220
+inline float safe_rcp(float v) { return v == 0.0f ? 1e+20f : 1.0f / v; }                  // :1062
+
+// ------------------------------------------------------------------------------------------------
+// hash / RNG (src/pine/core/rng.h:9-144)
+// ------------------------------------------------------------------------------------------------
+uint64_t murmur64A(const unsigned char* key, size_t len, uint64_t seed) {  // rng.h:9-49
+  const uint64_t m = 0xc6a4a7935bd1e995ull;
+  const int r = 47;
+  uint64_t h = seed ^ (len * m);
+  const unsigned char* end = key + 8 * (len / 8);
+  while (key != end) {
+    uint64_t k;
+    memcpy(&k, key, 8);
+    key += 8;
+    k *= m;
+    k ^= k >> r;
+    k *= m;
+    h ^= k;
+    h *= m;
+  }
+  switch (len & 7) {
+    case 7: h ^= uint64_t(key[6]) << 48; [[fallthrough]];
+    case 6: h ^= uint64_t(key[5]) << 40; [[fallthrough]];
+    case 5: h ^= uint64_t(key[4]) << 32; [[fallthrough]];
+    case 4: h ^= uint64_t(key[3]) << 24; [[fallthrough]];
+    case 3: h ^= uint64_t(key[2]) << 16; [[fallthrough]];
+    case 2: h ^= uint64_t(key[1]) << 8; [[fallthrough]];
+    case 1: h ^= uint64_t(key[0]); h *= m;
+  }
+  h ^= h >> r;
+  h *= m;
+  h ^= h >> r;
+  return h;
+}
+uint64_t hash_pixel(int px, int py, int sample_index) {  // hash(vec2i, int): rng.h:60-65
+  int buf[3] = {px, py, sample_index};
+  return murmur64A((const unsigned char*)buf, 12, 0);
+}
+struct RNG {  // rng.h:97-144
+  uint64_t s[2];
+  explicit RNG(uint64_t seed = 0) {
+    s[0] = split_mix(seed);
+    s[1] = split_mix(seed);
+  }
+  static uint64_t split_mix(uint64_t& st) {  // rng.h:72-77
+    uint64_t r = st += 0x9E3779B97f4A7C15ULL;
+    r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    r = (r ^ (r >> 27)) * 0x94D049BB133111EBULL;
+    return r ^ (r >> 31);
+  }
+  static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+  uint64_t next64u() {  // rng.h:116-126
+    const uint64_t s0 = s[0];
+    uint64_t s1 = s[1];
+    const uint64_t result = s0 + s1;
+    s1 ^= s0;
+    s[0] = rotl(s0, 24) ^ s1 ^ (s1 << 16);
+    s[1] = rotl(s1, 37);
+    return result;
+  }
+  float nextf() {  // rng.h:132-135
+    uint64_t u = next64u();
+    return fmin_(uint32_t(u ^ (u >> 32)) * 0x1p-32f, kOneMinusEps);
+  }
+  vec2 next2f() {  // braced init list: x first, then y (rng.h:136-138)
+    float a = nextf();
+    float b = nextf();
+    return {a, b};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// BlueSobolSampler + Sampler wrapper (sampler.h:166-201,275-324; sampler.cpp:115-143;
+// src/contrib/bluesobol/bluenoise_16spp.cpp:14-34)
+// ------------------------------------------------------------------------------------------------
+struct BlueTables {
+  const uint8_t* sobol = nullptr;     // [256*256]
+  const uint8_t* scramble = nullptr;  // [128*128*8] for the chosen spp
+  const uint8_t* rank = nullptr;      // [128*128*8]
+};
+int roundup2(int x) {  // src/psl/math.h:86-94
+  if (x == 0) return 0;
+  x -= 1;
+  for (size_t i = 1; i != sizeof(x) * 8; i <<= 1) x |= x >> i;
+  return x + 1;
+}
+int bluesobol_effective_spp(int spp) {  // sampler.cpp:115-121
+  if (spp > 256) spp = 256;
+  return roundup2(spp);
+}
+BlueTables select_tables(const uint8_t* blob, int spp_eff) {
+  int k = 0;
+  while ((1 << k) < spp_eff) k++;
+  BlueTables t;
+  t.sobol = blob;
+  t.scramble = blob + 65536 + size_t(k) * 262144;
+  t.rank = t.scramble + 131072;
+  return t;
+}
+struct Sampler {
+  BlueTables t;
+  int spp = 1;
+  int dimension = 0;
+  int px = 0, py = 0, index = 0;
+  RNG rng;
+  uint64_t* rng_draws = nullptr;
+
+  void start_pixel(int x, int y, int sample_index) {  // sampler.h:286-290 + :174-177
+    rng = RNG(hash_pixel(x, y, sample_index));
+    px = x;
+    py = y;
+    index = sample_index;  // NB: dimension is NOT reset here
+  }
+  void start_next_sample() {  // sampler.h:178-181
+    dimension = 0;
+    index++;
+  }
+  float sample_dimension(int dim) const {  // bluenoise_*spp.cpp:14-34
+    int pi = px & 127, pj = py & 127;
+    int si = index & 255;
+    int sd = dim & 255;
+    int ranked = si ^ t.rank[(sd + (pi + pj * 128) * 8) % (128 * 128 * 8)];
+    int value = t.sobol[sd + ranked * 256];
+    value = value ^ t.scramble[(sd % 8) + (pi + pj * 128) * 8];
+    return (0.5f + value) / 256.0f;
+  }
+  float get1d() {  // sampler.h:183-187
+    if (dimension >= 256) dimension = 2;
+    return sample_dimension(dimension++);
+  }
+  vec2 get2d() {  // sampler.h:188-194
+    if (dimension + 1 >= 256) dimension = 2;
+    int dim = dimension;
+    dimension += 2;
+    float a = sample_dimension(dim);
+    float b = sample_dimension(dim + 1);
+    return {a, b};
+  }
+  float randf() { return rng.nextf(); }
+  vec2 rand2f() { return rng.next2f(); }
+};
+// with_probability (sampler.h:317-324): draws from the RNG only when prob is strictly in (0,1)
+bool with_probability(float prob, Sampler& s) {
+  if (prob == 0) return false;
+  if (prob == 1) return true;
+  return s.randf() < prob;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling.h:8-89
+// ------------------------------------------------------------------------------------------------
+vec2 sample_disk_polar(vec2 u) {
+  float r = std::sqrt(u[0]);
+  float theta = 2 * Pi * u[1];
+  return {r * std::cos(theta), r * std::sin(theta)};
+}
+vec2 sample_disk_concentric(vec2 u) {
+  u = vec2(u.x * 2 - 1.0f, u.y * 2 - 1.0f);
+  float theta, r;
+  if (std::abs(u.x) > std::abs(u.y)) {
+    r = u.x;
+    theta = Pi / 4.0f * u.y / u.x;
+  } else {
+    r = u.y;
+    theta = Pi / 2.0f - Pi / 4.0f * (u.x / u.y);
+  }
+  return r * vec2(std::cos(theta), std::sin(theta));
+}
+vec3 cosine_weighted_hemisphere(vec2 u) {
+  vec2 d = sample_disk_concentric(u);
+  float z = std::sqrt(fmax_(1.0f - d.x * d.x - d.y * d.y, 0.0f));
+  return vec3(d.x, d.y, z);
+}
+vec3 uniform_sphere(vec2 u) {
+  const float phi = u.x * Pi * 2;
+  const float cos_theta = 1 - 2 * u.y;
+  const float sin_theta = std::sqrt(1.0f - sqr(cos_theta));
+  return vec3(sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta);
+}
+float balance_heuristic(float pF, float pG) { return pF / (pF + pG); }
+
+// ------------------------------------------------------------------------------------------------
+// Ray + spawn (src/pine/core/ray.h:8-57, interaction.cpp:6-13)
+// ------------------------------------------------------------------------------------------------
+struct Ray {
+  vec3 o, d;
+  float tmin = 0.0f, tmax = kFloatMax;
+  Ray() = default;
+  Ray(vec3 o, vec3 d) : o(o), d(d) {}
+  Ray(vec3 o, vec3 d, float tmin, float tmax) : o(o), d(d), tmin(tmin), tmax(tmax) {}
+  vec3 operator()() const { return o + tmax * d; }
+  vec3 operator()(float t) const { return o + t * d; }
+};
+inline float bits_add(float f, int di) {
+  int32_t b;
+  memcpy(&b, &f, 4);
+  b += di;
+  memcpy(&f, &b, 4);
+  return f;
+}
+vec3 offset_ray_origin(vec3 p, vec3 n) {  // ray.h:25-37 (integer ULP stepping)
+  const float origin = 1.0f / 32.0f;
+  const float float_scale = 1.0f / 65536.0f;
+  const float int_scale = 256.0f;
+  int ox = int(int_scale * n.x), oy = int(int_scale * n.y), oz = int(int_scale * n.z);
+  vec3 p_i(bits_add(p.x, p.x < 0 ? -ox : ox), bits_add(p.y, p.y < 0 ? -oy : oy),
+           bits_add(p.z, p.z < 0 ? -oz : oz));
+  return {std::abs(p.x) < origin ? p.x + n.x * float_scale : p_i.x,
+          std::abs(p.y) < origin ? p.y + n.y * float_scale : p_i.y,
+          std::abs(p.z) < origin ? p.z + n.z * float_scale : p_i.z};
+}
+Ray spawn_ray_pn(vec3 p, vec3 n, vec3 wo, float dist = kFloatMax) {  // ray.h:39-46
+  Ray r;
+  r.o = offset_ray_origin(p, n);
+  r.d = wo;
+  r.tmin = 0.0f;
+  r.tmax = dist * (1.0f - 1e-3f);
+  return r;
+}
+
+struct SurfaceInteraction {  // interaction.h:9-33
+  vec3 p, n;
+  vec2 uv;
+  mat3 w2l, l2w;
+  int geom = -1;
+  void compute_transformation() {
+    l2w = coordinate_system(n);
+    w2l = transpose(l2w);
+  }
+  vec3 to_world(vec3 w) const { return l2w * w; }
+  vec3 to_local(vec3 w) const { return w2l * w; }
+  Ray spawn_ray(vec3 wo, float tmax = kFloatMax) const {  // interaction.cpp:6-13
+    Ray r;
+    r.d = wo;
+    r.o = offset_ray_origin(p, face_same_hemisphere(n, r.d));
+    r.tmin = 0.0f;
+    r.tmax = tmax * (1.0f - 1e-3f);
+    return r;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// AABB (bbox.h:29-84, bbox.cpp:8-143)
+// ------------------------------------------------------------------------------------------------
+struct RayOctant {  // bbox.h:18-27
+  int octantx3[3];
+  vec3 dir_inv, org_div_dir;
+  explicit RayOctant(const Ray& r) {
+    for (int i = 0; i < 3; i++) octantx3[i] = (r.d[i] < 0 ? 1 : 0) * 3;
+    dir_inv = vec3(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
+    org_div_dir = r.o * dir_inv;
+  }
+};
+struct AABB {
+  vec3 lower{kFloatMax, kFloatMax, kFloatMax}, upper{-kFloatMax, -kFloatMax, -kFloatMax};
+  AABB() = default;
+  AABB(vec3 lo, vec3 hi) : lower(lo), upper(hi) {}
+  vec3 centroid() const { return (lower + upper) / 2.0f; }
+  float centroid(int d) const { return (lower[d] + upper[d]) / 2; }
+  vec3 diagonal() const { return upper - lower; }
+  float surface_area() const {  // bbox.cpp:37-40
+    vec3 d = diagonal();
+    return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z);
+  }
+  float area() const {  // bbox.cpp:139-142
+    vec3 d = diagonal();
+    return 2 * (d.x * d.y + d.x * d.z + d.y * d.z);
+  }
+  AABB& extend(vec3 p) {
+    lower = vmin(lower, p);
+    upper = vmax(upper, p);
+    return *this;
+  }
+  AABB& extend(const AABB& b) {
+    lower = vmin(lower, b.lower);
+    upper = vmax(upper, b.upper);
+    return *this;
+  }
+  AABB& extend_by(float a) {
+    lower = lower - vec3(a);
+    upper = upper + vec3(a);
+    return *this;
+  }
+  bool degenerated(int d) const { return upper[d] <= lower[d]; }
+  float relative_position(float p, int dim) const {  // bbox.cpp:32-36
+    float o = p - lower[dim];
+    float d = upper[dim] - lower[dim];
+    return d > 0.0f ? o / d : o;
+  }
+  // slab test used by the BVH (bbox.h:59-72)
+  bool hit(const RayOctant& r, float tmin, float& tmax) const {
+    const float* p = &lower.x;  // lower(3) then upper(3), contiguous
+    float q[6] = {lower.x, lower.y, lower.z, upper.x, upper.y, upper.z};
+    (void)p;
+    float tmin0 = q[0 + r.octantx3[0]] * r.dir_inv[0] - r.org_div_dir[0];
+    float tmin1 = q[1 + r.octantx3[1]] * r.dir_inv[1] - r.org_div_dir[1];
+    float tmin2 = q[2 + r.octantx3[2]] * r.dir_inv[2] - r.org_div_dir[2];
+    float tmax0 = q[3 - r.octantx3[0]] * r.dir_inv[0] - r.org_div_dir[0];
+    float tmax1 = q[4 - r.octantx3[1]] * r.dir_inv[1] - r.org_div_dir[1];
+    float tmax2 = q[5 - r.octantx3[2]] * r.dir_inv[2] - r.org_div_dir[2];
+    // psl::max(a,b,c,d) = max(a, max(b, max(c, d))) (src/psl/math.h:52-61)
+    tmin = fmax_(tmin0, fmax_(tmin1, fmax_(tmin2, tmin)));
+    tmax = fmin_(tmax0, fmin_(tmax1, fmin_(tmax2, tmax)));
+    return tmin <= tmax;
+  }
+  bool hit(const Ray& ray) const {  // bbox.cpp:75-93
+    float tmin = ray.tmin, tmax = ray.tmax;
+    if (tmin > tmax) return false;
+    for (int i = 0; i < 3; i++) {
+      if (std::abs(ray.d[i]) < 1e-6f) {
+        if (ray.o[i] < lower[i] || ray.o[i] > upper[i]) return false;
+        continue;
+      }
+      float inv_d = 1.0f / ray.d[i];
+      float t_near = (lower[i] - ray.o[i]) * inv_d;
+      float t_far = (upper[i] - ray.o[i]) * inv_d;
+      if (inv_d < 0.0f) std::swap(t_far, t_near);
+      tmin = fmax_(t_near, tmin);
+      tmax = fmin_(t_far, tmax);
+      if (tmin > tmax) return false;
+    }
+    return true;
+  }
+  bool intersect(vec3 o, vec3 d, float& tmin, float& tmax) const {  // bbox.cpp:94-111
+    for (int i = 0; i < 3; i++) {
+      if (std::abs(d[i]) < 1e-6f) {
+        if (o[i] < lower[i] || o[i] > upper[i]) return false;
+        continue;
+      }
+      float inv_d = 1.0f / d[i];
+      float t_near = (lower[i] - o[i]) * inv_d;
+      float t_far = (upper[i] - o[i]) * inv_d;
+      if (inv_d < 0.0f) std::swap(t_far, t_near);
+      tmin = fmax_(t_near, tmin);
+      tmax = fmin_(t_far, tmax);
+      if (tmin > tmax) return false;
+    }
+    return true;
+  }
+  bool intersect(Ray& ray) const {  // bbox.cpp:112-121
+    float tmin = ray.tmin, tmax = ray.tmax;
+    if (intersect(ray.o, ray.d, tmin, tmax)) {
+      ray.tmax = tmin > ray.tmin ? tmin : tmax;
+      return true;
+    }
+    return false;
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {  // bbox.cpp:122-129
+    it.p = p;
+    vec3 pu = (p - centroid()) / diagonal();
+    int axis = max_axis(vabs(pu));
+    it.n = vec3(0.0f);
+    it.n[axis] = pu[axis] > 0 ? 1 : -1;
+    it.p[axis] = pu[axis] > 0 ? upper[axis] : lower[axis];
+  }
+};
+inline AABB union_(AABB l, AABB r) { return {vmin(l.lower, r.lower), vmax(l.upper, r.upper)}; }
+
+// ------------------------------------------------------------------------------------------------
+// Shapes (geometry.h / geometry.cpp / bbox.cpp)
+// ------------------------------------------------------------------------------------------------
+struct ShapeSample {  // bbox.h:8-16
+  vec3 p, n;
+  vec2 uv;
+  vec3 w;
+  float distance = 0.0f, pdf = 0.0f;
+};
+bool intersect_quadratic(float a, float b, float c, float tmin, float& tmax) {  // geometry.cpp:20-29
+  float d = b * b - 4 * a * c;
+  if (d <= 0.0f) return false;
+  d = std::sqrt(d);
+  float t = (-b - d) / (2 * a);
+  if (t < tmin) t += d / a;
+  if (t < tmin || t > tmax) return false;
+  tmax = t;
+  return true;
+}
+
+struct Rect {  // geometry.cpp:255-408
+  vec3 position, ex, ey, n;
+  float lx, ly;
+  vec3 rx, ry;
+  Rect(vec3 position_, vec3 ex_, vec3 ey_, bool flip) : position(position_) {
+    ex = normalize(ex_);
+    ey = normalize(ey_);
+    n = normalize(cross(ex, ey)) * float(flip ? -1 : 1);
+    lx = length(ex_);
+    ly = length(ey_);
+    rx = ex / lx;
+    ry = ey / ly;
+  }
+  float area() const { return lx * ly; }
+  bool hit(const Ray& ray) const {  // :275-286
+    float denom = dot(ray.d, n);
+    if (denom == 0.0f) return false;
+    float t = (dot(position - ray.o, n)) / denom;
+    if (t <= ray.tmin || t >= ray.tmax) return false;
+    vec3 p = ray(t) - position;
+    float u = dot(p, rx);
+    if (u < -0.5f || u > 0.5f) return false;
+    float v = dot(p, ry);
+    if (v < -0.5f || v > 0.5f) return false;
+    return true;
+  }
+  bool intersect(Ray& ray) const {  // :287-299
+    float denom = dot(ray.d, n);
+    if (denom == 0.0f) return false;
+    float t = (dot(position - ray.o, n)) / denom;
+    if (t <= ray.tmin || t >= ray.tmax) return false;
+    vec3 p = ray(t) - position;
+    float u = dot(p, rx);
+    if (u < -0.5f || u > 0.5f) return false;
+    float v = dot(p, ry);
+    if (v < -0.5f || v > 0.5f) return false;
+    ray.tmax = t;
+    return true;
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {  // :300-307
+    vec3 rp = p - position;
+    float u = dot(rp, rx);
+    float v = dot(rp, ry);
+    it.p = position + lx * ex * u + ly * ey * v;
+    it.n = n;
+    it.uv = vec2(u, v) + vec2(0.5f, 0.5f);
+  }
+  ShapeSample sample(vec3 o, vec2 u) const {  // :308-316
+    ShapeSample ss;
+    ss.p = position + (u[0] - 0.5f) * ex * lx + (u[1] - 0.5f) * ey * ly;
+    ss.n = n;
+    ss.uv = u;
+    ss.w = normalize(ss.p - o, ss.distance);
+    ss.pdf = sqr(ss.distance) / (absdot(ss.w, ss.n) * area());
+    return ss;
+  }
+  float pdf(const Ray& ray, vec3 ns) const {  // :368-370  (NB multiplies by cos -- Appendix A4)
+    return sqr(ray.tmax) / area() * absdot(ns, ray.d);
+  }
+  AABB get_aabb() const {  // :401-408
+    AABB b;
+    b.extend(position - ex * lx / 2.0f - ey * ly / 2.0f);
+    b.extend(position - ex * lx / 2.0f + ey * ly / 2.0f);
+    b.extend(position + ex * lx / 2.0f - ey * ly / 2.0f);
+    b.extend(position + ex * lx / 2.0f + ey * ly / 2.0f);
+    return b;
+  }
+};
+
+struct OBB {  // bbox.cpp:144-182
+  AABB base;
+  mat4 m, m_inv;
+  OBB(AABB b, mat4 m_) : base(b), m(m_), m_inv(inverse(m_)) {}
+  bool hit(Ray ray) const {  // :145-149
+    ray.o = m_inv * ray.o;
+    ray.d = normalize(to_mat3(m_inv) * ray.d);
+    return base.hit(ray);
+  }
+  bool intersect(vec3 o, vec3 d, float& tmin, float& tmax) const {  // :150-163
+    vec3 org = o;
+    o = m_inv * o;
+    d = normalize(to_mat3(m_inv) * d);
+    if (base.intersect(o, d, tmin, tmax)) {
+      vec3 ps = o + tmin * d;
+      vec3 pe = o + tmax * d;
+      tmin = distance(m * ps, org);
+      tmax = distance(m * pe, org);
+      return true;
+    }
+    return false;
+  }
+  bool intersect(Ray& ray) const {  // :164-172
+    float tmin = ray.tmin, tmax = ray.tmax;
+    if (intersect(ray.o, ray.d, tmin, tmax)) {
+      ray.tmax = tmin > ray.tmin ? tmin : tmax;
+      return true;
+    }
+    return false;
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {  // :173-177
+    base.compute_surface_info(m_inv * p, it);
+    it.p = m * it.p;
+    it.n = normalize(transpose(to_mat3(m_inv)) * it.n);
+  }
+  AABB get_aabb() const {  // bbox.cpp:8-16 (no epsilon pad, bbox.h:93)
+    AABB r;
+    for (int i = 0; i < 8; i++) {
+      vec3 p = base.lower;
+      if (i % 2 >= 1) p[0] = base.upper[0];
+      if (i % 4 >= 2) p[1] = base.upper[1];
+      if (i % 8 >= 4) p[2] = base.upper[2];
+      r.extend(m * p);
+    }
+    return r;
+  }
+};
+
+struct Sphere {  // geometry.cpp:72-121
+  vec3 c;
+  float r;
+  static float compute_t(vec3 ro, vec3 rd, float tmin, vec3 p, float r) {  // :73-83
+    vec3 ro_p = ro - p;
+    float b = dot(ro_p, rd);
+    float c = dot(ro_p, ro_p) - r * r;
+    float d = b * b - c;
+    if (d <= 0.0f) return -1.0f;
+    d = std::sqrt(d);
+    float t = -b - d;
+    if (t < tmin) t = -b + d;
+    return t;
+  }
+  bool hit(const Ray& ray) const {
+    float t = compute_t(ray.o, ray.d, ray.tmin, c, r);
+    return t > ray.tmin && t < ray.tmax;
+  }
+  bool intersect(Ray& ray) const {
+    float t = compute_t(ray.o, ray.d, ray.tmin, c, r);
+    if (t < ray.tmin || t > ray.tmax) return false;
+    ray.tmax = t;
+    return true;
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {  // :94-98
+    it.n = normalize(p - c);
+    it.p = c + it.n * r;
+    it.uv = cartesian_to_spherical(it.n);
+  }
+  ShapeSample sample(vec3 p, vec2 u) const {  // :99-114
+    ShapeSample ss;
+    float l = length(c - p);
+    float cos_theta = std::sqrt(1 - sqr(r / l));
+    float S = 2 * Pi * (1 - cos_theta);
+    float cos_theta_wo = 1 - u.y * (1 - cos_theta);
+    float sin_theta_wo = std::sqrt(1 - cos_theta_wo * cos_theta_wo);
+    ss.w = spherical_to_cartesian(u.x * 2 * Pi, sin_theta_wo, cos_theta_wo);
+    ss.w = coordinate_system((c - p) / l) * ss.w;
+    ss.distance = compute_t(p, ss.w, 0.0f, c, r);
+    ss.pdf = 1.0f / S;
+    ss.p = p + ss.w * ss.distance;
+    ss.n = (ss.p - c) / r;
+    ss.uv = cartesian_to_spherical(ss.n);
+    return ss;
+  }
+  float pdf(const Ray& ray) const {  // :115-120
+    float l = length(c - ray.o);
+    float cos_theta = std::sqrt(1 - sqr(r / l));
+    float S = 2 * Pi * (1 - cos_theta);
+    return 1.0f / S;
+  }
+  AABB get_aabb() const { return {c - vec3(r), c + vec3(r)}; }
+};
+
+struct Disk {  // geometry.cpp:123-169
+  vec3 position, n, u, v;
+  float r;
+  Disk(vec3 p, vec3 normal, float r) : position(p), n(normalize(normal)), r(r) {
+    coordinate_system(n, u, v);
+  }
+  float area() const { return Pi * r * r; }
+  bool hit(const Ray& ray) const {  // :128-137
+    float denom = dot(ray.d, n);
+    if (denom == 0.0f) return false;
+    float t = (dot(position, n) - dot(ray.o, n)) / denom;
+    if (t < ray.tmin) return false;
+    if (t >= ray.tmax) return false;
+    vec3 p = ray(t) - position;
+    if (length_squared(p) > sqr(r)) return false;
+    return true;
+  }
+  bool intersect(Ray& ray) const {  // :138-148
+    float denom = dot(ray.d, n);
+    if (denom == 0.0f) return false;
+    float t = (dot(position, n) - dot(ray.o, n)) / denom;
+    if (t < ray.tmin || t > ray.tmax) return false;
+    vec3 p = ray(t) - position;
+    if (length_squared(p) > sqr(r)) return false;
+    ray.tmax = t;
+    return true;
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {  // :149-155
+    it.n = n;
+    float ex = dot(p - position, u);
+    float ey = dot(p - position, v);
+    it.uv = {ex, ey};
+    it.p = position + ex * u + ey * v;
+  }
+  ShapeSample sample(vec3 p, vec2 u2) const {  // :156-165
+    ShapeSample ss;
+    vec2 uv = sample_disk_concentric(u2);
+    ss.p = position + r * u * uv[0] + r * v * uv[1];
+    ss.n = n;
+    ss.uv = u2;
+    ss.w = normalize(ss.p - p, ss.distance);
+    ss.pdf = sqr(ss.distance) / fmax_(absdot(ss.w, ss.n) * area(), kEpsilon);
+    return ss;
+  }
+  float pdf(const Ray& ray, vec3 ns) const {  // :166-168
+    return sqr(ray.tmax) / (area() * absdot(ns, ray.d));
+  }
+  AABB get_aabb() const { return Sphere{position, r}.get_aabb(); }  // :169
+};
+
+struct Cone {  // geometry.cpp:409-464, geometry.h:122-142
+  Disk bottom;
+  vec3 p, n;
+  float r, h, A, A2, S;
+  Cone(vec3 p_, vec3 n_, float r, float h)
+      : bottom(p_, n_, r), p(p_ + n_ * h), n(normalize(n_)), r(r), h(h) {
+    A2 = sqr(r / h) + 1;
+    A = std::sqrt(A2);
+    S = r / std::sqrt(r * r + h * h);
+  }
+  float area() const { return std::sqrt(r * r + h * h) * Pi * r + bottom.area(); }
+  bool hit(const Ray& ray) const {  // :415-427
+    vec3 o = ray.o - p;
+    const vec3& d = ray.d;
+    float a = -A2 * sqr(dot(d, n)) + dot(d, d);
+    float b = 2 * (-A2 * dot(o, n) * dot(d, n) + dot(o, d));
+    float c = -A2 * sqr(dot(o, n)) + dot(o, o);
+    float tmax = ray.tmax;
+    return intersect_quadratic(a, b, c, ray.tmin, tmax) && dot(o + tmax * d, n) <= 0;
+  }
+  bool intersect(Ray& ray) const {  // :428-454
+    vec3 o = ray.o - p;
+    const vec3& d = ray.d;
+    float a = -A2 * sqr(dot(d, n)) + dot(d, d);
+    float b = 2 * (-A2 * dot(o, n) * dot(d, n) + dot(o, d));
+    float c = -A2 * sqr(dot(o, n)) + dot(o, o);
+    float tmax = ray.tmax;
+    if (intersect_quadratic(a, b, c, ray.tmin, tmax) && dot(o + tmax * d, n) < 0) {
+      ray.tmax = tmax;
+      return true;
+    }
+    return false;
+  }
+  void compute_surface_info(vec3 ps, SurfaceInteraction& it) const {  // :455-460
+    float l = length(ps - p) * A;
+    vec3 x = p - n * l;
+    it.n = normalize(ps - x);
+    it.p = x + it.n * l * S;
+  }
+  float pdf(const Ray& ray, vec3 ns) const {  // :462-464
+    return sqr(ray.tmax) / area() * absdot(ns, ray.d);
+  }
+  AABB get_aabb() const { return bottom.get_aabb().extend(p); }  // geometry.h:129
+};
+
+struct Tri {  // geometry.cpp:525-599 (static helpers)
+  static bool hit(const Ray& ray, vec3 v0, vec3 v1, vec3 v2) {  // :532-547
+    vec3 E1 = v1 - v0, E2 = v2 - v0, T = ray.o - v0;
+    vec3 P = cross(ray.d, E2), Q = cross(T, E1);
+    float D = dot(P, E1);
+    if (D == 0.0f) return false;
+    float t = dot(Q, E2) / D;
+    if (t < ray.tmin || t > ray.tmax) return false;
+    float u = dot(P, T) / D;
+    if (u < 0.0f || u > 1.0f) return false;
+    float v = dot(Q, ray.d) / D;
+    if (v < 0.0f || v > 1.0f) return false;
+    return u + v < 1.0f;
+  }
+  static bool intersect(Ray& ray, vec3 v0, vec3 v1, vec3 v2) {  // :548-565
+    vec3 E1 = v1 - v0, E2 = v2 - v0, T = ray.o - v0;
+    vec3 P = cross(ray.d, E2), Q = cross(T, E1);
+    float D = dot(P, E1);
+    if (D == 0.0f) return false;
+    float t = dot(Q, E2) / D;
+    if (t <= ray.tmin || t >= ray.tmax) return false;
+    float u = dot(P, T) / D;
+    if (u < 0.0f || u > 1.0f) return false;
+    float v = dot(Q, ray.d) / D;
+    if (v < 0.0f || v > 1.0f) return false;
+    if (u + v > 1.0f) return false;
+    ray.tmax = t;
+    return true;
+  }
+};
+
+struct BVHImpl;
+struct Mesh {  // geometry.h:158-232, geometry.cpp:601-650
+  std::vector<vec3> vertices;
+  std::vector<uint32_t> indices;  // 3 per face
+  std::shared_ptr<BVHImpl> bvh;   // per-mesh BVH (bvh.cpp:459-475 == ShapeBVH, :549-567)
+  size_t num_triangles() const { return indices.size() / 3; }
+  void face(size_t i, vec3& a, vec3& b, vec3& c) const {
+    a = vertices[indices[3 * i]];
+    b = vertices[indices[3 * i + 1]];
+    c = vertices[indices[3 * i + 2]];
+  }
+  bool hit(const Ray& ray, int i) const {
+    vec3 a, b, c;
+    face(i, a, b, c);
+    return Tri::hit(ray, a, b, c);
+  }
+  bool intersect(Ray& ray, int i) const {
+    vec3 a, b, c;
+    face(i, a, b, c);
+    return Tri::intersect(ray, a, b, c);
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it, int i) const {  // :632-646
+    vec3 v0, v1, v2;
+    face(i, v0, v1, v2);
+    vec3 e1 = v1 - v0, e2 = v2 - v0;
+    it.n = cross(e1, e2);
+    mat3 tbn = inverse(mat3(e1, e2, it.n));
+    vec3 q = tbn * (p - v0);
+    it.uv = vec2(q.x, q.y);
+    it.p = lerp3(it.uv[0], it.uv[1], v0, v1, v2);
+    it.n = normalize(it.n);
+  }
+  AABB get_aabb(size_t i) const {  // :647-652
+    vec3 a, b, c;
+    face(i, a, b, c);
+    AABB r;
+    r.extend(a);
+    r.extend(b);
+    r.extend(c);
+    return r;
+  }
+  float tri_area(size_t i) const {  // geometry.h:118
+    vec3 a, b, c;
+    face(i, a, b, c);
+    return length(cross(b - a, c - a)) / 2;
+  }
+  float area() const { return tri_area(0) * num_triangles(); }  // geometry.h:167-169 (quirk A4)
+  float pdf(const Ray& ray, vec3 ns) const {                    // geometry.h:180-182
+    return sqr(ray.tmax) / (area() * absdot(ns, ray.d));
+  }
+  ShapeSample sample_tri(size_t i, vec3 p, vec2 u) const {  // Triangle::sample geometry.cpp:575-584
+    vec3 v0, v1, v2;
+    face(i, v0, v1, v2);
+    vec3 n = normalize(cross(v0 - v1, v0 - v2));  // Triangle(v0,v1,v2) ctor :528-531
+    if (n.is_zero()) n = vec3(0, 0, 1);
+    ShapeSample ss;
+    if (u.x + u.y > 1.0f) u = vec2(1.0f, 1.0f) - u;
+    ss.p = lerp3(u.x, u.y, v0, v1, v2);
+    ss.n = n;
+    ss.uv = u;
+    ss.w = normalize(ss.p - p, ss.distance);
+    float a = length(cross(v1 - v0, v2 - v0)) / 2;
+    ss.pdf = sqr(ss.distance) / fmax_(absdot(ss.w, ss.n) * a, kEpsilon);
+    return ss;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Materials / BXDFs (material.h, material.cpp, bxdf.h, bxdf.cpp, scattering.h)
+// ------------------------------------------------------------------------------------------------
+inline float CosTheta(vec3 w) { return w.z; }
+inline float Cos2Theta(vec3 w) { return sqr(w.z); }
+inline float AbsCosTheta(vec3 w) { return std::abs(w.z); }
+inline float Sin2Theta(vec3 w) { return 1.0f - Cos2Theta(w); }
+inline float SinTheta(vec3 w) { return std::sqrt(Sin2Theta(w)); }
+inline float Tan2Theta(vec3 w) { return Sin2Theta(w) / fmax_(Cos2Theta(w), kEpsilon); }
+inline float CosPhi(vec3 w) {
+  float s = SinTheta(w);
+  return (s == 0) ? 1 : clampf(w.x / s, -1.0f, 1.0f);
+}
+inline float SinPhi(vec3 w) {
+  float s = SinTheta(w);
+  return (s == 0) ? 1 : clampf(w.y / s, -1.0f, 1.0f);
+}
+inline bool SameHemisphere(vec3 a, vec3 b) { return a.z * b.z > 0.0f; }
+inline vec3 FaceNormal(vec3 v) { return v.z < 0.0f ? -v : v; }
+inline vec3 Reflect(vec3 w) { return vec3(-w.x, -w.y, w.z); }
+inline vec3 Reflect(vec3 wi, vec3 n) { return 2.0f * dot(wi, n) * n - wi; }
+bool Refract(vec3 wi, vec3 n, float eta, vec3& wt, float* etap = nullptr) {  // scattering.h:58-77
+  float cosThetaI = dot(n, wi);
+  if (cosThetaI < 0) {
+    eta = 1.0f / eta;
+    cosThetaI = -cosThetaI;
+    n = -n;
+  }
+  float sin2ThetaI = fmax_(0.0f, 1.0f - sqr(cosThetaI));
+  float sin2ThetaT = sin2ThetaI / sqr(eta);
+  if (sin2ThetaT >= 1) return false;
+  float cosThetaT = std::sqrt(1.0f - sin2ThetaT);
+  wt = -wi / eta + (cosThetaI / eta - cosThetaT) * n;
+  if (etap) *etap = eta;
+  return true;
+}
+float FrDielectric(float cosThetaI, float eta) {  // scattering.h:79-94
+  if (cosThetaI < 0) {
+    eta = 1 / eta;
+    cosThetaI = -cosThetaI;
+  }
+  float sin2ThetaI = 1.0f - sqr(cosThetaI);
+  float sin2ThetaT = sin2ThetaI / sqr(eta);
+  if (sin2ThetaT >= 1.0f) return 1.0f;
+  float cosThetaT = std::sqrt(1.0f - sin2ThetaT);
+  float rParl = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+  float rPerp = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+  return (sqr(rParl) + sqr(rPerp)) / 2.0f;
+}
+vec3 FrSchlick(vec3 F0, float cosTheta) {  // scattering.h:96-98
+  return F0 + (vec3(1.0f) - F0) * std::pow(1.0f - cosTheta, 5.0f);
+}
+struct TRDist {  // scattering.h:100-150
+  float ax, ay;
+  float D(vec3 wm) const {
+    float tan2Theta = Tan2Theta(wm);
+    float cos4Theta = sqr(Cos2Theta(wm));
+    if (cos4Theta < 1e-6f) return 0.0f;
+    float e = tan2Theta * (sqr(CosPhi(wm) / ax) + sqr(SinPhi(wm) / ay));
+    return 1.0f / (Pi * ax * ay * cos4Theta * sqr(1 + e));
+  }
+  float Lambda(vec3 w) const {
+    float tan2Theta = Tan2Theta(w);
+    float alpha2 = sqr(CosPhi(w) * ax) + sqr(SinPhi(w) * ay);
+    return (std::sqrt(1.0f + alpha2 * tan2Theta) - 1.0f) / 2.0f;
+  }
+  float G1(vec3 w) const { return 1.0f / (1.0f + Lambda(w)); }
+  float G(vec3 wi, vec3 wo) const { return 1.0f / (1.0f + Lambda(wi) + Lambda(wo)); }
+  float D_G(vec3 wi, vec3 wm, vec3 wo) const { return D(wm) * G(wi, wo); }
+  float D(vec3 w, vec3 wm) const { return G1(w) / AbsCosTheta(w) * D(wm) * absdot(w, wm); }
+  float pdf(vec3 w, vec3 wm) const { return fmax_(D(w, wm), kEpsilon); }
+  vec3 SampleWm(vec3 w, vec2 u) const {
+    vec3 wh = normalize(vec3(ax * w.x, ay * w.y, w.z));
+    if (wh.z < 0.0f) wh = -wh;
+    vec3 T1 = (wh.z < 0.99999f) ? normalize(cross(vec3(0, 0, 1), wh)) : vec3(1, 0, 0);
+    vec3 T2 = cross(wh, T1);
+    vec2 p = sample_disk_polar(u);
+    float h = std::sqrt(1.0f - sqr(p.x));
+    // psl::lerp(t, a, b) = a * (1 - t) + b * t (src/psl/math.h:118-121)
+    float t = (1.0f + wh.z) / 2;
+    p.y = h * (1.0f - t) + p.y * t;
+    float pz = std::sqrt(fmax_(0.0f, 1.0f - (p.x * p.x + p.y * p.y)));
+    vec3 nh = p.x * T1 + p.y * T2 + pz * wh;
+    return normalize(vec3(ax * nh.x, ay * nh.y, fmax_(1e-6f, nh.z)));
+  }
+};
+
+struct BSDFSample {
+  vec3 wo, f;
+  float pdf = 0.0f;
+  bool is_delta = false;
+};
+enum BxdfKind { BX_DIFFUSE, BX_CONDUCTOR, BX_REFRACTIVE, BX_REFR_DIEL, BX_DIFF_DIEL, BX_BSSRDF };
+struct BXDF {  // bxdf.h:36-157 flattened into one tagged struct
+  BxdfKind kind = BX_DIFFUSE;
+  vec3 albedo;
+  float roughness = 0, ior = 1;
+  vec3 sigma_s;
+  vec3 wi;  // local
+  bool is_delta() const {
+    switch (kind) {
+      case BX_DIFFUSE: case BX_DIFF_DIEL: case BX_BSSRDF: return false;
+      default: return roughness < 1e-2f;
+    }
+  }
+  bool sample(Sampler& sampler, BSDFSample& bs) const;
+  vec3 f(vec3 wo) const;
+  float pdf(vec3 wo) const;
+};
+bool BXDF::sample(Sampler& sampler, BSDFSample& bs) const {
+  switch (kind) {
+    case BX_DIFFUSE: {  // bxdf.cpp:11-23
+      vec3 wo = cosine_weighted_hemisphere(sampler.get2d());
+      if (CosTheta(wi) < 0) wo = -wo;
+      bs.wo = wo;
+      bs.pdf = AbsCosTheta(bs.wo) / Pi;
+      bs.f = albedo / Pi;
+      return true;
+    }
+    case BX_CONDUCTOR: {  // bxdf.cpp:39-64
+      float alpha = sqr(roughness);
+      if (alpha < 1e-4f) {
+        bs.wo = Reflect(wi);
+        bs.f = FrSchlick(albedo, AbsCosTheta(bs.wo)) / AbsCosTheta(bs.wo);
+        bs.pdf = 1.0f;
+        bs.is_delta = true;
+        return true;
+      }
+      TRDist distrib{alpha, alpha};
+      vec3 wm = distrib.SampleWm(wi, sampler.get2d());
+      vec3 wo = Reflect(wi, wm);
+      if (!SameHemisphere(wi, wo)) return false;
+      vec3 fr = FrSchlick(albedo, absdot(wi, wm));
+      bs.wo = wo;
+      bs.pdf = distrib.pdf(wi, wm) / (4 * absdot(wi, wm));
+      bs.f = fr * (distrib.D_G(wo, wm, wi) / (4 * CosTheta(wi) * CosTheta(wo)));
+      return true;
+    }
+    case BX_REFRACTIVE: {  // bxdf.cpp:102-124
+      float alpha = sqr(roughness);
+      if (alpha < 1e-4f) {
+        bs.wo = Reflect(wi);
+        bs.f = albedo;
+        bs.pdf = AbsCosTheta(bs.wo);
+        bs.is_delta = true;
+        return true;
+      }
+      TRDist distrib{alpha, alpha};
+      vec3 wm = distrib.SampleWm(wi, sampler.get2d());
+      vec3 wo = Reflect(wi, wm);
+      if (!SameHemisphere(wi, wo)) return false;
+      bs.wo = wo;
+      bs.pdf = distrib.pdf(wi, wm) / (4 * absdot(wi, wm));
+      bs.f = albedo * (distrib.D_G(wo, wm, wi) / (4 * CosTheta(wi) * CosTheta(wo)));
+      return true;
+    }
+    case BX_REFR_DIEL: {  // bxdf.cpp:162-208
+      float fr = FrDielectric(CosTheta(wi), ior);
+      float alpha = sqr(roughness);
+      if (alpha < 1e-4f) {
+        if (sampler.get1d() < fr) {
+          bs.wo = Reflect(wi);
+          bs.f = albedo * (fr / AbsCosTheta(bs.wo));
+          bs.pdf = fr;
+          bs.is_delta = true;
+        } else {
+          if (!Refract(wi, vec3(0, 0, 1), ior, bs.wo)) return false;
+          bs.f = albedo * ((1 - fr) / AbsCosTheta(bs.wo));
+          bs.pdf = 1 - fr;
+          bs.is_delta = true;
+        }
+        return true;
+      }
+      TRDist distrib{alpha, alpha};
+      vec3 wm = distrib.SampleWm(wi, sampler.get2d());
+      if (sampler.get1d() < fr) {
+        vec3 wo = Reflect(wi, wm);
+        if (!SameHemisphere(wi, wo)) return false;
+        bs.wo = wo;
+        bs.pdf = fr * distrib.pdf(wi, wm) / (4 * absdot(wi, wm));
+        bs.f = albedo * (fr * distrib.D_G(wo, wm, wi) / (4 * CosTheta(wi) * CosTheta(wo)));
+      } else {
+        float eta = 1.0f;
+        if (!Refract(wi, wm, ior, bs.wo, &eta)) return false;
+        const vec3& wo = bs.wo;
+        float denom = sqr(dot(wo, wm) + dot(wi, wm) / eta);
+        bs.pdf = (1 - fr) * distrib.pdf(wi, wm) * absdot(wo, wm) / denom;
+        bs.f = albedo * ((1 - fr) * distrib.D(wm) * distrib.G(wi, wo) *
+                         std::abs(dot(wo, wm) * dot(wi, wm) / (denom * CosTheta(wi) * CosTheta(wo))));
+      }
+      return true;
+    }
+    case BX_DIFF_DIEL: {  // bxdf.cpp:250-287
+      float fr = FrDielectric(CosTheta(wi), ior);
+      float alpha = sqr(roughness);
+      if (alpha < 1e-4f) {
+        if (sampler.get1d() < fr) {
+          bs.wo = Reflect(wi);
+          bs.f = vec3(fr);
+          bs.pdf = fr * AbsCosTheta(bs.wo);
+          bs.is_delta = true;
+        } else {
+          bs.wo = cosine_weighted_hemisphere(sampler.get2d());
+          bs.f = albedo * ((1 - fr) / Pi);
+          bs.pdf = (1 - fr) * AbsCosTheta(bs.wo) / Pi;
+        }
+        return true;
+      }
+      TRDist distrib{alpha, alpha};
+      vec3 wm = distrib.SampleWm(wi, sampler.get2d());
+      if (sampler.get1d() < fr) {
+        vec3 wo = Reflect(wi, wm);
+        if (!SameHemisphere(wi, wo)) return false;
+        bs.wo = wo;
+        bs.f = vec3(fr * distrib.D_G(wi, wm, wo) / (4 * CosTheta(wi) * CosTheta(wo)));
+        bs.pdf = fr * distrib.pdf(wi, wm) / (4 * absdot(wi, wm));
+      } else {
+        bs.wo = cosine_weighted_hemisphere(sampler.get2d());
+        bs.f = albedo * ((1 - fr) / Pi);
+        bs.pdf = AbsCosTheta(bs.wo) * (1 - fr) / Pi;
+      }
+      return true;
+    }
+    case BX_BSSRDF: {  // bxdf.cpp:356-367
+      vec3 wo = cosine_weighted_hemisphere(sampler.get2d());
+      if (CosTheta(wi) > 0) wo = -wo;
+      bs.wo = wo;
+      bs.pdf = AbsCosTheta(bs.wo) / Pi;
+      bs.f = albedo / Pi;
+      return true;
+    }
+  }
+  return false;
+}
+vec3 BXDF::f(vec3 wo) const {
+  switch (kind) {
+    case BX_DIFFUSE:  // bxdf.cpp:24-28
+      if (!SameHemisphere(wi, wo)) return vec3(0.0f);
+      return albedo / Pi;
+    case BX_CONDUCTOR: {  // bxdf.cpp:65-79
+      if (!SameHemisphere(wi, wo)) return {};
+      float alpha = sqr(roughness);
+      TRDist distrib{alpha, alpha};
+      vec3 wm = normalize(wi + wo);
+      if (wm.is_zero()) return {};
+      vec3 fr = FrSchlick(albedo, absdot(wi, wm));
+      return fr * (distrib.D_G(wo, wm, wi) / (4 * AbsCosTheta(wo) * AbsCosTheta(wi)));
+    }
+    case BX_REFRACTIVE: {  // bxdf.cpp:125-140
+      float alpha = sqr(roughness);
+      TRDist distrib{alpha, alpha};
+      float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      bool reflect = cosThetaI * cosThetaO > 0;
+      if (!reflect) return {};
+      vec3 wm = FaceNormal(normalize(wo + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return {};
+      return albedo * (distrib.D_G(wi, wm, wo) / std::abs(4 * cosThetaI * cosThetaO));
+    }
+    case BX_REFR_DIEL: {  // bxdf.cpp:209-230  (NB `auto eta = 1` is an int there)
+      float alpha = sqr(roughness);
+      TRDist distrib{alpha, alpha};
+      float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      bool reflect = cosThetaI * cosThetaO > 0;
+      int eta = 1;
+      if (!reflect) eta = int(cosThetaI > 0 ? ior : 1 / ior);
+      vec3 wm = FaceNormal(normalize(wo * float(eta) + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return {};
+      float fr = FrDielectric(dot(wi, wm), ior);
+      if (reflect) {
+        return albedo * (fr * distrib.D_G(wi, wm, wo) / std::abs(4 * cosThetaI * cosThetaO));
+      } else {
+        float denom = sqr(dot(wo, wm) + dot(wi, wm) / eta) * cosThetaI * cosThetaO;
+        return albedo * ((1 - fr) * distrib.D(wm) * distrib.G(wi, wo) *
+                         std::abs(dot(wo, wm) * dot(wi, wm) / denom));
+      }
+    }
+    case BX_DIFF_DIEL: {  // bxdf.cpp:288-306
+      if (!SameHemisphere(wi, wo)) return {};
+      float alpha = sqr(roughness);
+      TRDist distrib{alpha, alpha};
+      float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      vec3 wm = FaceNormal(normalize(wo + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return {};
+      float fr = FrDielectric(dot(wi, wm), ior);
+      vec3 diffused = albedo * (1 - fr) / Pi;
+      if (alpha < 1e-4f) return diffused;
+      float reflected = fr * distrib.D_G(wo, wm, wi) / std::abs(4 * cosThetaI * cosThetaO);
+      return vec3(reflected) + diffused;
+    }
+    case BX_BSSRDF:  // bxdf.cpp:368-370
+      return albedo / Pi;
+  }
+  return {};
+}
+float BXDF::pdf(vec3 wo) const {
+  switch (kind) {
+    case BX_DIFFUSE:  // bxdf.cpp:29-33
+      if (!SameHemisphere(wi, wo)) return 0.0f;
+      return AbsCosTheta(wo) / Pi;
+    case BX_CONDUCTOR: {  // bxdf.cpp:80-95
+      if (!SameHemisphere(wi, wo)) return 0.0f;
+      float alpha = sqr(roughness);
+      TRDist distrib{alpha, alpha};
+      vec3 wm = normalize(wi + wo);
+      if (wm.is_zero()) return 0.0f;
+      wm = FaceNormal(wm);
+      return distrib.pdf(wi, wm) / (4 * absdot(wi, wm));
+    }
+    case BX_REFRACTIVE: {  // bxdf.cpp:141-157
+      float alpha = sqr(roughness);
+      TRDist distrib{alpha, alpha};
+      float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      bool reflect = cosThetaI * cosThetaO > 0;
+      if (!reflect) return 0.0f;
+      vec3 wm = FaceNormal(normalize(wo + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return 0.0f;
+      return distrib.pdf(wi, wm) / (4 * absdot(wi, wm));
+    }
+    case BX_REFR_DIEL: {  // bxdf.cpp:231-245
+      float alpha = sqr(roughness);
+      TRDist distrib{alpha, alpha};
+      float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      bool reflect = cosThetaI * cosThetaO > 0;
+      int eta = 1;
+      if (!reflect) eta = int(cosThetaI > 0 ? ior : 1 / ior);
+      vec3 wm = FaceNormal(normalize(wo * float(eta) + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return 0.0f;
+      float fr = FrDielectric(dot(wi, wm), ior);
+      if (reflect) {
+        return fr * distrib.pdf(wi, wm) / (4 * absdot(wi, wm));
+      } else {
+        float denom = sqr(dot(wo, wm) + dot(wi, wm) / eta);
+        float dwm_dwo = absdot(wo, wm) / denom;
+        return (1 - fr) * distrib.pdf(wi, wm) * dwm_dwo;
+      }
+    }
+    case BX_DIFF_DIEL: {  // bxdf.cpp:307-324
+      if (!SameHemisphere(wi, wo)) return 0.0f;
+      float alpha = sqr(roughness);
+      TRDist distrib{alpha, alpha};
+      float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      vec3 wm = FaceNormal(normalize(wo + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return 0.0f;
+      float fr = FrDielectric(dot(wi, wm), ior);
+      float pt = (1 - fr) * AbsCosTheta(wo) / Pi;
+      if (alpha < 1e-4f) return pt;
+      float pr = fr * distrib.pdf(wi, wm) / (4 * absdot(wi, wm));
+      return pr + pt;
+    }
+    case BX_BSSRDF:  // bxdf.cpp:371-373
+      return AbsCosTheta(wo) / Pi;
+  }
+  return 0.0f;
+}
+
+enum MatKind { M_EMISSIVE, M_DIFFUSE, M_UBER, M_SUBSURFACE };
+struct Material {
+  MatKind kind = M_DIFFUSE;
+  vec3 color;  // albedo / emission
+  float roughness = 0, metallic = 0, transmission = 0, ior = 1.45f;
+  vec3 sigma_s;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Geometry variant + Scene
+// ------------------------------------------------------------------------------------------------
+enum ShapeKind { S_RECT, S_AABB, S_OBB, S_SPHERE, S_DISK, S_CONE, S_MESH };
+struct Geometry {
+  ShapeKind kind;
+  std::shared_ptr<void> impl;
+  int material = -1;
+  template <class T> const T& as() const { return *static_cast<const T*>(impl.get()); }
+  bool hit(const Ray& r) const {
+    switch (kind) {
+      case S_RECT: return as<Rect>().hit(r);
+      case S_AABB: return as<AABB>().hit(r);
+      case S_OBB: return as<OBB>().hit(r);
+      case S_SPHERE: return as<Sphere>().hit(r);
+      case S_DISK: return as<Disk>().hit(r);
+      case S_CONE: return as<Cone>().hit(r);
+      default: return false;
+    }
+  }
+  bool intersect(Ray& r) const {
+    switch (kind) {
+      case S_RECT: return as<Rect>().intersect(r);
+      case S_AABB: return as<AABB>().intersect(r);
+      case S_OBB: return as<OBB>().intersect(r);
+      case S_SPHERE: return as<Sphere>().intersect(r);
+      case S_DISK: return as<Disk>().intersect(r);
+      case S_CONE: return as<Cone>().intersect(r);
+      default: return false;
+    }
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {
+    switch (kind) {
+      case S_RECT: as<Rect>().compute_surface_info(p, it); break;
+      case S_AABB: as<AABB>().compute_surface_info(p, it); break;
+      case S_OBB: as<OBB>().compute_surface_info(p, it); break;
+      case S_SPHERE: as<Sphere>().compute_surface_info(p, it); break;
+      case S_DISK: as<Disk>().compute_surface_info(p, it); break;
+      case S_CONE: as<Cone>().compute_surface_info(p, it); break;
+      default: break;
+    }
+  }
+  AABB get_aabb() const {
+    switch (kind) {
+      case S_RECT: return as<Rect>().get_aabb();
+      case S_AABB: { AABB b = as<AABB>(); return b.extend_by(kEpsilon); }  // bbox.h:77
+      case S_OBB: return as<OBB>().get_aabb();
+      case S_SPHERE: return as<Sphere>().get_aabb();
+      case S_DISK: return as<Disk>().get_aabb();
+      case S_CONE: return as<Cone>().get_aabb();
+      default: return AABB();
+    }
+  }
+  // Shape::sample (geometry.h:331-340): nullopt if pdf <= 0 or inf
+  bool sample(vec3 p, vec2 u, float u1, ShapeSample& ss) const {
+    switch (kind) {
+      case S_RECT: ss = as<Rect>().sample(p, u); break;
+      case S_SPHERE: ss = as<Sphere>().sample(p, u); break;
+      case S_DISK: ss = as<Disk>().sample(p, u); break;
+      case S_MESH: {  // geometry.h:170-178
+        const Mesh& m = as<Mesh>();
+        if (m.num_triangles() == 0) return false;
+        ss = m.sample_tri(size_t(int(m.num_triangles() * u1)), p, u);
+        ss.pdf /= m.num_triangles();
+        break;
+      }
+      default: return false;  // Cone::sample returns {} (geometry.cpp:461); AABB/OBB unsupported
+    }
+    if (ss.pdf <= 0 || std::isinf(ss.pdf)) return false;
+    return true;
+  }
+  float pdf(const Ray& ray, vec3 ns) const {
+    switch (kind) {
+      case S_RECT: return as<Rect>().pdf(ray, ns);
+      case S_SPHERE: return as<Sphere>().pdf(ray);
+      case S_DISK: return as<Disk>().pdf(ray, ns);
+      case S_CONE: return as<Cone>().pdf(ray, ns);
+      case S_MESH: return as<Mesh>().pdf(ray, ns);
+      default: return 0.0f;
+    }
+  }
+};
+
+struct Camera {  // camera.cpp:7-33
+  vec3 position;
+  mat3 c2w;
+  vec2 fov2d;
+  float len_radius = 0, focus_distance = 1;
+  int W = 0, H = 0;
+  void init(int w, int h, vec3 from, vec3 to, float fov, float lr, float fd) {
+    W = w;
+    H = h;
+    position = from;
+    c2w = to_mat3(look_at(from, to));
+    float aspect = float(w) / h;  // film.h:32
+    fov2d = vec2(fov * aspect, fov);
+    len_radius = lr;
+    focus_distance = fd;
+  }
+  Ray gen_ray(vec2 p_film, vec2 u2) const {
+    p_film = (p_film - vec2(0.5f, 0.5f)) * 2.0f;  // camera.cpp:17-20
+    vec2 pc = p_film * fov2d;
+    if (len_radius == 0.0f) {
+      return Ray(position, normalize(c2w * vec3(pc.x, pc.y, 1.0f)));
+    } else {
+      vec3 dir = normalize(vec3(pc.x, pc.y, 1.0f));
+      vec3 p_focus = focus_distance * dir / dir.z;
+      vec2 d = len_radius * sample_disk_polar(u2);
+      vec3 p_len(d.x, d.y, 0.0f);
+      return Ray(position + p_len, c2w * normalize(p_focus - p_len));
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// pine's BVH (src/pine/impl/accel/bvh.cpp:30-147 build, :321-451 traversal, :453-548 two-level)
+// ------------------------------------------------------------------------------------------------
+struct BVHImpl {
+  struct Primitive {
+    AABB aabb;
+    int index = 0;
+  };
+  struct Node {
+    AABB aabbs[2];
+    int children[2] = {-1, -1};
+    std::vector<int> prims;
+  };
+  std::vector<Node> nodes;
+  int root = -1;
+
+  void build(std::vector<Primitive> prims) {  // :30-41
+    AABB aabb;
+    for (auto& p : prims) aabb.extend(p.aabb);
+    nodes.reserve(prims.size());
+    build_rec(prims.data(), prims.data() + prims.size(), aabb);
+    root = int(nodes.size()) - 1;
+  }
+  AABB get_aabb() const { return union_(nodes[root].aabbs[0], nodes[root].aabbs[1]); }
+
+  int build_rec(Primitive* begin, Primitive* end, AABB aabb) {  // build_sah_binned :43-147
+    Node node;
+    int n = int(end - begin);
+    auto make_leaf = [&]() {
+      for (int i = 0; i < n; i++) node.prims.push_back(begin[i].index);
+      for (Primitive* p = begin; p != end; p++) node.aabbs[0].extend(p->aabb);
+      node.aabbs[1] = node.aabbs[0];
+      nodes.push_back(node);
+      return int(nodes.size()) - 1;
+    };
+    if (n == 1) return make_leaf();
+
+    AABB cb;
+    for (int i = 0; i < n; i++) cb.extend(begin[i].aabb.centroid());
+    float surfaceArea = aabb.surface_area();
+    const int nBuckets = 16;
+    float minCost = kFloatMax;
+    int bestAxis = -1, splitBucket = -1;
+    for (int axis = 0; axis < 3; axis++) {
+      if (cb.degenerated(axis)) continue;
+      struct Bucket {
+        int count = 0;
+        AABB aabb;
+      } buckets[nBuckets];
+      for (int i = 0; i < n; i++) {
+        int b = std::min(int(nBuckets * cb.relative_position(begin[i].aabb.centroid(axis), axis)),
+                         nBuckets - 1);
+        buckets[b].count++;
+        buckets[b].aabb.extend(begin[i].aabb);
+      }
+      float cost[nBuckets - 1] = {};
+      AABB bF;
+      int cF = 0;
+      for (int i = 0; i < nBuckets - 1; i++) {
+        bF.extend(buckets[i].aabb);
+        cF += buckets[i].count;
+        cost[i] += cF * bF.surface_area();
+      }
+      AABB bB;
+      int cB = 0;
+      for (int i = nBuckets - 1; i >= 1; i--) {
+        bB.extend(buckets[i].aabb);
+        cB += buckets[i].count;
+        cost[i - 1] += cB * bB.surface_area();
+      }
+      for (int i = 0; i < nBuckets - 1; i++) cost[i] = 1.0f + cost[i] / surfaceArea;
+      float axisMin = kFloatMax;
+      int axisSplit = -1;
+      for (int i = 0; i < nBuckets - 1; i++)
+        if (cost[i] < axisMin) {
+          axisMin = cost[i];
+          axisSplit = i;
+        }
+      if (axisMin < minCost) {
+        minCost = axisMin;
+        bestAxis = axis;
+        splitBucket = axisSplit;
+      }
+    }
+    float leafCost = float(n);
+    if (minCost > leafCost) return make_leaf();
+
+    // psl::partition (src/psl/algorithm.h:394-402): Lomuto, swap(tail++, i) when pred holds
+    Primitive* tail = begin;
+    for (Primitive* i = begin; i != end; ++i) {
+      int b = int(nBuckets * cb.relative_position(i->aabb.centroid(bestAxis), bestAxis));
+      if (b == nBuckets) b = nBuckets - 1;
+      if (b <= splitBucket) std::swap(*tail++, *i);
+    }
+    Primitive* pmid = tail;
+    for (Primitive* p = begin; p != pmid; p++) node.aabbs[0].extend(p->aabb);
+    for (Primitive* p = pmid; p != end; p++) node.aabbs[1].extend(p->aabb);
+    node.children[0] = build_rec(begin, pmid, node.aabbs[0]);
+    node.children[1] = build_rec(pmid, end, node.aabbs[1]);
+    nodes.push_back(node);
+    return int(nodes.size()) - 1;
+  }
+
+  template <class F>
+  bool any_hit(const Ray& ray, F&& f) const {  // BVHImpl::hit :321-383
+    if (nodes.empty()) return false;
+    RayOctant oct(ray);
+    int stack[32], ptr = 0, next = root;
+    if (!nodes[next].prims.empty()) {
+      for (int idx : nodes[next].prims)
+        if (f(ray, idx)) return true;
+      return false;
+    }
+    while (true) {
+      const Node& node = nodes[next];
+      int l = -1, r = -1;
+      float t0 = ray.tmax, t1 = ray.tmax;
+      if (node.aabbs[0].hit(oct, ray.tmin, t0)) {
+        const Node& c = nodes[node.children[0]];
+        if (c.prims.empty()) l = node.children[0];
+        else
+          for (int idx : c.prims)
+            if (f(ray, idx)) return true;
+      }
+      if (node.aabbs[1].hit(oct, ray.tmin, t1)) {
+        const Node& c = nodes[node.children[1]];
+        if (c.prims.empty()) r = node.children[1];
+        else
+          for (int idx : c.prims)
+            if (f(ray, idx)) return true;
+      }
+      if (l != -1) {
+        if (r != -1) {
+          if (t0 > t1) { stack[ptr++] = l; next = r; }
+          else { stack[ptr++] = r; next = l; }
+        } else next = l;
+      } else if (r != -1) next = r;
+      else {
+        if (ptr == 0) break;
+        next = stack[--ptr];
+      }
+    }
+    return false;
+  }
+  template <class F>
+  bool closest(Ray& ray, F&& f) const {  // BVHImpl::Intersect :385-451
+    if (nodes.empty()) return false;
+    RayOctant oct(ray);
+    bool hit = false;
+    int stack[32], ptr = 0, next = root;
+    if (!nodes[next].prims.empty()) {
+      for (int idx : nodes[next].prims)
+        if (f(ray, idx)) hit = true;
+      return hit;
+    }
+    while (true) {
+      const Node& node = nodes[next];
+      int l = -1, r = -1;
+      float t0 = ray.tmax, t1 = ray.tmax;
+      if (node.aabbs[0].hit(oct, ray.tmin, t0)) {
+        const Node& c = nodes[node.children[0]];
+        if (c.prims.empty()) l = node.children[0];
+        else
+          for (int idx : c.prims)
+            if (f(ray, idx)) hit = true;
+      }
+      if (node.aabbs[1].hit(oct, ray.tmin, t1)) {
+        const Node& c = nodes[node.children[1]];
+        if (c.prims.empty()) r = node.children[1];
+        else
+          for (int idx : c.prims)
+            if (f(ray, idx)) hit = true;
+      }
+      if (l != -1) {
+        if (r != -1) {
+          if (t0 > t1) { stack[ptr++] = l; next = r; }
+          else { stack[ptr++] = r; next = l; }
+        } else next = l;
+      } else if (r != -1) next = r;
+      else {
+        if (ptr == 0) break;
+        next = stack[--ptr];
+      }
+    }
+    return hit;
+  }
+};
+
+struct Scene {
+  std::vector<Material> materials;
+  std::vector<std::string> material_names;
+  std::vector<Geometry> geometries;
+  std::vector<int> lights;  // geometry indices of emissive geometry, in add order (scene.cpp:16-22)
+  Camera camera;
+  // accel (BVH::build bvh.cpp:453-495)
+  std::vector<std::shared_ptr<BVHImpl>> lbvh;
+  BVHImpl tbvh;
+  std::vector<int> indices;
+
+  int find_material(const std::string& n) const {
+    for (int i = int(material_names.size()) - 1; i >= 0; i--)  // map semantics: last add wins
+      if (material_names[i] == n) return i;
+    return -1;
+  }
+  void build_accel() {
+    lbvh.clear();
+    tbvh = BVHImpl();
+    indices.clear();
+    if (geometries.empty()) return;
+    for (size_t i = 0; i < geometries.size(); i++) {
+      if (geometries[i].kind != S_MESH) continue;
+      auto& mesh = *static_cast<Mesh*>(geometries[i].impl.get());
+      if (mesh.num_triangles() == 0) continue;
+      std::vector<BVHImpl::Primitive> prims;
+      for (size_t t = 0; t < mesh.num_triangles(); t++) {
+        BVHImpl::Primitive p;
+        p.aabb = mesh.get_aabb(t);
+        p.index = int(prims.size());
+        prims.push_back(p);
+      }
+      auto b = std::make_shared<BVHImpl>();
+      b->build(std::move(prims));
+      mesh.bvh = b;
+      lbvh.push_back(b);
+      indices.push_back(int(i));
+    }
+    std::vector<BVHImpl::Primitive> prims;
+    for (auto& s : lbvh) {
+      BVHImpl::Primitive p;
+      p.aabb = s->get_aabb();
+      p.index = int(prims.size());
+      prims.push_back(p);
+    }
+    for (size_t i = 0; i < geometries.size(); i++) {
+      if (geometries[i].kind == S_MESH) continue;
+      BVHImpl::Primitive p;
+      p.aabb = geometries[i].get_aabb();
+      p.index = int(prims.size());
+      prims.push_back(p);
+      indices.push_back(int(i));
+    }
+    tbvh.build(prims);
+  }
+  bool hit(Ray ray) const {  // BVH::hit :497-511
+    if (geometries.empty()) return false;
+    return tbvh.any_hit(ray, [&](const Ray& r, int li) {
+      const Geometry& g = geometries[indices[li]];
+      if (li < int(lbvh.size())) {
+        const Mesh& m = g.as<Mesh>();
+        return lbvh[li]->any_hit(r, [&](const Ray& rr, int idx) { return m.hit(rr, idx); });
+      }
+      return g.hit(r);
+    });
+  }
+  bool intersect(Ray& ray, SurfaceInteraction& it) const {  // BVH::intersect :513-548
+    if (geometries.empty()) return false;
+    uint32_t geom_index = 0, prim_index = 0;
+    bool hit = tbvh.closest(ray, [&](Ray& r, int li) {
+      const Geometry& g = geometries[indices[li]];
+      if (li < int(lbvh.size())) {
+        const Mesh& m = g.as<Mesh>();
+        bool h = lbvh[li]->closest(r, [&](Ray& rr, int idx) {
+          bool hh = m.intersect(rr, idx);
+          if (hh) prim_index = idx;
+          return hh;
+        });
+        if (h) geom_index = indices[li];
+        return h;
+      }
+      bool h = g.intersect(r);
+      if (h) geom_index = indices[li];
+      return h;
+    });
+    if (hit) {
+      const Geometry& g = geometries[geom_index];
+      it.geom = int(geom_index);
+      if (g.kind == S_MESH)
+        g.as<Mesh>().compute_surface_info(ray(), it, prim_index);
+      else
+        g.compute_surface_info(ray(), it);
+    }
+    return hit;
+  }
+};
+
+// Mesh::intersect(ray, it) via ShapeBVH (bvh.cpp:568-582) -- used by the BSSRDF walk only
+bool mesh_intersect_full(const Mesh& m, Ray& ray, SurfaceInteraction& it) {
+  int prim = 0;
+  bool hit = m.bvh->closest(ray, [&](Ray& r, int idx) {
+    bool h = m.intersect(r, idx);
+    if (h) prim = idx;
+    return h;
+  });
+  if (hit) m.compute_surface_info(ray(), it, prim);
+  return hit;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PathIntegrator (src/pine/impl/integrator/path.cpp:26-124, src/pine/core/integrator.cpp:26-81)
+// ------------------------------------------------------------------------------------------------
+struct Counters {
+  uint64_t vertices = 0, shadow = 0, bsdf = 0;
+};
+struct Vertex {  // path.cpp:15-25
+  int length, diffuse_length;
+  float pdf;
+  bool is_delta;
+};
+struct RadianceResult {
+  vec3 Lo;
+  bool has_light_pdf = false;
+  float light_pdf = 0;
+};
+
+struct LightSample {
+  vec3 le, wo;
+  float distance = 0, pdf = 0;
+  bool is_delta = false;
+};
+
+struct Integrator {
+  const Scene* scene;
+  int max_path_length;
+
+  vec3 material_le(const Material& m, vec3 n, vec3 wo) const {  // material.h:22-25
+    if (m.kind != M_EMISSIVE) return vec3(0.0f);
+    if (dot(wo, n) < 0.0f) return vec3(0.0f);
+    return m.color;
+  }
+  // UniformLightSampler::sample (lightsampler.cpp:12-26) + AreaLight::sample (light.cpp:55-69)
+  bool sample_light(vec3 p, float u1, vec2 u2, LightSample& ls) const {
+    int N = int(scene->lights.size());
+    if (N == 0) return false;
+    u1 *= N;
+    int index = int(u1);
+    const Geometry& g = scene->geometries[scene->lights[index]];
+    ShapeSample gs;
+    if (!g.sample(p, u2, u1 - index, gs)) return false;
+    ls.wo = gs.w;
+    ls.pdf = gs.pdf;
+    ls.distance = gs.distance;
+    ls.le = material_le(scene->materials[g.material], gs.n, -ls.wo);
+    if (ls.le.is_zero()) return false;
+    ls.pdf = ls.pdf / N;
+    ls.is_delta = false;
+    return true;
+  }
+
+  // BSSRDF::sample_p (bxdf.cpp:329-353) + BXDF::sample_p (:375-382)
+  void bssrdf_walk(BXDF& bxdf, vec3& beta, SurfaceInteraction& it, vec3 bc_p, vec3 bc_n, vec3 bc_wi,
+                   Sampler& sampler) const {
+    vec3 p = bc_p;
+    vec3 w = -bc_wi;
+    if (!Refract(bc_wi, bc_n, bxdf.ior, w)) return;
+    int channel = int(sampler.randf() * 3);
+    vec3 b(0.0f);
+    b[channel] = 3;
+    float sigma_t_inv = 1 / bxdf.sigma_s[channel];
+    const Geometry& g = scene->geometries[it.geom];
+    for (int i = 0;; i++) {
+      Ray ray = i == 0 ? spawn_ray_pn(p, bc_n, w) : Ray(p, w);
+      SurfaceInteraction sit;  // p, n zero-initialised (Appendix A5)
+      bool h;
+      if (g.kind == S_MESH) h = mesh_intersect_full(g.as<Mesh>(), ray, sit);
+      else h = g.intersect(ray);  // non-mesh shapes do not fill it.p/it.n
+      if (!h) return;
+      float t = -std::log(1 - sampler.get1d()) * sigma_t_inv;
+      if (ray.tmax < t) {
+        beta = b;
+        it.p = sit.p;
+        it.n = sit.n;
+        it.compute_transformation();
+        bxdf.wi = it.to_local(-w);
+        return;
+      } else {
+        p = ray(t);
+        w = uniform_sphere(sampler.get2d());
+      }
+    }
+  }
+
+  RadianceResult radiance(Ray ray, Sampler& sampler, Vertex pv, Counters& cnt) const {
+    RadianceResult result;
+    cnt.vertices++;
+    vec3 wi = -ray.d;
+    vec3& Lo = result.Lo;
+
+    SurfaceInteraction it;
+    bool hit = scene->intersect(ray, it);
+    if (hit) it.compute_transformation();  // integrator.cpp:36-41
+    // medium block (path.cpp:50-72) is dead: no mediums.  Tr == vec3(1) (integrator.cpp:75-81)
+    if (!hit) return result;  // no env light (path.cpp:75-81)
+
+    const Geometry& g = scene->geometries[it.geom];
+    const Material& mat = scene->materials[g.material];
+    if (mat.kind == M_EMISSIVE) {  // path.cpp:83-87
+      Lo += vec3(1.0f) * material_le(mat, it.n, wi);
+      if (!pv.is_delta) {
+        result.has_light_pdf = true;
+        result.light_pdf = g.pdf(ray, it.n) / float(scene->lights.size());  // lightsampler.cpp:27-29
+      }
+      return result;
+    }
+    if (pv.length + 1 >= max_path_length) return result;  // path.cpp:89
+
+    // BxdfSampleCtx (bxdf.h:10-21): copies p,n,uv now; min_roughness only once diffused
+    bool diffused = pv.diffuse_length > 0;
+    float min_roughness = diffused ? 0.6f : 0.0f;
+    vec3 bc_p = it.p, bc_n = it.n;
+    BXDF bxdf;
+    switch (mat.kind) {  // material.h:30-131, material.cpp:9-28
+      case M_DIFFUSE:
+        bxdf.kind = BX_DIFFUSE;
+        bxdf.albedo = mat.color;
+        break;
+      case M_UBER:
+        if (with_probability(mat.metallic, sampler)) {
+          bxdf.kind = BX_CONDUCTOR;
+          bxdf.albedo = mat.color;
+          bxdf.roughness = mat.roughness;
+        } else if (with_probability(mat.transmission, sampler)) {
+          bxdf.kind = BX_REFR_DIEL;
+          bxdf.albedo = mat.color;
+          bxdf.roughness = mat.roughness;
+          bxdf.ior = mat.ior;
+        } else {
+          bxdf.kind = BX_DIFF_DIEL;
+          bxdf.albedo = mat.color;
+          bxdf.roughness = mat.roughness;
+          bxdf.ior = mat.ior;
+        }
+        break;
+      case M_SUBSURFACE: {
+        const float ior = 1.4f;  // material.h:110
+        float fr = FrDielectric(dot(wi, bc_n), ior);
+        if (sampler.get1d() < fr) {
+          bxdf.kind = BX_REFRACTIVE;
+          bxdf.albedo = mat.color;
+          bxdf.roughness = fmax_(mat.roughness, min_roughness);
+          bxdf.ior = ior;
+        } else if (diffused) {
+          bxdf.kind = BX_DIFFUSE;
+          bxdf.albedo = mat.color;
+        } else {
+          bxdf.kind = BX_BSSRDF;
+          bxdf.albedo = mat.color;
+          bxdf.ior = ior;
+          bxdf.sigma_s = mat.sigma_s;
+        }
+        break;
+      }
+      default: break;
+    }
+    bxdf.wi = it.to_local(wi);  // material.h:119
+
+    vec3 beta(1.0f);
+    if (bxdf.kind == BX_BSSRDF) bssrdf_walk(bxdf, beta, it, bc_p, bc_n, wi, sampler);
+
+    vec3 lo(0.0f);
+    if (!bxdf.is_delta()) {  // path.cpp:98-113
+      // g++ evaluates LightSampler::sample's arguments right-to-left (lightsampler.h:27):
+      vec2 u2 = sampler.get2d();
+      float u1 = sampler.get1d();
+      LightSample ls;
+      if (sample_light(it.p, u1, u2, ls)) {
+        cnt.shadow++;
+        if (!scene->hit(it.spawn_ray(ls.wo, ls.distance))) {
+          float cosine = absdot(ls.wo, it.n);
+          vec3 tr(1.0f);
+          vec3 wo = it.to_local(ls.wo);
+          vec3 f = bxdf.f(wo);
+          float mis = balance_heuristic(ls.pdf, bxdf.pdf(wo));
+          lo += ls.le * tr * cosine * f / ls.pdf * mis;
+        }
+      }
+    }
+    BSDFSample bs;
+    if (bxdf.sample(sampler, bs)) {  // path.cpp:114-120
+      cnt.bsdf++;
+      bs.wo = it.to_world(bs.wo);
+      float cosine = absdot(bs.wo, it.n);
+      Vertex nv{pv.length + 1, pv.diffuse_length + (bs.is_delta ? 0 : 1), bs.pdf, bs.is_delta};
+      RadianceResult child = radiance(it.spawn_ray(bs.wo), sampler, nv, cnt);
+      float mis = child.has_light_pdf ? balance_heuristic(bs.pdf, child.light_pdf) : 1.0f;
+      lo += child.Lo * bs.f * (cosine / bs.pdf * mis);
+    }
+    Lo += vmin(vec3(1.0f) * beta * lo, vec3(8.0f));  // path.cpp:121 per-level clamp
+    return result;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// pscene parser (format: pine_amd/scene_io.py)
+// ------------------------------------------------------------------------------------------------
+std::string g_error;
+float rdf(std::istream& in) {
+  std::string tok;
+  in >> tok;
+  return strtof(tok.c_str(), nullptr);
+}
+vec3 rd3(std::istream& in) {
+  float x = rdf(in), y = rdf(in), z = rdf(in);
+  return vec3(x, y, z);
+}
+bool parse_pscene(const char* text, Scene& scene) {
+  std::istringstream f(text);
+  std::string line;
+  while (std::getline(f, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    std::istringstream in(line);
+    std::string kw;
+    in >> kw;
+    if (kw == "material") {
+      std::string name, kind;
+      in >> name >> kind;
+      Material m;
+      if (kind == "emissive") {
+        m.kind = M_EMISSIVE;
+        m.color = rd3(in);
+      } else if (kind == "diffuse") {
+        m.kind = M_DIFFUSE;
+        m.color = rd3(in);
+      } else if (kind == "uber") {
+        m.kind = M_UBER;
+        m.color = rd3(in);
+        m.roughness = rdf(in);
+        m.metallic = rdf(in);
+        m.transmission = rdf(in);
+        m.ior = rdf(in);
+      } else if (kind == "subsurface") {
+        m.kind = M_SUBSURFACE;
+        m.color = rd3(in);
+        m.roughness = rdf(in);
+        m.sigma_s = rd3(in);
+      } else {
+        g_error = "unknown material kind " + kind;
+        return false;
+      }
+      scene.materials.push_back(m);
+      scene.material_names.push_back(name);
+    } else if (kw == "shape") {
+      std::string kind, mat;
+      in >> kind >> mat;
+      Geometry g;
+      g.material = scene.find_material(mat);
+      if (g.material < 0) {
+        g_error = "Can't find material `" + mat + "`";
+        return false;
+      }
+      if (kind == "rect") {
+        vec3 p = rd3(in), ex = rd3(in), ey = rd3(in);
+        int flip;
+        in >> flip;
+        g.kind = S_RECT;
+        g.impl = std::make_shared<Rect>(p, ex, ey, flip != 0);
+      } else if (kind == "box") {
+        vec3 lo = rd3(in), hi = rd3(in);
+        g.kind = S_AABB;
+        g.impl = std::make_shared<AABB>(lo, hi);
+      } else if (kind == "obb") {
+        vec3 lo = rd3(in), hi = rd3(in);
+        float m[16];
+        for (auto& v : m) v = rdf(in);
+        mat4 M(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11], m[12],
+               m[13], m[14], m[15]);
+        g.kind = S_OBB;
+        g.impl = std::make_shared<OBB>(AABB(lo, hi), M);
+      } else if (kind == "sphere") {
+        vec3 c = rd3(in);
+        float r = rdf(in);
+        g.kind = S_SPHERE;
+        g.impl = std::make_shared<Sphere>(Sphere{c, r});
+      } else if (kind == "disk") {
+        vec3 p = rd3(in), n = rd3(in);
+        float r = rdf(in);
+        g.kind = S_DISK;
+        g.impl = std::make_shared<Disk>(p, n, r);
+      } else if (kind == "cone") {
+        vec3 p = rd3(in), n = rd3(in);
+        float r = rdf(in), h = rdf(in);
+        g.kind = S_CONE;
+        g.impl = std::make_shared<Cone>(p, n, r, h);
+      } else if (kind == "mesh") {
+        int nv, nt;
+        in >> nv >> nt;
+        auto m = std::make_shared<Mesh>();
+        for (int i = 0; i < nv; i++) m->vertices.push_back(rd3(in));
+        for (int i = 0; i < 3 * nt; i++) {
+          uint32_t a;
+          in >> a;
+          m->indices.push_back(a);
+        }
+        g.kind = S_MESH;
+        g.impl = m;
+      } else {
+        g_error = "unknown shape kind " + kind;
+        return false;
+      }
+      scene.geometries.push_back(g);
+      if (scene.materials[g.material].kind == M_EMISSIVE)
+        scene.lights.push_back(int(scene.geometries.size()) - 1);
+    } else if (kw == "camera") {
+      std::string kind;
+      int W, H;
+      in >> kind >> W >> H;
+      vec3 from = rd3(in), to = rd3(in);
+      float fov = rdf(in), lr = rdf(in), fd = rdf(in);
+      scene.camera.init(W, H, from, to, fov, lr, fd);
+    } else {
+      g_error = "unknown keyword " + kw;
+      return false;
+    }
+  }
+  return true;
+}
+
+// PathIntegrator::render (path.cpp:26-41) with parallel_for's scheduling shape (parallel.h:19-57)
+void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int depth, int threads,
+                 int y0, int y1, float* film, float* samples_out, oracle_stats* stats) {
+  int W = scene.camera.W, H = scene.camera.H;
+  int spp = bluesobol_effective_spp(spp_req);
+  BlueTables bt = select_tables(tables, spp);
+  Integrator integ{&scene, depth};
+  if (threads <= 0) threads = int(std::thread::hardware_concurrency());
+  if (threads <= 0) threads = 1;
+  if (y1 <= y0) {
+    y0 = 0;
+    y1 = H;
+  }
+  int first = y0 * W, n_items = (y1 - y0) * W;
+  int batch_count = std::max(threads, n_items / 64);
+  int batch_size = std::max(n_items / batch_count, 1);
+  std::atomic<int> global_index{0};
+  std::vector<Counters> counters(threads);
+  auto work = [&](int tid) {
+    Sampler sampler;
+    sampler.t = bt;
+    sampler.spp = spp;
+    Counters& cnt = counters[tid];
+    while (true) {
+      int index = (global_index += batch_size) - batch_size;
+      int end_index = std::min(index + batch_size, n_items);
+      for (int i = index; i < end_index; i++) {
+        int px = (first + i) % W, py = (first + i) / W;
+        sampler.start_pixel(px, py, 0);
+        vec3 L(0.0f);
+        for (int si = 0; si < spp; si++, sampler.start_next_sample()) {
+          // g++ right-to-left: lens sample first, then pixel jitter (path.cpp:35, Appendix A2)
+          vec2 u_lens = sampler.rand2f();
+          vec2 jitter = sampler.rand2f();
+          vec2 pf((float(px) + jitter.x) / float(W), (float(py) + jitter.y) / float(H));
+          Ray ray = scene.camera.gen_ray(pf, u_lens);
+          uint64_t v0 = cnt.vertices;
+          vec3 Ls = integ.radiance(ray, sampler, Vertex{0, 0, 0.0f, true}, cnt).Lo;
+          L += Ls;
+          if (samples_out) {
+            float* o = samples_out + (size_t(py * W + px) * spp + si) * 4;
+            o[0] = Ls.x;
+            o[1] = Ls.y;
+            o[2] = Ls.z;
+            o[3] = float(cnt.vertices - v0);
+          }
+        }
+        if (film) {
+          float* o = film + size_t(py * W + px) * 4;
+          vec3 m = L / float(spp);
+          o[0] = m.x;
+          o[1] = m.y;
+          o[2] = m.z;
+          o[3] = 1.0f;
+        }
+      }
+      if (end_index >= n_items) break;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+  work(0);
+  for (auto& t : pool) t.join();
+  if (stats) {
+    stats->camera_samples = uint64_t(n_items) * spp;
+    stats->vertices = stats->shadow_rays = stats->bsdf_samples = 0;
+    for (auto& c : counters) {
+      stats->vertices += c.vertices;
+      stats->shadow_rays += c.shadow;
+      stats->bsdf_samples += c.bsdf;
+    }
+    stats->threads = threads;
+    stats->spp_effective = spp;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* oracle_last_error(void) { return g_error.c_str(); }
+
+int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,
+                  int y0, int y1, float* film_out, oracle_stats* stats) {
+  if (depth <= 0) {
+    g_error = "`PathIntegrator` expect `max_path_length` to be positive";  // path.cpp:12-13
+    return 1;
+  }
+  Scene scene;
+  if (!parse_pscene(pscene, scene)) return 2;
+  auto t0 = std::chrono::steady_clock::now();
+  scene.build_accel();  // inside render() in the reference too (integrator.cpp:33)
+  render_impl(scene, tables, spp, depth, threads, y0, y1, film_out, nullptr, stats);
+  auto t1 = std::chrono::steady_clock::now();
+  if (stats) stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+  return 0;
+}
+
+int oracle_render_samples(const char* pscene, const uint8_t* tables, int spp, int depth,
+                          int threads, float* samples_out) {
+  Scene scene;
+  if (!parse_pscene(pscene, scene)) return 2;
+  scene.build_accel();
+  render_impl(scene, tables, spp, depth, threads, 0, 0, nullptr, samples_out, nullptr);
+  return 0;
+}
+
+static const int kPixels[][2] = {{0, 0}, {1, 0}, {3, 5}, {127, 127}, {128, 5}, {639, 639}};
+
+int oracle_sampler_stream(const uint8_t* tables, int spp_req, float* out, int64_t capacity) {
+  int spp = bluesobol_effective_spp(spp_req);
+  int64_t need = int64_t(6) * spp * (260 + 270);
+  if (capacity < need) return int(-1);
+  Sampler s;
+  s.t = select_tables(tables, spp);
+  s.spp = spp;
+  int64_t k = 0;
+  for (auto& px : kPixels) {
+    s.dimension = 0;
+    s.start_pixel(px[0], px[1], 0);
+    for (int i = 0; i < spp; i++) {
+      for (int d = 0; d < 130; d++) {
+        vec2 v = s.get2d();
+        out[k++] = v.x;
+        out[k++] = v.y;
+      }
+      s.start_next_sample();
+    }
+    s.start_pixel(px[0], px[1], 0);
+    for (int i = 0; i < spp; i++) {
+      for (int d = 0; d < 90; d++) {
+        out[k++] = s.get1d();
+        vec2 v = s.get2d();
+        out[k++] = v.x;
+        out[k++] = v.y;
+      }
+      s.start_next_sample();
+    }
+  }
+  return 0;
+}
+
+int oracle_rng_stream(uint64_t* out, int64_t capacity) {
+  if (capacity < 6 * 19) return -1;
+  int64_t k = 0;
+  for (auto& px : kPixels) {
+    uint64_t h = hash_pixel(px[0], px[1], 0);
+    out[k++] = h;
+    RNG r(h);
+    out[k++] = r.s[0];
+    out[k++] = r.s[1];
+    for (int i = 0; i < 16; i++) {
+      float f = r.nextf();
+      uint32_t b;
+      memcpy(&b, &f, 4);
+      out[k++] = b;
+    }
+  }
+  return 0;
+}
+
+int oracle_host_math(float* out, int64_t capacity) {
+  if (capacity < 8 * 16 + 5 * 9) return -1;
+  int64_t k = 0;
+  auto push4 = [&](const mat4& m) {
+    for (int c = 0; c < 4; c++)
+      for (int r = 0; r < 4; r++) out[k++] = m[c][r];
+  };
+  auto push3 = [&](const mat3& m) {
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) out[k++] = m[c][r];
+  };
+  mat4 m0 = translate(vec3(0.0f, 0.0f, 0.6f)) * rotate_y(0.4f) * scale(vec3(0.6f, 0.6f, 0.6f));
+  mat4 m1 = translate(vec3(-0.6f, 0.0f, 1.0f)) * rotate_y(-0.4f) * scale(vec3(0.6f, 1.3f, 0.6f));
+  push4(m0);
+  push4(inverse(m0));
+  push4(m1);
+  push4(inverse(m1));
+  push4(look_at(vec3(0, 0, 0), vec3(0, 0, 1)));
+  push4(look_at(vec3(0, 1, -4), vec3(0, 1, 0)));
+  push4(look_at(vec3(0, 4, -8), vec3(0, 1, 0)));
+  push4(rotate_x(0.3f) * rotate_z(-1.1f));
+  vec3 ns[] = {vec3(0, 1, 0), vec3(1, 0, 0), vec3(0, 0, -1), normalize(vec3(1, 2, 3)),
+               normalize(vec3(-3, 2, 0.5f))};
+  for (auto n : ns) push3(coordinate_system(n));
+  return 0;
+}
+
+int oracle_shapes(const char* pscene, const float* rays, int64_t nrays, float* out,
+                  int64_t capacity) {
+  Scene scene;
+  if (!parse_pscene(pscene, scene)) return 2;
+  int64_t k = 0;
+  for (auto& g : scene.geometries) {
+    if (g.kind == S_MESH) continue;
+    for (int64_t i = 0; i < nrays; i++) {
+      if (k + 11 > capacity) return -1;
+      const float* q = rays + i * 8;
+      Ray r(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
+      out[k++] = g.hit(r) ? 1.0f : 0.0f;
+      SurfaceInteraction it;
+      Ray r2 = r;
+      bool h = g.intersect(r2);
+      out[k++] = h ? 1.0f : 0.0f;
+      out[k++] = r2.tmax;
+      if (h) g.compute_surface_info(r2(), it);
+      out[k++] = it.p.x;
+      out[k++] = it.p.y;
+      out[k++] = it.p.z;
+      out[k++] = it.n.x;
+      out[k++] = it.n.y;
+      out[k++] = it.n.z;
+      out[k++] = it.uv.x;
+      out[k++] = it.uv.y;
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

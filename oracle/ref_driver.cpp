@@ -1,0 +1,299 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Our own driver around the REAL reference (wicstas/pine), compiled against the reference sources
+// where they lie under /root/reference (see oracle/Makefile).  It builds a Scene through the
+// reference's C++ API from this repo's neutral scene description (.pscene, see
+// pine_amd/scene_io.py), runs the reference's PathIntegrator with pine's own BVH accel
+// (SURVEY.md oracle variant O-gcc-bvh) and dumps raw outputs that become golden fixtures under
+// tests/golden/.  Nothing from the reference is copied here: only its public API is called.
+//
+//   pine_ref render  <scene.pscene> <spp> <depth> <out.film>      raw vec4 film, W*H*16 bytes
+//   pine_ref sampler <spp> <out.bin>     BlueSobolSampler get1d/get2d streams (fixture 1)
+//   pine_ref rng     <out.bin>           hash()/RNG known answers (fixture 1)
+//   pine_ref host    <out.bin>           host-side math known answers (matrices, look_at, ctors)
+//   pine_ref shapes  <scene.pscene> <rays.bin> <out.bin>   per-shape hit/intersect records
+#include <pine/core/lightsampler.h>
+#include <pine/core/sampler.h>
+#include <pine/core/scene.h>
+#include <pine/core/rng.h>
+#include <pine/impl/integrator/path.h>
+#include <pine/impl/accel/bvh.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace pine;
+
+static float rdf(std::istream& in) {
+  std::string tok;
+  in >> tok;
+  return strtof(tok.c_str(), nullptr);  // accepts hexfloat
+}
+static vec3 rd3(std::istream& in) {
+  float x = rdf(in), y = rdf(in), z = rdf(in);
+  return vec3(x, y, z);
+}
+
+struct Loaded {
+  Scene scene;
+  int W = 0, H = 0;
+};
+
+static void load_pscene(const char* path, Loaded& out) {
+  std::ifstream f(path);
+  if (!f) {
+    fprintf(stderr, "cannot open %s\n", path);
+    exit(2);
+  }
+  auto& scene = out.scene;
+  std::string line;
+  while (std::getline(f, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    std::istringstream in(line);
+    std::string kw;
+    in >> kw;
+    if (kw == "material") {
+      std::string name, kind;
+      in >> name >> kind;
+      if (kind == "emissive") {
+        scene.add_material(name.c_str(), Material(EmissiveMaterial(rd3(in))));
+      } else if (kind == "diffuse") {
+        scene.add_material(name.c_str(), Material(DiffuseMaterial(rd3(in))));
+      } else if (kind == "uber") {
+        auto albedo = rd3(in);
+        float rough = rdf(in), metal = rdf(in), trans = rdf(in), ior = rdf(in);
+        scene.add_material(name.c_str(), Material(UberMaterial(albedo, rough, metal, trans, ior)));
+      } else if (kind == "subsurface") {
+        auto albedo = rd3(in);
+        float rough = rdf(in);
+        auto sigma = rd3(in);
+        scene.add_material(name.c_str(), Material(SubsurfaceMaterial(albedo, rough, sigma)));
+      } else {
+        fprintf(stderr, "unknown material kind %s\n", kind.c_str());
+        exit(2);
+      }
+    } else if (kw == "shape") {
+      std::string kind, mat;
+      in >> kind >> mat;
+      if (kind == "rect") {
+        auto p = rd3(in), ex = rd3(in), ey = rd3(in);
+        int flip;
+        in >> flip;
+        scene.add_geometry(Rect(p, ex, ey, flip != 0), psl::string(mat.c_str()));
+      } else if (kind == "box") {
+        auto lo = rd3(in), hi = rd3(in);
+        scene.add_geometry(AABB(lo, hi), psl::string(mat.c_str()));
+      } else if (kind == "obb") {
+        auto lo = rd3(in), hi = rd3(in);
+        float m[16];
+        for (auto& v : m) v = rdf(in);
+        // row-major constructor arguments, as the reference's mat4 scalar ctor takes them
+        auto M = mat4(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11],
+                      m[12], m[13], m[14], m[15]);
+        scene.add_geometry(OBB(AABB(lo, hi), M), psl::string(mat.c_str()));
+      } else if (kind == "sphere") {
+        auto c = rd3(in);
+        float r = rdf(in);
+        scene.add_geometry(Sphere(c, r), psl::string(mat.c_str()));
+      } else if (kind == "disk") {
+        auto p = rd3(in), n = rd3(in);
+        float r = rdf(in);
+        scene.add_geometry(Disk(p, n, r), psl::string(mat.c_str()));
+      } else if (kind == "cone") {
+        auto p = rd3(in), n = rd3(in);
+        float r = rdf(in), h = rdf(in);
+        scene.add_geometry(Cone(p, n, r, h), psl::string(mat.c_str()));
+      } else if (kind == "mesh") {
+        int nv, nt;
+        in >> nv >> nt;
+        psl::vector<vec3> verts;
+        psl::vector<vec3u32> idx;
+        for (int i = 0; i < nv; i++) verts.push_back(rd3(in));
+        for (int i = 0; i < nt; i++) {
+          uint32_t a, b, c;
+          in >> a >> b >> c;
+          idx.push_back(vec3u32(a, b, c));
+        }
+        scene.add_geometry(Mesh(MOVE(verts), MOVE(idx)), psl::string(mat.c_str()));
+      } else {
+        fprintf(stderr, "unknown shape kind %s\n", kind.c_str());
+        exit(2);
+      }
+    } else if (kw == "camera") {
+      std::string kind;
+      in >> kind;
+      in >> out.W >> out.H;
+      auto from = rd3(in), to = rd3(in);
+      float fov = rdf(in), lr = rdf(in), fd = rdf(in);
+      scene.set_camera(ThinLenCamera(Film(vec2i(out.W, out.H)), from, to, fov, lr, fd));
+    } else {
+      fprintf(stderr, "unknown keyword %s\n", kw.c_str());
+      exit(2);
+    }
+  }
+}
+
+static void write_file(const char* path, const void* p, size_t n) {
+  FILE* f = fopen(path, "wb");
+  if (!f || fwrite(p, 1, n, f) != n) {
+    fprintf(stderr, "cannot write %s\n", path);
+    exit(2);
+  }
+  fclose(f);
+}
+
+static const int kPixels[][2] = {{0, 0}, {1, 0}, {3, 5}, {127, 127}, {128, 5}, {639, 639}};
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  std::string cmd = argv[1];
+  if (cmd == "render" && argc == 6) {
+    Loaded L;
+    load_pscene(argv[2], L);
+    int spp = atoi(argv[3]), depth = atoi(argv[4]);
+    // zero the film first: PathIntegrator::render does not clear it (path.cpp:38 plain store)
+    L.scene.camera.film().clear();
+    auto integ = PathIntegrator(Accel(BVH()), BlueSobolSampler(spp), UniformLightSampler(), depth);
+    auto t0 = std::chrono::steady_clock::now();
+    integ.render(L.scene);
+    auto t1 = std::chrono::steady_clock::now();
+    double sec = std::chrono::duration<double>(t1 - t0).count();
+    auto& film = L.scene.camera.film();
+    write_file(argv[5], film.data(), size_t(16) * L.W * L.H);
+    int eff = BlueSobolSampler(spp).spp();
+    printf("{\"seconds\": %.6f, \"threads\": %u, \"w\": %d, \"h\": %d, \"spp\": %d, \"depth\": %d, "
+           "\"msamples_per_s\": %.6f}\n",
+           sec, std::thread::hardware_concurrency(), L.W, L.H, eff, depth,
+           double(L.W) * L.H * eff / sec * 1e-6);
+    return 0;
+  }
+  if (cmd == "sampler" && argc == 4) {
+    // fixture 1: for each pixel in kPixels, sample indices 0..n-1, 130 x get2d (dims 0..259 with
+    // the wrap-to-2 at 256) then the same via alternating get1d/get2d to pin the counters.
+    int spp = atoi(argv[2]);
+    std::vector<float> out;
+    for (auto& px : kPixels) {
+      auto s = BlueSobolSampler(spp);
+      s.start_pixel(vec2i(px[0], px[1]), 0);
+      for (int i = 0; i < s.spp(); i++) {
+        for (int d = 0; d < 130; d++) {
+          auto v = s.get2d();
+          out.push_back(v.x);
+          out.push_back(v.y);
+        }
+        s.start_next_sample();
+      }
+      s.start_pixel(vec2i(px[0], px[1]), 0);
+      for (int i = 0; i < s.spp(); i++) {
+        for (int d = 0; d < 90; d++) {
+          out.push_back(s.get1d());
+          auto v = s.get2d();
+          out.push_back(v.x);
+          out.push_back(v.y);
+        }
+        s.start_next_sample();
+      }
+    }
+    write_file(argv[3], out.data(), out.size() * 4);
+    return 0;
+  }
+  if (cmd == "rng" && argc == 3) {
+    // per pixel: hash (u64), state after seeding (2 x u64), then 16 nextf as raw bits (u32, padded
+    // to u64) -- all as u64 words.
+    std::vector<uint64_t> out;
+    for (auto& px : kPixels) {
+      uint64_t h = hash(vec2i(px[0], px[1]), int(0));
+      out.push_back(h);
+      RNG r(h);
+      out.push_back(r.s[0]);
+      out.push_back(r.s[1]);
+      for (int i = 0; i < 16; i++) {
+        float f = r.nextf();
+        uint32_t b;
+        memcpy(&b, &f, 4);
+        out.push_back(b);
+      }
+    }
+    write_file(argv[2], out.data(), out.size() * 8);
+    return 0;
+  }
+  if (cmd == "host" && argc == 3) {
+    // host-side math known answers: the two cbox box transforms + inverses, look_at for both
+    // cameras, coordinate_system of a few normals.
+    std::vector<float> out;
+    auto push4 = [&](mat4 m) {
+      for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) out.push_back(m[c][r]);  // column-major storage order
+    };
+    auto push3 = [&](mat3 m) {
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) out.push_back(m[c][r]);
+    };
+    auto m0 = translate(vec3(0.0f, 0.0f, 0.6f)) * rotate_y(0.4f) * scale(vec3(0.6f, 0.6f, 0.6f));
+    auto m1 = translate(vec3(-0.6f, 0.0f, 1.0f)) * rotate_y(-0.4f) * scale(vec3(0.6f, 1.3f, 0.6f));
+    push4(m0);
+    push4(inverse(m0));
+    push4(m1);
+    push4(inverse(m1));
+    push4(look_at(vec3(0, 0, 0), vec3(0, 0, 1)));
+    push4(look_at(vec3(0, 1, -4), vec3(0, 1, 0)));
+    push4(look_at(vec3(0, 4, -8), vec3(0, 1, 0)));
+    push4(rotate_x(0.3f) * rotate_z(-1.1f));
+    vec3 ns[] = {vec3(0, 1, 0), vec3(1, 0, 0), vec3(0, 0, -1), normalize(vec3(1, 2, 3)),
+                 normalize(vec3(-3, 2, 0.5f))};
+    for (auto n : ns) push3(coordinate_system(n));
+    write_file(argv[2], out.data(), out.size() * 4);
+    return 0;
+  }
+  if (cmd == "shapes" && argc == 5) {
+    // For every geometry g in the scene and every ray r (8 floats: o, d, tmin, tmax):
+    //   hit(r) -> 1 float (0/1); intersect(r) -> hit flag, tmax after; compute_surface_info at
+    //   ray(tmax) -> p(3), n(3), uv(2)   => 11 floats per (g, r)
+    Loaded L;
+    load_pscene(argv[2], L);
+    std::ifstream rf(argv[3], std::ios::binary);
+    std::vector<float> rays((std::istreambuf_iterator<char>(rf)), {});
+    rays.clear();
+    rf.clear();
+    rf.seekg(0, std::ios::end);
+    size_t nbytes = rf.tellg();
+    rf.seekg(0);
+    rays.resize(nbytes / 4);
+    rf.read((char*)rays.data(), nbytes);
+    size_t nr = rays.size() / 8;
+    std::vector<float> out;
+    for (auto& g : L.scene.geometries) {
+      if (g->shape.is<Mesh>()) continue;
+      for (size_t i = 0; i < nr; i++) {
+        const float* q = &rays[i * 8];
+        Ray r(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
+        out.push_back(g->hit(r) ? 1.0f : 0.0f);
+        SurfaceInteraction it;
+        Ray r2 = r;
+        bool h = g->intersect(r2, it);
+        out.push_back(h ? 1.0f : 0.0f);
+        out.push_back(r2.tmax);
+        if (h) g->compute_surface_info(r2(), it);
+        out.push_back(it.p.x);
+        out.push_back(it.p.y);
+        out.push_back(it.p.z);
+        out.push_back(it.n.x);
+        out.push_back(it.n.y);
+        out.push_back(it.n.z);
+        out.push_back(it.uv.x);
+        out.push_back(it.uv.y);
+      }
+    }
+    write_file(argv[4], out.data(), out.size() * 4);
+    return 0;
+  }
+  fprintf(stderr, "usage: see header of oracle/ref_driver.cpp\n");
+  return 2;
+}

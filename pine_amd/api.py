@@ -1,0 +1,376 @@
+"""Host-side mirror of the reference's script-visible interface for the PathIntegrator path.
+
+Names, argument order and error behaviour follow what a `.pine` script sees (registered in
+src/pine/core/program_context.cpp:23-125 and the *_context functions it calls), e.g.
+
+    scene = Scene()
+    scene.add("floor", Diffuse([0.9, 0.9, 0.9]))
+    scene.add(Rect([0, 0, 1], [2, 0, 0], [0, 0, 2], True), "floor")
+    scene.set(ThinLenCamera(Film([640, 640], Uncharted2()), [0, 0, 0], [0, 0, 1], 0.4))
+    PathIntegrator(BlueSampler(256), 8).render(scene)
+    scene.camera.film().save("images/cbox.png")
+
+Everything here is plumbing over the C ABI (include/pine_gpu.h); all arithmetic that feeds the
+render (shape constructors, matrices, camera, BVH) happens in libpine_gpu.so.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, PineError, f3, f16
+
+
+def _v3(v):
+    v = list(v)
+    if len(v) != 3:
+        raise PineError("expected a vec3")
+    return f3(*[float(x) for x in v])
+
+
+# ---- mat4 (PRL builtins translate/rotate_*/scale/look_at, vecmath.h:1102-1180) -----------------
+class mat4:
+    """Column-vector 4x4 float matrix in the reference's storage order (m[c*4 + r])."""
+
+    def __init__(self, storage=None):
+        self.s = f16()
+        if storage is None:
+            lib.pine_gpu_mat4_identity(self.s)
+        else:
+            for i, x in enumerate(storage):
+                self.s[i] = float(x)
+
+    def __mul__(self, other):
+        out = mat4()
+        lib.pine_gpu_mat4_mul(self.s, other.s, out.s)
+        return out
+
+    def numpy(self):
+        """4x4 array indexed [row, col]."""
+        return np.array(list(self.s), dtype=np.float32).reshape(4, 4).T.copy()
+
+
+def translate(v):
+    out = mat4()
+    lib.pine_gpu_mat4_translate(_v3(v), out.s)
+    return out
+
+
+def scale(v):
+    out = mat4()
+    lib.pine_gpu_mat4_scale(_v3(v), out.s)
+    return out
+
+
+def rotate_x(rad):
+    out = mat4()
+    lib.pine_gpu_mat4_rotate_x(float(rad), out.s)
+    return out
+
+
+def rotate_y(rad):
+    out = mat4()
+    lib.pine_gpu_mat4_rotate_y(float(rad), out.s)
+    return out
+
+
+def rotate_z(rad):
+    out = mat4()
+    lib.pine_gpu_mat4_rotate_z(float(rad), out.s)
+    return out
+
+
+def inverse(m):
+    out = mat4()
+    lib.pine_gpu_mat4_inverse(m.s, out.s)
+    return out
+
+
+def look_at(frm, to):
+    out = mat4()
+    lib.pine_gpu_mat4_look_at(_v3(frm), _v3(to), out.s)
+    return out
+
+
+# ---- materials (src/pine/core/material.cpp:46-62) ---------------------------------------------
+class Material:
+    pass
+
+
+class Emissive(Material):
+    def __init__(self, color):
+        self.color = color
+
+
+class Diffuse(Material):
+    def __init__(self, albedo):
+        self.albedo = albedo
+
+
+class Uber(Material):
+    def __init__(self, albedo, roughness, metallic=0.0, transmission=0.0, ior=1.45):
+        self.albedo, self.roughness, self.metallic, self.transmission, self.ior = albedo, roughness, metallic, transmission, ior
+
+
+class Subsurface(Material):
+    def __init__(self, albedo, roughness, sigma_s):
+        self.albedo, self.roughness, self.sigma_s = albedo, roughness, sigma_s
+
+
+# ---- shapes (src/pine/core/geometry.cpp:901-946) ------------------------------------------------
+class Shape:
+    pass
+
+
+class Rect(Shape):
+    def __init__(self, position, ex, ey, flip_normal=False):
+        self.position, self.ex, self.ey, self.flip_normal = position, ex, ey, flip_normal
+
+
+class AABB(Shape):
+    def __init__(self, lower, upper):
+        self.lower, self.upper = lower, upper
+
+
+class OBB(Shape):
+    def __init__(self, aabb, m):
+        self.aabb, self.m = aabb, m
+
+
+def Box(*args):
+    """Box(lower, upper) | Box(AABB, mat4) | Box(lower, upper, mat4) -- geometry.cpp:913-918."""
+    if len(args) == 2 and isinstance(args[0], AABB):
+        return OBB(args[0], args[1])
+    if len(args) == 2:
+        return AABB(args[0], args[1])
+    if len(args) == 3:
+        return OBB(AABB(args[0], args[1]), args[2])
+    raise PineError("Box: no matching overload")
+
+
+class Sphere(Shape):
+    def __init__(self, center, radius):
+        self.center, self.radius = center, radius
+
+
+class Disk(Shape):
+    def __init__(self, position, normal, radius):
+        self.position, self.normal, self.radius = position, normal, radius
+
+
+class Cone(Shape):
+    def __init__(self, position, normal, radius, height):
+        self.position, self.normal, self.radius, self.height = position, normal, radius, height
+
+
+class Mesh(Shape):
+    def __init__(self, vertices, indices):
+        self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+
+
+# ---- film / camera / sampler -------------------------------------------------------------------
+class Uncharted2:
+    code = 0
+
+
+class ACES:
+    code = 1
+
+
+class Film:
+    """Film(size[, tonemapper]) -- src/pine/core/film.h:24-27.  pixels: H x W x 4 float32, row 0 first."""
+
+    def __init__(self, size, tone_mapper=None):
+        self.size = (int(size[0]), int(size[1]))
+        self.tone_mapper = tone_mapper or Uncharted2()
+        self.pixels = np.zeros((self.size[1], self.size[0], 4), dtype=np.float32)
+
+    def width(self):
+        return self.size[0]
+
+    def height(self):
+        return self.size[1]
+
+    def finalize_u8(self):
+        """film.finalize() + gamma + y-flip as save() does (film.cpp:12-27, fileio.cpp:42-54)."""
+        w, h = self.size
+        out = np.zeros((h, w, 4), dtype=np.uint8)
+        src = np.ascontiguousarray(self.pixels, dtype=np.float32)
+        check(lib.pine_gpu_film_finalize_u8(src.ctypes.data_as(_lib.c_f_p), w, h, self.tone_mapper.code,
+                                            out.ctypes.data_as(C.POINTER(C.c_uint8))), "film.finalize")
+        return out
+
+    def save(self, filename):
+        """scene.camera.film().save(path): 8-bit PNG of the tone-mapped film."""
+        from . import png
+        png.write_png(filename, self.finalize_u8())
+
+
+class ThinLenCamera:
+    def __init__(self, film, frm, to, fov, len_radius=0.0, focus_distance=1.0):
+        self._film, self.frm, self.to, self.fov = film, frm, to, fov
+        self.len_radius, self.focus_distance = len_radius, focus_distance
+
+    def film(self):
+        return self._film
+
+
+class BlueSampler:
+    """BlueSobolSampler: spp rounded up to a power of two and clamped to 256 (sampler.cpp:115-121)."""
+
+    def __init__(self, samples_per_pixel):
+        if samples_per_pixel <= 0:
+            raise PineError("`BlueSampler` should have positive samples per pixel")
+        self.requested = int(samples_per_pixel)
+
+    def spp(self):
+        n = min(self.requested, 256)
+        p = 1
+        while p < n:
+            p *= 2
+        return p
+
+
+# ---- Scene (src/pine/core/scene.cpp:64-79) -----------------------------------------------------
+class Scene:
+    def __init__(self):
+        self._h = C.c_void_p(check(lib.pine_gpu_scene_create(), "Scene()"))
+        self.camera = None
+        self._anon = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib.pine_gpu_scene_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # scene.add(name, material) | scene.add(shape, material | name)
+    def add(self, a, b):
+        if isinstance(a, str) and isinstance(b, Material):
+            return self._add_material(a, b)
+        if isinstance(a, Shape):
+            if isinstance(b, str):
+                mid = check(lib.pine_gpu_scene_find_material(self._h, b.encode()), "scene.add")
+            elif isinstance(b, Material):
+                mid = self._add_material("", b)
+            else:
+                raise PineError("scene.add: second argument must be a material or a material name")
+            return self._add_shape(a, mid)
+        raise PineError("scene.add: no matching overload")
+
+    def set(self, camera):
+        if not isinstance(camera, ThinLenCamera):
+            raise PineError("scene.set: expected a camera")
+        f = camera.film()
+        check(lib.pine_gpu_scene_set_camera_thinlens(self._h, f.size[0], f.size[1], f.tone_mapper.code,
+                                                     _v3(camera.frm), _v3(camera.to), float(camera.fov),
+                                                     float(camera.len_radius), float(camera.focus_distance)),
+              "scene.set")
+        self.camera = camera
+        return camera
+
+    def _add_material(self, name, m):
+        n = name.encode()
+        if isinstance(m, Emissive):
+            return check(lib.pine_gpu_scene_add_material_emissive(self._h, n, _v3(m.color)), "Emissive")
+        if isinstance(m, Diffuse):
+            return check(lib.pine_gpu_scene_add_material_diffuse(self._h, n, _v3(m.albedo)), "Diffuse")
+        if isinstance(m, Uber):
+            return check(lib.pine_gpu_scene_add_material_uber(self._h, n, _v3(m.albedo), float(m.roughness),
+                                                              float(m.metallic), float(m.transmission), float(m.ior)), "Uber")
+        if isinstance(m, Subsurface):
+            return check(lib.pine_gpu_scene_add_material_subsurface(self._h, n, _v3(m.albedo), float(m.roughness),
+                                                                    _v3(m.sigma_s)), "Subsurface")
+        raise PineError("unsupported material")
+
+    def _add_shape(self, s, mid):
+        h = self._h
+        if isinstance(s, Rect):
+            return check(lib.pine_gpu_scene_add_rect(h, _v3(s.position), _v3(s.ex), _v3(s.ey), int(bool(s.flip_normal)), mid), "Rect")
+        if isinstance(s, AABB):
+            return check(lib.pine_gpu_scene_add_aabb(h, _v3(s.lower), _v3(s.upper), mid), "Box")
+        if isinstance(s, OBB):
+            return check(lib.pine_gpu_scene_add_obb(h, _v3(s.aabb.lower), _v3(s.aabb.upper), s.m.s, mid), "Box")
+        if isinstance(s, Sphere):
+            return check(lib.pine_gpu_scene_add_sphere(h, _v3(s.center), float(s.radius), mid), "Sphere")
+        if isinstance(s, Disk):
+            return check(lib.pine_gpu_scene_add_disk(h, _v3(s.position), _v3(s.normal), float(s.radius), mid), "Disk")
+        if isinstance(s, Cone):
+            return check(lib.pine_gpu_scene_add_cone(h, _v3(s.position), _v3(s.normal), float(s.radius), float(s.height), mid), "Cone")
+        if isinstance(s, Mesh):
+            return check(lib.pine_gpu_scene_add_mesh(h, s.vertices.ctypes.data_as(_lib.c_f_p), len(s.vertices),
+                                                     s.indices.ctypes.data_as(C.POINTER(C.c_uint32)), len(s.indices), mid), "Mesh")
+        raise PineError("unsupported shape")
+
+    def describe(self) -> str:
+        """The scene as .pscene text (exchange format shared with the oracle and the reference driver)."""
+        n = check(lib.pine_gpu_scene_describe(self._h, None, 0), "describe")
+        buf = C.create_string_buffer(n + 1)
+        lib.pine_gpu_scene_describe(self._h, buf, n + 1)
+        return buf.value.decode()
+
+
+# ---- PathIntegrator (program_context.cpp:76-81) -------------------------------------------------
+class Plan:
+    """A PathIntegrator bound to a scene with all device state resident (bench / multi-GPU)."""
+
+    def __init__(self, scene, spp, max_path_length, device=0, shard_rank=0, shard_world=1,
+                 samples_per_item=0, timing=False):
+        if scene.camera is None:
+            raise PineError("scene has no camera")
+        self.scene = scene
+        self.params = _lib.RenderParams(int(spp), int(max_path_length), int(device), int(shard_rank),
+                                        int(shard_world), int(samples_per_item),
+                                        _lib.FLAG_TIMING if timing else 0, 0)
+        h = lib.pine_gpu_plan_create(scene._h, C.byref(self.params))
+        if not h:
+            raise PineError("PathIntegrator: " + _lib.last_error())
+        self._h = C.c_void_p(h)
+
+    def launch(self, film_dev_ptr, stream_ptr=0):
+        check(lib.pine_gpu_plan_launch(self._h, C.c_void_p(film_dev_ptr), C.c_void_p(stream_ptr)), "render")
+
+    def stats(self):
+        st = _lib.PlanStats()
+        check(lib.pine_gpu_plan_stats_get(self._h, C.byref(st)), "stats")
+        return st
+
+    def read_samples(self):
+        w, h = self.scene.camera.film().size
+        spp = self.stats().spp_effective
+        out = np.zeros((h, w, spp, 4), dtype=np.float32)
+        check(lib.pine_gpu_plan_read_samples(self._h, out.ctypes.data_as(_lib.c_f_p), out.size), "read_samples")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pine_gpu_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PathIntegrator:
+    """PathIntegrator(sampler, max_path_length).render(scene) -- the convenience overload a .pine
+    script uses (program_context.cpp:79-81); pine-BVH traversal order, UniformLightSampler."""
+
+    def __init__(self, sampler, max_path_length, device=0):
+        if max_path_length <= 0:  # path.cpp:12-13
+            raise PineError(f"`PathIntegrator` expect `max_path_length` to be positive, get {max_path_length}")
+        self.sampler, self.max_path_length, self.device = sampler, int(max_path_length), device
+
+    def render(self, scene):
+        if scene.camera is None:
+            raise PineError("scene has no camera")
+        film = scene.camera.film()
+        prm = _lib.RenderParams(self.sampler.requested, self.max_path_length, self.device, 0, 1, 0, 0, 0)
+        out = np.zeros((film.size[1], film.size[0], 4), dtype=np.float32)
+        check(lib.pine_gpu_path_render(scene._h, C.byref(prm), out.ctypes.data_as(_lib.c_f_p)), "PathIntegrator.render")
+        film.pixels = out
+        return film

@@ -1,0 +1,958 @@
+// pine_amd/csrc/pine_device.h -- device-side restatement of the reference's per-ray algorithms:
+// sampler / RNG, ray spawn, shape hit / intersect / surface info / light sampling, BSDFs.
+// Pure functions over the POD records of pine_types.h; no memory allocation, no recursion.
+// The traversal loop and the path state machine live in pine_kernels.hip.
+//
+// Reference citations are paths relative to the reference repository (wicstas/pine).  Floating
+// point: binary32, no contraction, operand order of the reference; sin/cos via pine_libm.h.
+#pragma once
+#include "pine_math.h"
+#include "pine_types.h"
+
+namespace pine_gpu {
+
+// ------------------------------------------------------------------------------------------------
+// hash + RNG (src/pine/core/rng.h:9-144) -- integer exact
+// ------------------------------------------------------------------------------------------------
+PINE_HD uint64_t hash_pixel(int px, int py, int sample_index) {
+  // murmur_hash64A over the 12 bytes {px, py, sample_index}, seed 0 (rng.h:9-49, :60-65)
+  const uint64_t m = 0xc6a4a7935bd1e995ull;
+  const int r = 47;
+  uint64_t h = 0 ^ (12ull * m);
+  uint64_t k = uint64_t(uint32_t(px)) | (uint64_t(uint32_t(py)) << 32);
+  k *= m;
+  k ^= k >> r;
+  k *= m;
+  h ^= k;
+  h *= m;
+  uint32_t t = uint32_t(sample_index);  // tail of 4 bytes: cases 4..1
+  h ^= uint64_t((t >> 24) & 0xff) << 24;
+  h ^= uint64_t((t >> 16) & 0xff) << 16;
+  h ^= uint64_t((t >> 8) & 0xff) << 8;
+  h ^= uint64_t(t & 0xff);
+  h *= m;
+  h ^= h >> r;
+  h *= m;
+  h ^= h >> r;
+  return h;
+}
+struct DRng {
+  uint64_t s0, s1;
+};
+PINE_HD uint64_t split_mix_64(uint64_t& s) {  // rng.h:72-77
+  uint64_t r = s += 0x9E3779B97f4A7C15ULL;
+  r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  r = (r ^ (r >> 27)) * 0x94D049BB133111EBULL;
+  return r ^ (r >> 31);
+}
+PINE_HD DRng rng_seed(uint64_t seed) {  // RNG::RNG rng.h:98-101
+  DRng g;
+  g.s0 = split_mix_64(seed);
+  g.s1 = split_mix_64(seed);
+  return g;
+}
+PINE_HD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+PINE_HD uint64_t rng_next64(DRng& g) {  // rng.h:116-126
+  const uint64_t s0 = g.s0;
+  uint64_t s1 = g.s1;
+  const uint64_t result = s0 + s1;
+  s1 ^= s0;
+  g.s0 = rotl64(s0, 24) ^ s1 ^ (s1 << 16);
+  g.s1 = rotl64(s1, 37);
+  return result;
+}
+PINE_HD float rng_nextf(DRng& g) {  // rng.h:132-135
+  uint64_t u = rng_next64(g);
+  return pmin(float(uint32_t(u ^ (u >> 32))) * 0x1p-32f, kOneMinusEps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BlueSobolSampler (src/pine/core/sampler.h:166-201, src/contrib/bluesobol/bluenoise_*spp.cpp:14-34)
+// ------------------------------------------------------------------------------------------------
+struct DTables {
+  const uint8_t* sobol;     // [256*256]
+  const uint8_t* scramble;  // [128*128*8] of the selected spp variant
+  const uint8_t* rank;      // [128*128*8]
+};
+PINE_HD float blue_sample_dimension(const DTables& t, int px, int py, int index, int dim) {
+  const int pix = (px & 127) + (py & 127) * 128;
+  const int si = index & 255;
+  const int sd = dim & 255;
+  const int ranked = si ^ int(t.rank[(sd + pix * 8) % (128 * 128 * 8)]);
+  int value = t.sobol[sd + ranked * 256];
+  value = value ^ int(t.scramble[(sd % 8) + pix * 8]);
+  return (0.5f + float(value)) / 256.0f;
+}
+struct DSampler {
+  int px, py;
+  int index;      // sample index within the pixel
+  int dimension;  // BlueSobolSampler::dimension
+  DRng rng;
+};
+PINE_HD float sampler_get1d(const DTables& t, DSampler& s) {  // sampler.h:183-187
+  if (s.dimension >= 256) s.dimension = 2;
+  return blue_sample_dimension(t, s.px, s.py, s.index, s.dimension++);
+}
+PINE_HD f2 sampler_get2d(const DTables& t, DSampler& s) {  // sampler.h:188-194
+  if (s.dimension + 1 >= 256) s.dimension = 2;
+  const int dim = s.dimension;
+  s.dimension += 2;
+  const float a = blue_sample_dimension(t, s.px, s.py, s.index, dim);
+  const float b = blue_sample_dimension(t, s.px, s.py, s.index, dim + 1);
+  return f2{a, b};
+}
+// with_probability (sampler.h:317-324): consumes an RNG float only for prob strictly in (0,1)
+PINE_HD bool with_probability(float prob, DSampler& s) {
+  if (prob == 0) return false;
+  if (prob == 1) return true;
+  return rng_nextf(s.rng) < prob;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling.h:8-89
+// ------------------------------------------------------------------------------------------------
+PINE_HD f2 sample_disk_polar(f2 u) {
+  const float r = psqrt(u.x);
+  const float theta = 2 * kPi * u.y;
+  return f2{r * pcos(theta), r * psin(theta)};
+}
+PINE_HD f2 sample_disk_concentric(f2 u) {
+  u = f2{u.x * 2 - 1.0f, u.y * 2 - 1.0f};
+  float theta, r;
+  if (pabs(u.x) > pabs(u.y)) {
+    r = u.x;
+    theta = kPi / 4.0f * u.y / u.x;
+  } else {
+    r = u.y;
+    theta = kPi / 2.0f - kPi / 4.0f * (u.x / u.y);
+  }
+  return r * f2{pcos(theta), psin(theta)};
+}
+PINE_HD f3 cosine_weighted_hemisphere(f2 u) {
+  const f2 d = sample_disk_concentric(u);
+  const float z = psqrt(pmax(1.0f - d.x * d.x - d.y * d.y, 0.0f));
+  return f3{d.x, d.y, z};
+}
+PINE_HD f3 uniform_sphere(f2 u) {
+  const float phi = u.x * kPi * 2;
+  const float cos_theta = 1 - 2 * u.y;
+  const float sin_theta = psqrt(1.0f - sqr(cos_theta));
+  return f3{sin_theta * pcos(phi), sin_theta * psin(phi), cos_theta};
+}
+PINE_HD float balance_heuristic(float pF, float pG) { return pF / (pF + pG); }
+
+// ------------------------------------------------------------------------------------------------
+// Ray, spawn_ray (src/pine/core/ray.h:8-46, src/pine/core/interaction.cpp:6-13)
+// ------------------------------------------------------------------------------------------------
+struct DRay {
+  f3 o, d;
+  float tmin, tmax;
+};
+PINE_HD f3 ray_at(const DRay& r, float t) { return r.o + t * r.d; }
+PINE_HD f3 offset_ray_origin(f3 p, f3 n) {  // ray.h:25-37: integer ULP stepping on the float bits
+  const float origin = 1.0f / 32.0f;
+  const float float_scale = 1.0f / 65536.0f;
+  const float int_scale = 256.0f;
+  const int ox = int(int_scale * n.x), oy = int(int_scale * n.y), oz = int(int_scale * n.z);
+  const float pix = as_float(as_int(p.x) + (p.x < 0 ? -ox : ox));
+  const float piy = as_float(as_int(p.y) + (p.y < 0 ? -oy : oy));
+  const float piz = as_float(as_int(p.z) + (p.z < 0 ? -oz : oz));
+  return f3{pabs(p.x) < origin ? p.x + n.x * float_scale : pix,
+            pabs(p.y) < origin ? p.y + n.y * float_scale : piy,
+            pabs(p.z) < origin ? p.z + n.z * float_scale : piz};
+}
+// SurfaceInteraction::spawn_ray (interaction.cpp:6-13)
+PINE_HD DRay spawn_ray(f3 p, f3 n, f3 wo, float tmax) {
+  DRay r;
+  r.d = wo;
+  r.o = offset_ray_origin(p, face_same_hemisphere(n, wo));
+  r.tmin = 0.0f;
+  r.tmax = tmax * (1.0f - 1e-3f);
+  return r;
+}
+// free spawn_ray(p, n, wo) (ray.h:39-46) -- no hemisphere flip; used by the BSSRDF walk
+PINE_HD DRay spawn_ray_raw(f3 p, f3 n, f3 wo) {
+  DRay r;
+  r.o = offset_ray_origin(p, n);
+  r.d = wo;
+  r.tmin = 0.0f;
+  r.tmax = kFloatMax * (1.0f - 1e-3f);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AABB slab tests
+// ------------------------------------------------------------------------------------------------
+struct DRayOct {  // RayOctant bbox.h:18-27
+  f3 dir_inv, org_div_dir;
+  int neg;  // bit i set when d[i] < 0
+};
+PINE_HD DRayOct make_oct(const DRay& r) {
+  DRayOct o;
+  o.dir_inv = f3{safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z)};
+  o.org_div_dir = r.o * o.dir_inv;
+  o.neg = (r.d.x < 0 ? 1 : 0) | (r.d.y < 0 ? 2 : 0) | (r.d.z < 0 ? 4 : 0);
+  return o;
+}
+// AABB::hit(RayOctant, tmin, tmax&) bbox.h:59-72
+PINE_HD bool box_hit_oct(const float* lo, const float* hi, const DRayOct& r, float tmin, float& tmax) {
+  const bool nx = r.neg & 1, ny = r.neg & 2, nz = r.neg & 4;
+  const float tmin0 = (nx ? hi[0] : lo[0]) * r.dir_inv.x - r.org_div_dir.x;
+  const float tmin1 = (ny ? hi[1] : lo[1]) * r.dir_inv.y - r.org_div_dir.y;
+  const float tmin2 = (nz ? hi[2] : lo[2]) * r.dir_inv.z - r.org_div_dir.z;
+  const float tmax0 = (nx ? lo[0] : hi[0]) * r.dir_inv.x - r.org_div_dir.x;
+  const float tmax1 = (ny ? lo[1] : hi[1]) * r.dir_inv.y - r.org_div_dir.y;
+  const float tmax2 = (nz ? lo[2] : hi[2]) * r.dir_inv.z - r.org_div_dir.z;
+  tmin = pmax(tmin0, pmax(tmin1, pmax(tmin2, tmin)));  // psl::max(a,b,c,d) src/psl/math.h:52-61
+  tmax = pmin(tmax0, pmin(tmax1, pmin(tmax2, tmax)));
+  return tmin <= tmax;
+}
+// AABB::intersect(o, d, tmin&, tmax&) bbox.cpp:94-111 (also the body of AABB::hit(Ray) :75-93)
+PINE_HD bool box_slabs(f3 lo, f3 hi, f3 o, f3 d, float& tmin, float& tmax) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float di = get(d, i), oi = get(o, i), l = get(lo, i), h = get(hi, i);
+    if (pabs(di) < 1e-6f) {
+      if (oi < l || oi > h) return false;
+      continue;
+    }
+    const float inv_d = 1.0f / di;
+    float t_near = (l - oi) * inv_d;
+    float t_far = (h - oi) * inv_d;
+    if (inv_d < 0.0f) {
+      const float t = t_far;
+      t_far = t_near;
+      t_near = t;
+    }
+    tmin = pmax(t_near, tmin);
+    tmax = pmin(t_far, tmax);
+    if (tmin > tmax) return false;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shapes: any-hit, closest-hit (shrinks ray.tmax), surface info.  S is the 128-byte record.
+// ------------------------------------------------------------------------------------------------
+struct DSurface {
+  f3 p, n;
+  f2 uv;
+};
+
+PINE_HD bool intersect_quadratic(float a, float b, float c, float tmin, float& tmax) {  // geometry.cpp:20-29
+  float d = b * b - 4 * a * c;
+  if (d <= 0.0f) return false;
+  d = psqrt(d);
+  float t = (-b - d) / (2 * a);
+  if (t < tmin) t += d / a;
+  if (t < tmin || t > tmax) return false;
+  tmax = t;
+  return true;
+}
+PINE_HD float sphere_compute_t(f3 ro, f3 rd, float tmin, f3 p, float r) {  // geometry.cpp:73-83
+  const f3 ro_p = ro - p;
+  const float b = dot(ro_p, rd);
+  const float c = dot(ro_p, ro_p) - r * r;
+  float d = b * b - c;
+  if (d <= 0.0f) return -1.0f;
+  d = psqrt(d);
+  float t = -b - d;
+  if (t < tmin) t = -b + d;
+  return t;
+}
+
+// Rect::hit / Rect::intersect share the plane + extent test (geometry.cpp:275-299)
+PINE_HD bool rect_test(const float* f, const DRay& ray, float& t_out) {
+  const f3 position = ld3(f), n = ld3(f + 9);
+  const float denom = dot(ray.d, n);
+  if (denom == 0.0f) return false;
+  const float t = (dot(position - ray.o, n)) / denom;
+  if (t <= ray.tmin || t >= ray.tmax) return false;
+  const f3 p = ray_at(ray, t) - position;
+  const float u = dot(p, ld3(f + 14));
+  if (u < -0.5f || u > 0.5f) return false;
+  const float v = dot(p, ld3(f + 17));
+  if (v < -0.5f || v > 0.5f) return false;
+  t_out = t;
+  return true;
+}
+// OBB: ray into object space with a re-normalised direction but WORLD tmin/tmax (bbox.cpp:145-163)
+PINE_HD void obb_local_ray(const float* f, f3 o, f3 d, f3& lo_o, f3& lo_d) {
+  const m34 mi = ld34(f + 18);
+  lo_o = mul_point(mi, o);
+  lo_d = normalize(mul(linear(mi), d));
+}
+PINE_HD bool cone_quadratic(const float* f, const DRay& ray, float& tmax, float& side) {  // geometry.cpp:415-434
+  const f3 p = ld3(f), n = ld3(f + 3);
+  const float A2 = f[9];
+  const f3 o = ray.o - p;
+  const f3 d = ray.d;
+  const float a = -A2 * sqr(dot(d, n)) + dot(d, d);
+  const float b = 2 * (-A2 * dot(o, n) * dot(d, n) + dot(o, d));
+  const float c = -A2 * sqr(dot(o, n)) + dot(o, o);
+  tmax = ray.tmax;
+  if (!intersect_quadratic(a, b, c, ray.tmin, tmax)) return false;
+  side = dot(o + tmax * d, n);
+  return true;
+}
+
+PINE_HD bool shape_hit(const DShape* S, const DRay& ray) {
+  const float* f = S->f;
+  switch (S->kind) {
+    case SHAPE_RECT: {
+      float t;
+      return rect_test(f, ray, t);
+    }
+    case SHAPE_AABB: {  // AABB::hit(Ray) bbox.cpp:75-93
+      float tmin = ray.tmin, tmax = ray.tmax;
+      if (tmin > tmax) return false;
+      return box_slabs(ld3(f), ld3(f + 3), ray.o, ray.d, tmin, tmax);
+    }
+    case SHAPE_OBB: {  // OBB::hit bbox.cpp:145-149
+      f3 o, d;
+      obb_local_ray(f, ray.o, ray.d, o, d);
+      float tmin = ray.tmin, tmax = ray.tmax;
+      if (tmin > tmax) return false;
+      return box_slabs(ld3(f), ld3(f + 3), o, d, tmin, tmax);
+    }
+    case SHAPE_SPHERE: {  // geometry.cpp:84-87
+      const float t = sphere_compute_t(ray.o, ray.d, ray.tmin, ld3(f), f[3]);
+      return t > ray.tmin && t < ray.tmax;
+    }
+    case SHAPE_DISK: {  // geometry.cpp:128-137
+      const f3 position = ld3(f), n = ld3(f + 3);
+      const float denom = dot(ray.d, n);
+      if (denom == 0.0f) return false;
+      const float t = (dot(position, n) - dot(ray.o, n)) / denom;
+      if (t < ray.tmin) return false;
+      if (t >= ray.tmax) return false;
+      const f3 p = ray_at(ray, t) - position;
+      if (length_squared(p) > sqr(f[12])) return false;
+      return true;
+    }
+    case SHAPE_CONE: {  // geometry.cpp:415-427
+      float tmax, side;
+      return cone_quadratic(f, ray, tmax, side) && side <= 0;
+    }
+    default: return false;
+  }
+}
+
+PINE_HD bool shape_intersect(const DShape* S, DRay& ray) {
+  const float* f = S->f;
+  switch (S->kind) {
+    case SHAPE_RECT: {
+      float t;
+      if (!rect_test(f, ray, t)) return false;
+      ray.tmax = t;
+      return true;
+    }
+    case SHAPE_AABB: {  // bbox.cpp:112-121
+      float tmin = ray.tmin, tmax = ray.tmax;
+      if (!box_slabs(ld3(f), ld3(f + 3), ray.o, ray.d, tmin, tmax)) return false;
+      ray.tmax = tmin > ray.tmin ? tmin : tmax;
+      return true;
+    }
+    case SHAPE_OBB: {  // bbox.cpp:150-172: endpoints mapped back to world distances
+      f3 o, d;
+      obb_local_ray(f, ray.o, ray.d, o, d);
+      float tmin = ray.tmin, tmax = ray.tmax;
+      if (!box_slabs(ld3(f), ld3(f + 3), o, d, tmin, tmax)) return false;
+      const m34 m = ld34(f + 6);
+      const f3 ps = o + tmin * d;
+      const f3 pe = o + tmax * d;
+      tmin = distance(mul_point(m, ps), ray.o);
+      tmax = distance(mul_point(m, pe), ray.o);
+      ray.tmax = tmin > ray.tmin ? tmin : tmax;
+      return true;
+    }
+    case SHAPE_SPHERE: {  // geometry.cpp:88-93
+      const float t = sphere_compute_t(ray.o, ray.d, ray.tmin, ld3(f), f[3]);
+      if (t < ray.tmin || t > ray.tmax) return false;
+      ray.tmax = t;
+      return true;
+    }
+    case SHAPE_DISK: {  // geometry.cpp:138-148
+      const f3 position = ld3(f), n = ld3(f + 3);
+      const float denom = dot(ray.d, n);
+      if (denom == 0.0f) return false;
+      const float t = (dot(position, n) - dot(ray.o, n)) / denom;
+      if (t < ray.tmin || t > ray.tmax) return false;
+      const f3 p = ray_at(ray, t) - position;
+      if (length_squared(p) > sqr(f[12])) return false;
+      ray.tmax = t;
+      return true;
+    }
+    case SHAPE_CONE: {  // geometry.cpp:428-454
+      float tmax, side;
+      if (cone_quadratic(f, ray, tmax, side) && side < 0) {
+        ray.tmax = tmax;
+        return true;
+      }
+      return false;
+    }
+    default: return false;
+  }
+}
+
+// AABB::compute_surface_info bbox.cpp:122-129
+PINE_HD void aabb_surface_info(f3 lo, f3 hi, f3 p, DSurface& it) {
+  it.p = p;
+  const f3 pu = (p - (lo + hi) / 2.0f) / (hi - lo);
+  const int axis = max_axis(vabs(pu));
+  it.n = mk3(0.0f);
+  const bool pos = get(pu, axis) > 0;
+  set(it.n, axis, pos ? 1.0f : -1.0f);
+  set(it.p, axis, pos ? get(hi, axis) : get(lo, axis));
+}
+
+PINE_HD void shape_surface_info(const DShape* S, f3 p, DSurface& it) {
+  const float* f = S->f;
+  it.uv = f2{0, 0};
+  switch (S->kind) {
+    case SHAPE_RECT: {  // geometry.cpp:300-307
+      const f3 position = ld3(f);
+      const f3 rp = p - position;
+      const float u = dot(rp, ld3(f + 14));
+      const float v = dot(rp, ld3(f + 17));
+      it.p = position + f[12] * ld3(f + 3) * u + f[13] * ld3(f + 6) * v;
+      it.n = ld3(f + 9);
+      it.uv = f2{u, v} + f2{0.5f, 0.5f};
+      break;
+    }
+    case SHAPE_AABB: aabb_surface_info(ld3(f), ld3(f + 3), p, it); break;
+    case SHAPE_OBB: {  // bbox.cpp:173-177
+      const m34 mi = ld34(f + 18);
+      aabb_surface_info(ld3(f), ld3(f + 3), mul_point(mi, p), it);
+      it.p = mul_point(ld34(f + 6), it.p);
+      it.n = normalize(mul(transpose(linear(mi)), it.n));
+      break;
+    }
+    case SHAPE_SPHERE: {  // geometry.cpp:94-98
+      const f3 c = ld3(f);
+      it.n = normalize(p - c);
+      it.p = c + it.n * f[3];
+      // uv = cartesian_to_spherical(n): only shading nodes read it; device libm (not bit-exact)
+      float phi = atan2f(it.n.y, it.n.x);
+      phi = phi < 0.0f ? kPi * 2 + phi : phi;
+      it.uv = f2{phi, acosf(it.n.z)};
+      break;
+    }
+    case SHAPE_DISK: {  // geometry.cpp:149-155
+      const f3 position = ld3(f), u = ld3(f + 6), v = ld3(f + 9);
+      it.n = ld3(f + 3);
+      const float ex = dot(p - position, u);
+      const float ey = dot(p - position, v);
+      it.uv = f2{ex, ey};
+      it.p = position + ex * u + ey * v;
+      break;
+    }
+    case SHAPE_CONE: {  // geometry.cpp:455-460
+      const f3 apex = ld3(f), n = ld3(f + 3);
+      const float l = length(p - apex) * f[8];
+      const f3 x = apex - n * l;
+      it.n = normalize(p - x);
+      it.p = x + it.n * l * f[10];
+      break;
+    }
+    default: it.p = p; it.n = mk3(0.0f); break;
+  }
+}
+
+// Triangle tests on 9 floats v0,v1,v2 (geometry.cpp:532-565)
+PINE_HD bool tri_hit(const float* v, const DRay& ray) {
+  const f3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+  const f3 E1 = v1 - v0, E2 = v2 - v0, T = ray.o - v0;
+  const f3 P = cross(ray.d, E2), Q = cross(T, E1);
+  const float D = dot(P, E1);
+  if (D == 0.0f) return false;
+  const float t = dot(Q, E2) / D;
+  if (t < ray.tmin || t > ray.tmax) return false;
+  const float u = dot(P, T) / D;
+  if (u < 0.0f || u > 1.0f) return false;
+  const float w = dot(Q, ray.d) / D;
+  if (w < 0.0f || w > 1.0f) return false;
+  return u + w < 1.0f;
+}
+PINE_HD bool tri_intersect(const float* v, DRay& ray) {
+  const f3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+  const f3 E1 = v1 - v0, E2 = v2 - v0, T = ray.o - v0;
+  const f3 P = cross(ray.d, E2), Q = cross(T, E1);
+  const float D = dot(P, E1);
+  if (D == 0.0f) return false;
+  const float t = dot(Q, E2) / D;
+  if (t <= ray.tmin || t >= ray.tmax) return false;
+  const float u = dot(P, T) / D;
+  if (u < 0.0f || u > 1.0f) return false;
+  const float w = dot(Q, ray.d) / D;
+  if (w < 0.0f || w > 1.0f) return false;
+  if (u + w > 1.0f) return false;
+  ray.tmax = t;
+  return true;
+}
+// Mesh::compute_surface_info without normals/texcoords (geometry.cpp:632-646)
+PINE_HD void tri_surface_info(const float* v, f3 p, DSurface& it) {
+  const f3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+  const f3 e1 = v1 - v0, e2 = v2 - v0;
+  const f3 n = cross(e1, e2);
+  const m3 tbn = inverse(m3{e1, e2, n});
+  const f3 q = mul(tbn, p - v0);
+  it.uv = f2{q.x, q.y};
+  it.p = lerp3(q.x, q.y, v0, v1, v2);
+  it.n = normalize(n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Light sampling on shapes (Shape::sample geometry.h:331-340) and Shape::pdf
+// ------------------------------------------------------------------------------------------------
+struct DShapeSample {
+  f3 p, n, w;
+  float distance, pdf;
+};
+PINE_HD bool tri_sample(const float* v, f3 p, f2 u, DShapeSample& ss) {  // Triangle::sample :575-584
+  const f3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+  f3 n = normalize(cross(v0 - v1, v0 - v2));  // Triangle(v0,v1,v2) :528-531
+  if (is_zero(n)) n = mk3(0, 0, 1);
+  if (u.x + u.y > 1.0f) u = f2{1.0f, 1.0f} - u;
+  ss.p = lerp3(u.x, u.y, v0, v1, v2);
+  ss.n = n;
+  ss.w = normalize(ss.p - p, ss.distance);
+  const float area = length(cross(v1 - v0, v2 - v0)) / 2;
+  ss.pdf = sqr(ss.distance) / pmax(absdot(ss.w, ss.n) * area, kEpsilon);
+  return true;
+}
+PINE_HD bool shape_sample(const DShape* S, const float* tri_verts, f3 o, f2 u, float u1, DShapeSample& ss) {
+  const float* f = S->f;
+  switch (S->kind) {
+    case SHAPE_RECT: {  // geometry.cpp:308-316
+      ss.p = ld3(f) + (u.x - 0.5f) * ld3(f + 3) * f[12] + (u.y - 0.5f) * ld3(f + 6) * f[13];
+      ss.n = ld3(f + 9);
+      ss.w = normalize(ss.p - o, ss.distance);
+      ss.pdf = sqr(ss.distance) / (absdot(ss.w, ss.n) * f[20]);
+      break;
+    }
+    case SHAPE_SPHERE: {  // geometry.cpp:99-114
+      const f3 c = ld3(f);
+      const float r = f[3];
+      const float l = length(c - o);
+      const float cos_theta = psqrt(1 - sqr(r / l));
+      const float Sa = 2 * kPi * (1 - cos_theta);
+      const float cos_theta_wo = 1 - u.y * (1 - cos_theta);
+      const float sin_theta_wo = psqrt(1 - cos_theta_wo * cos_theta_wo);
+      const float phi = u.x * 2 * kPi;
+      f3 w = f3{sin_theta_wo * pcos(phi), sin_theta_wo * psin(phi), cos_theta_wo};
+      w = mul(coordinate_system((c - o) / l), w);
+      ss.w = w;
+      ss.distance = sphere_compute_t(o, w, 0.0f, c, r);
+      ss.pdf = 1.0f / Sa;
+      ss.p = o + w * ss.distance;
+      ss.n = (ss.p - c) / r;
+      break;
+    }
+    case SHAPE_DISK: {  // geometry.cpp:156-165
+      const f2 uv = sample_disk_concentric(u);
+      const float r = f[12];
+      ss.p = ld3(f) + r * ld3(f + 6) * uv.x + r * ld3(f + 9) * uv.y;
+      ss.n = ld3(f + 3);
+      ss.w = normalize(ss.p - o, ss.distance);
+      ss.pdf = sqr(ss.distance) / pmax(absdot(ss.w, ss.n) * f[13], kEpsilon);
+      break;
+    }
+    case SHAPE_MESH: {  // Mesh::sample geometry.h:170-178
+      const int first = as_int(f[0]), nt = as_int(f[1]);
+      if (nt == 0) return false;
+      const int ti = int(float(size_t(nt)) * u1);
+      tri_sample(tri_verts + size_t(first + ti) * 9, o, u, ss);
+      ss.pdf /= float(size_t(nt));
+      break;
+    }
+    default: return false;  // Cone::sample returns {} (geometry.cpp:461); boxes are not samplable
+  }
+  if (ss.pdf <= 0 || isinf(ss.pdf)) return false;
+  return true;
+}
+PINE_HD float shape_pdf(const DShape* S, const DRay& ray, f3 ns) {
+  const float* f = S->f;
+  switch (S->kind) {
+    case SHAPE_RECT: return sqr(ray.tmax) / f[20] * absdot(ns, ray.d);  // geometry.cpp:368-370 (quirk A4)
+    case SHAPE_SPHERE: {                                               // :115-120
+      const float l = length(ld3(f) - ray.o);
+      const float cos_theta = psqrt(1 - sqr(f[3] / l));
+      const float Sa = 2 * kPi * (1 - cos_theta);
+      return 1.0f / Sa;
+    }
+    case SHAPE_DISK: return sqr(ray.tmax) / (f[13] * absdot(ns, ray.d));  // :166-168
+    case SHAPE_CONE: return sqr(ray.tmax) / f[11] * absdot(ns, ray.d);   // :462-464
+    case SHAPE_MESH: return sqr(ray.tmax) / (f[3] * absdot(ns, ray.d));  // geometry.h:180-182
+    default: return 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BSDFs (src/pine/core/bxdf.cpp, scattering.h)
+// ------------------------------------------------------------------------------------------------
+PINE_HD float CosTheta(f3 w) { return w.z; }
+PINE_HD float Cos2Theta(f3 w) { return sqr(w.z); }
+PINE_HD float AbsCosTheta(f3 w) { return pabs(w.z); }
+PINE_HD float Sin2Theta(f3 w) { return 1.0f - Cos2Theta(w); }
+PINE_HD float SinTheta(f3 w) { return psqrt(Sin2Theta(w)); }
+PINE_HD float Tan2Theta(f3 w) { return Sin2Theta(w) / pmax(Cos2Theta(w), kEpsilon); }
+PINE_HD float CosPhi(f3 w) {
+  const float s = SinTheta(w);
+  return (s == 0) ? 1 : pclamp(w.x / s, -1.0f, 1.0f);
+}
+PINE_HD float SinPhi(f3 w) {
+  const float s = SinTheta(w);
+  return (s == 0) ? 1 : pclamp(w.y / s, -1.0f, 1.0f);
+}
+PINE_HD bool SameHemisphere(f3 a, f3 b) { return a.z * b.z > 0.0f; }
+PINE_HD f3 FaceNormal(f3 v) { return v.z < 0.0f ? -v : v; }
+PINE_HD f3 Reflect(f3 w) { return f3{-w.x, -w.y, w.z}; }
+PINE_HD f3 Reflect(f3 wi, f3 n) { return 2.0f * dot(wi, n) * n - wi; }
+PINE_HD bool Refract(f3 wi, f3 n, float eta, f3& wt, float* etap) {  // scattering.h:58-77
+  float cosThetaI = dot(n, wi);
+  if (cosThetaI < 0) {
+    eta = 1.0f / eta;
+    cosThetaI = -cosThetaI;
+    n = -n;
+  }
+  const float sin2ThetaI = pmax(0.0f, 1.0f - sqr(cosThetaI));
+  const float sin2ThetaT = sin2ThetaI / sqr(eta);
+  if (sin2ThetaT >= 1) return false;
+  const float cosThetaT = psqrt(1.0f - sin2ThetaT);
+  wt = -wi / eta + (cosThetaI / eta - cosThetaT) * n;
+  if (etap) *etap = eta;
+  return true;
+}
+PINE_HD float FrDielectric(float cosThetaI, float eta) {  // scattering.h:79-94
+  if (cosThetaI < 0) {
+    eta = 1 / eta;
+    cosThetaI = -cosThetaI;
+  }
+  const float sin2ThetaI = 1.0f - sqr(cosThetaI);
+  const float sin2ThetaT = sin2ThetaI / sqr(eta);
+  if (sin2ThetaT >= 1.0f) return 1.0f;
+  const float cosThetaT = psqrt(1.0f - sin2ThetaT);
+  const float rParl = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+  const float rPerp = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+  return (sqr(rParl) + sqr(rPerp)) / 2.0f;
+}
+PINE_HD f3 FrSchlick(f3 F0, float cosTheta) {  // scattering.h:96-98 (powf: device libm, tolerance)
+  return F0 + (mk3(1.0f) - F0) * powf(1.0f - cosTheta, 5.0f);
+}
+struct TRDist {  // TrowbridgeReitzDistribution scattering.h:100-150
+  float ax, ay;
+};
+PINE_HD float tr_D(const TRDist& t, f3 wm) {
+  const float tan2Theta = Tan2Theta(wm);
+  const float cos4Theta = sqr(Cos2Theta(wm));
+  if (cos4Theta < 1e-6f) return 0.0f;
+  const float e = tan2Theta * (sqr(CosPhi(wm) / t.ax) + sqr(SinPhi(wm) / t.ay));
+  return 1.0f / (kPi * t.ax * t.ay * cos4Theta * sqr(1 + e));
+}
+PINE_HD float tr_Lambda(const TRDist& t, f3 w) {
+  const float tan2Theta = Tan2Theta(w);
+  const float alpha2 = sqr(CosPhi(w) * t.ax) + sqr(SinPhi(w) * t.ay);
+  return (psqrt(1.0f + alpha2 * tan2Theta) - 1.0f) / 2.0f;
+}
+PINE_HD float tr_G1(const TRDist& t, f3 w) { return 1.0f / (1.0f + tr_Lambda(t, w)); }
+PINE_HD float tr_G(const TRDist& t, f3 wi, f3 wo) { return 1.0f / (1.0f + tr_Lambda(t, wi) + tr_Lambda(t, wo)); }
+PINE_HD float tr_D_G(const TRDist& t, f3 wi, f3 wm, f3 wo) { return tr_D(t, wm) * tr_G(t, wi, wo); }
+PINE_HD float tr_Dw(const TRDist& t, f3 w, f3 wm) { return tr_G1(t, w) / AbsCosTheta(w) * tr_D(t, wm) * absdot(w, wm); }
+PINE_HD float tr_pdf(const TRDist& t, f3 w, f3 wm) { return pmax(tr_Dw(t, w, wm), kEpsilon); }
+PINE_HD f3 tr_SampleWm(const TRDist& t, f3 w, f2 u) {
+  f3 wh = normalize(f3{t.ax * w.x, t.ay * w.y, w.z});
+  if (wh.z < 0.0f) wh = -wh;
+  const f3 T1 = (wh.z < 0.99999f) ? normalize(cross(mk3(0, 0, 1), wh)) : mk3(1, 0, 0);
+  const f3 T2 = cross(wh, T1);
+  f2 p = sample_disk_polar(u);
+  const float h = psqrt(1.0f - sqr(p.x));
+  const float tt = (1.0f + wh.z) / 2;
+  p.y = h * (1.0f - tt) + p.y * tt;  // psl::lerp(t, a, b) = a*(1-t) + b*t (src/psl/math.h:118-121)
+  const float pz = psqrt(pmax(0.0f, 1.0f - (p.x * p.x + p.y * p.y)));
+  const f3 nh = p.x * T1 + p.y * T2 + pz * wh;
+  return normalize(f3{t.ax * nh.x, t.ay * nh.y, pmax(1e-6f, nh.z)});
+}
+
+enum BxdfKind : int { BX_DIFFUSE, BX_CONDUCTOR, BX_REFRACTIVE, BX_REFR_DIEL, BX_DIFF_DIEL, BX_BSSRDF };
+struct DBxdf {
+  int kind;
+  f3 albedo;
+  float roughness, ior;
+  f3 wi;  // local frame
+};
+PINE_HD bool bxdf_is_delta(const DBxdf& b) {
+  switch (b.kind) {
+    case BX_DIFFUSE:
+    case BX_DIFF_DIEL:
+    case BX_BSSRDF: return false;
+    default: return b.roughness < 1e-2f;
+  }
+}
+struct DBsdfSample {
+  f3 wo, f;
+  float pdf;
+  bool is_delta;
+};
+PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DBsdfSample& bs) {
+  const f3 wi = b.wi;
+  bs.is_delta = false;
+  switch (b.kind) {
+    case BX_DIFFUSE: {  // bxdf.cpp:11-23
+      f3 wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
+      if (CosTheta(wi) < 0) wo = -wo;
+      bs.wo = wo;
+      bs.pdf = AbsCosTheta(wo) / kPi;
+      bs.f = b.albedo / kPi;
+      return true;
+    }
+    case BX_CONDUCTOR: {  // bxdf.cpp:39-64
+      const float alpha = sqr(b.roughness);
+      if (alpha < 1e-4f) {
+        bs.wo = Reflect(wi);
+        bs.f = FrSchlick(b.albedo, AbsCosTheta(bs.wo)) / AbsCosTheta(bs.wo);
+        bs.pdf = 1.0f;
+        bs.is_delta = true;
+        return true;
+      }
+      const TRDist d{alpha, alpha};
+      const f3 wm = tr_SampleWm(d, wi, sampler_get2d(T, sampler));
+      const f3 wo = Reflect(wi, wm);
+      if (!SameHemisphere(wi, wo)) return false;
+      const f3 fr = FrSchlick(b.albedo, absdot(wi, wm));
+      bs.wo = wo;
+      bs.pdf = tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
+      bs.f = fr * (tr_D_G(d, wo, wm, wi) / (4 * CosTheta(wi) * CosTheta(wo)));
+      return true;
+    }
+    case BX_REFRACTIVE: {  // bxdf.cpp:102-124
+      const float alpha = sqr(b.roughness);
+      if (alpha < 1e-4f) {
+        bs.wo = Reflect(wi);
+        bs.f = b.albedo;
+        bs.pdf = AbsCosTheta(bs.wo);
+        bs.is_delta = true;
+        return true;
+      }
+      const TRDist d{alpha, alpha};
+      const f3 wm = tr_SampleWm(d, wi, sampler_get2d(T, sampler));
+      const f3 wo = Reflect(wi, wm);
+      if (!SameHemisphere(wi, wo)) return false;
+      bs.wo = wo;
+      bs.pdf = tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
+      bs.f = b.albedo * (tr_D_G(d, wo, wm, wi) / (4 * CosTheta(wi) * CosTheta(wo)));
+      return true;
+    }
+    case BX_REFR_DIEL: {  // bxdf.cpp:162-208
+      const float fr = FrDielectric(CosTheta(wi), b.ior);
+      const float alpha = sqr(b.roughness);
+      if (alpha < 1e-4f) {
+        if (sampler_get1d(T, sampler) < fr) {
+          bs.wo = Reflect(wi);
+          bs.f = b.albedo * (fr / AbsCosTheta(bs.wo));
+          bs.pdf = fr;
+          bs.is_delta = true;
+        } else {
+          if (!Refract(wi, mk3(0, 0, 1), b.ior, bs.wo, nullptr)) return false;
+          bs.f = b.albedo * ((1 - fr) / AbsCosTheta(bs.wo));
+          bs.pdf = 1 - fr;
+          bs.is_delta = true;
+        }
+        return true;
+      }
+      const TRDist d{alpha, alpha};
+      const f3 wm = tr_SampleWm(d, wi, sampler_get2d(T, sampler));
+      if (sampler_get1d(T, sampler) < fr) {
+        const f3 wo = Reflect(wi, wm);
+        if (!SameHemisphere(wi, wo)) return false;
+        bs.wo = wo;
+        bs.pdf = fr * tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
+        bs.f = b.albedo * (fr * tr_D_G(d, wo, wm, wi) / (4 * CosTheta(wi) * CosTheta(wo)));
+      } else {
+        float eta = 1.0f;
+        if (!Refract(wi, wm, b.ior, bs.wo, &eta)) return false;
+        const f3 wo = bs.wo;
+        const float denom = sqr(dot(wo, wm) + dot(wi, wm) / eta);
+        bs.pdf = (1 - fr) * tr_pdf(d, wi, wm) * absdot(wo, wm) / denom;
+        bs.f = b.albedo * ((1 - fr) * tr_D(d, wm) * tr_G(d, wi, wo) *
+                           pabs(dot(wo, wm) * dot(wi, wm) / (denom * CosTheta(wi) * CosTheta(wo))));
+      }
+      return true;
+    }
+    case BX_DIFF_DIEL: {  // bxdf.cpp:250-287 (diffuse lobe is NOT flipped to wi's side, Appendix A5)
+      const float fr = FrDielectric(CosTheta(wi), b.ior);
+      const float alpha = sqr(b.roughness);
+      if (alpha < 1e-4f) {
+        if (sampler_get1d(T, sampler) < fr) {
+          bs.wo = Reflect(wi);
+          bs.f = mk3(fr);
+          bs.pdf = fr * AbsCosTheta(bs.wo);
+          bs.is_delta = true;
+        } else {
+          bs.wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
+          bs.f = b.albedo * ((1 - fr) / kPi);
+          bs.pdf = (1 - fr) * AbsCosTheta(bs.wo) / kPi;
+        }
+        return true;
+      }
+      const TRDist d{alpha, alpha};
+      const f3 wm = tr_SampleWm(d, wi, sampler_get2d(T, sampler));
+      if (sampler_get1d(T, sampler) < fr) {
+        const f3 wo = Reflect(wi, wm);
+        if (!SameHemisphere(wi, wo)) return false;
+        bs.wo = wo;
+        bs.f = mk3(fr * tr_D_G(d, wi, wm, wo) / (4 * CosTheta(wi) * CosTheta(wo)));
+        bs.pdf = fr * tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
+      } else {
+        bs.wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
+        bs.f = b.albedo * ((1 - fr) / kPi);
+        bs.pdf = AbsCosTheta(bs.wo) * (1 - fr) / kPi;
+      }
+      return true;
+    }
+    case BX_BSSRDF: {  // bxdf.cpp:356-367
+      f3 wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
+      if (CosTheta(wi) > 0) wo = -wo;
+      bs.wo = wo;
+      bs.pdf = AbsCosTheta(wo) / kPi;
+      bs.f = b.albedo / kPi;
+      return true;
+    }
+  }
+  return false;
+}
+PINE_HD f3 bxdf_f(const DBxdf& b, f3 wo) {
+  const f3 wi = b.wi;
+  switch (b.kind) {
+    case BX_DIFFUSE:  // bxdf.cpp:24-28
+      if (!SameHemisphere(wi, wo)) return mk3(0.0f);
+      return b.albedo / kPi;
+    case BX_CONDUCTOR: {  // bxdf.cpp:65-79
+      if (!SameHemisphere(wi, wo)) return mk3(0.0f);
+      const float alpha = sqr(b.roughness);
+      const TRDist d{alpha, alpha};
+      const f3 wm = normalize(wi + wo);
+      if (is_zero(wm)) return mk3(0.0f);
+      const f3 fr = FrSchlick(b.albedo, absdot(wi, wm));
+      return fr * (tr_D_G(d, wo, wm, wi) / (4 * AbsCosTheta(wo) * AbsCosTheta(wi)));
+    }
+    case BX_REFRACTIVE: {  // bxdf.cpp:125-140
+      const float alpha = sqr(b.roughness);
+      const TRDist d{alpha, alpha};
+      const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      if (!(cosThetaI * cosThetaO > 0)) return mk3(0.0f);
+      const f3 wm = FaceNormal(normalize(wo + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return mk3(0.0f);
+      return b.albedo * (tr_D_G(d, wi, wm, wo) / pabs(4 * cosThetaI * cosThetaO));
+    }
+    case BX_REFR_DIEL: {  // bxdf.cpp:209-230 (`auto eta = 1` is an int in the reference)
+      const float alpha = sqr(b.roughness);
+      const TRDist d{alpha, alpha};
+      const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      const bool reflect = cosThetaI * cosThetaO > 0;
+      int eta = 1;
+      if (!reflect) eta = int(cosThetaI > 0 ? b.ior : 1 / b.ior);
+      const f3 wm = FaceNormal(normalize(wo * float(eta) + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return mk3(0.0f);
+      const float fr = FrDielectric(dot(wi, wm), b.ior);
+      if (reflect) return b.albedo * (fr * tr_D_G(d, wi, wm, wo) / pabs(4 * cosThetaI * cosThetaO));
+      const float denom = sqr(dot(wo, wm) + dot(wi, wm) / float(eta)) * cosThetaI * cosThetaO;
+      return b.albedo * ((1 - fr) * tr_D(d, wm) * tr_G(d, wi, wo) * pabs(dot(wo, wm) * dot(wi, wm) / denom));
+    }
+    case BX_DIFF_DIEL: {  // bxdf.cpp:288-306
+      if (!SameHemisphere(wi, wo)) return mk3(0.0f);
+      const float alpha = sqr(b.roughness);
+      const TRDist d{alpha, alpha};
+      const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      const f3 wm = FaceNormal(normalize(wo + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return mk3(0.0f);
+      const float fr = FrDielectric(dot(wi, wm), b.ior);
+      const f3 diffused = b.albedo * (1 - fr) / kPi;
+      if (alpha < 1e-4f) return diffused;
+      const float reflected = fr * tr_D_G(d, wo, wm, wi) / pabs(4 * cosThetaI * cosThetaO);
+      return mk3(reflected) + diffused;
+    }
+    case BX_BSSRDF: return b.albedo / kPi;  // bxdf.cpp:368-370
+  }
+  return mk3(0.0f);
+}
+PINE_HD float bxdf_pdf(const DBxdf& b, f3 wo) {
+  const f3 wi = b.wi;
+  switch (b.kind) {
+    case BX_DIFFUSE:  // bxdf.cpp:29-33
+      if (!SameHemisphere(wi, wo)) return 0.0f;
+      return AbsCosTheta(wo) / kPi;
+    case BX_CONDUCTOR: {  // bxdf.cpp:80-95
+      if (!SameHemisphere(wi, wo)) return 0.0f;
+      const float alpha = sqr(b.roughness);
+      const TRDist d{alpha, alpha};
+      f3 wm = normalize(wi + wo);
+      if (is_zero(wm)) return 0.0f;
+      wm = FaceNormal(wm);
+      return tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
+    }
+    case BX_REFRACTIVE: {  // bxdf.cpp:141-157
+      const float alpha = sqr(b.roughness);
+      const TRDist d{alpha, alpha};
+      const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      if (!(cosThetaI * cosThetaO > 0)) return 0.0f;
+      const f3 wm = FaceNormal(normalize(wo + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return 0.0f;
+      return tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
+    }
+    case BX_REFR_DIEL: {  // bxdf.cpp:231-245
+      const float alpha = sqr(b.roughness);
+      const TRDist d{alpha, alpha};
+      const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      const bool reflect = cosThetaI * cosThetaO > 0;
+      int eta = 1;
+      if (!reflect) eta = int(cosThetaI > 0 ? b.ior : 1 / b.ior);
+      const f3 wm = FaceNormal(normalize(wo * float(eta) + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return 0.0f;
+      const float fr = FrDielectric(dot(wi, wm), b.ior);
+      if (reflect) return fr * tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
+      const float denom = sqr(dot(wo, wm) + dot(wi, wm) / float(eta));
+      const float dwm_dwo = absdot(wo, wm) / denom;
+      return (1 - fr) * tr_pdf(d, wi, wm) * dwm_dwo;
+    }
+    case BX_DIFF_DIEL: {  // bxdf.cpp:307-324
+      if (!SameHemisphere(wi, wo)) return 0.0f;
+      const float alpha = sqr(b.roughness);
+      const TRDist d{alpha, alpha};
+      const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+      const f3 wm = FaceNormal(normalize(wo + wi));
+      if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return 0.0f;
+      const float fr = FrDielectric(dot(wi, wm), b.ior);
+      const float pt = (1 - fr) * AbsCosTheta(wo) / kPi;
+      if (alpha < 1e-4f) return pt;
+      const float pr = fr * tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
+      return pr + pt;
+    }
+    case BX_BSSRDF: return AbsCosTheta(wo) / kPi;  // bxdf.cpp:371-373
+  }
+  return 0.0f;
+}
+
+// ThinLenCamera::gen_ray (src/pine/core/camera.cpp:17-33)
+PINE_HD DRay camera_gen_ray(const DCamera& c, f2 p_film, f2 u2) {
+  p_film = (p_film - f2{0.5f, 0.5f}) * 2.0f;
+  const f2 pc = p_film * f2{c.fov2d[0], c.fov2d[1]};
+  const m3 c2w{ld3(c.c2w), ld3(c.c2w + 3), ld3(c.c2w + 6)};
+  DRay r;
+  r.tmin = 0.0f;
+  r.tmax = kFloatMax;
+  if (c.len_radius == 0.0f) {
+    r.o = ld3(c.position);
+    r.d = normalize(mul(c2w, f3{pc.x, pc.y, 1.0f}));
+  } else {
+    const f3 dir = normalize(f3{pc.x, pc.y, 1.0f});
+    const f3 p_focus = c.focus_distance * dir / dir.z;
+    const f2 d = c.len_radius * sample_disk_polar(u2);
+    const f3 p_len{d.x, d.y, 0.0f};
+    r.o = ld3(c.position) + p_len;
+    r.d = mul(c2w, normalize(p_focus - p_len));
+  }
+  return r;
+}
+
+}  // namespace pine_gpu

@@ -1,0 +1,747 @@
+// pine_amd/csrc/pine_host.cpp -- host side of the C ABI: scene container, shape constructors,
+// host matrix math, pine's BVH build flattened for the GPU, film finalize.  No GPU calls here.
+#include "pine_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/pine_gpu.h"
+
+namespace pine_gpu {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+static std::string fmt(const char* f, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof buf, f, ap);
+  va_end(ap);
+  return buf;
+}
+static std::string hex3(const float* v) { return fmt("%a %a %a", v[0], v[1], v[2]); }
+static std::string hex3(f3 v) { return fmt("%a %a %a", v.x, v.y, v.z); }
+
+// ------------------------------------------------------------------------------------------------
+// Mat4 (src/pine/core/vecmath.h:575-640,1102-1180; src/pine/core/vecmath.cpp:103-132)
+// ------------------------------------------------------------------------------------------------
+Mat4 Mat4::identity() {
+  Mat4 r{};
+  for (int i = 0; i < 4; i++) r.m[i][i] = 1.0f;
+  return r;
+}
+Mat4 Mat4::from_rows(const float a[16]) {  // scalar ctor takes row-major args (vecmath.h:579-581)
+  Mat4 r{};
+  for (int row = 0; row < 4; row++)
+    for (int col = 0; col < 4; col++) r.m[col][row] = a[row * 4 + col];
+  return r;
+}
+Mat4 Mat4::from_storage(const float s[16]) {
+  Mat4 r{};
+  for (int c = 0; c < 4; c++)
+    for (int rr = 0; rr < 4; rr++) r.m[c][rr] = s[c * 4 + rr];
+  return r;
+}
+void Mat4::to_storage(float s[16]) const {
+  for (int c = 0; c < 4; c++)
+    for (int rr = 0; rr < 4; rr++) s[c * 4 + rr] = m[c][rr];
+}
+Mat4 mat4_mul(const Mat4& l, const Mat4& r) {  // vecmath.h:617-624: accumulate from zero, i = 0..3
+  Mat4 ret{};
+  for (int c = 0; c < 4; c++)
+    for (int rr = 0; rr < 4; rr++) {
+      float acc = 0.0f;
+      for (int i = 0; i < 4; i++) acc += l.m[i][rr] * r.m[c][i];
+      ret.m[c][rr] = acc;
+    }
+  return ret;
+}
+Mat4 mat4_inverse(const Mat4& M) {  // cofactor expansion with the reference's index pattern
+  const auto& m = M.m;
+  Mat4 R = Mat4::identity();
+  float det = 0;
+  for (int i = 0; i < 4; i++)
+    det += (m[(1 + i) % 4][0] *
+                (m[(2 + i) % 4][1] * m[(3 + i) % 4][2] - m[(3 + i) % 4][1] * m[(2 + i) % 4][2]) +
+            m[(2 + i) % 4][0] *
+                (m[(3 + i) % 4][1] * m[(1 + i) % 4][2] - m[(1 + i) % 4][1] * m[(3 + i) % 4][2]) +
+            m[(3 + i) % 4][0] *
+                (m[(1 + i) % 4][1] * m[(2 + i) % 4][2] - m[(2 + i) % 4][1] * m[(1 + i) % 4][2])) *
+           m[i % 4][3] * (i % 2 ? -1 : 1);
+  if (det == 0) return R;
+  for (int v = 0; v < 4; v++)
+    for (int i = 0; i < 4; i++)
+      R.m[v][i] = (m[(1 + i) % 4][(1 + v) % 4] *
+                       (m[(2 + i) % 4][(2 + v) % 4] * m[(3 + i) % 4][(3 + v) % 4] -
+                        m[(3 + i) % 4][(2 + v) % 4] * m[(2 + i) % 4][(3 + v) % 4]) +
+                   m[(2 + i) % 4][(1 + v) % 4] *
+                       (m[(3 + i) % 4][(2 + v) % 4] * m[(1 + i) % 4][(3 + v) % 4] -
+                        m[(1 + i) % 4][(2 + v) % 4] * m[(3 + i) % 4][(3 + v) % 4]) +
+                   m[(3 + i) % 4][(1 + v) % 4] *
+                       (m[(1 + i) % 4][(2 + v) % 4] * m[(2 + i) % 4][(3 + v) % 4] -
+                        m[(2 + i) % 4][(2 + v) % 4] * m[(1 + i) % 4][(3 + v) % 4])) *
+                  ((v + i) % 2 ? 1 : -1);
+  for (int c = 0; c < 4; c++)
+    for (int rr = 0; rr < 4; rr++) R.m[c][rr] /= det;
+  return R;
+}
+Mat4 mat4_translate(f3 v) {
+  const float a[16] = {1, 0, 0, v.x, 0, 1, 0, v.y, 0, 0, 1, v.z, 0, 0, 0, 1};
+  return Mat4::from_rows(a);
+}
+Mat4 mat4_scale(f3 v) {
+  const float a[16] = {v.x, 0, 0, 0, 0, v.y, 0, 0, 0, 0, v.z, 0, 0, 0, 0, 1};
+  return Mat4::from_rows(a);
+}
+// The host trig goes through the system libm exactly as the reference's does (psl::cos -> std::cos).
+Mat4 mat4_rotate_x(float r) {
+  const float a[16] = {1, 0, 0, 0, 0, std::cos(r), -std::sin(r), 0, 0, std::sin(r), std::cos(r), 0, 0, 0, 0, 1};
+  return Mat4::from_rows(a);
+}
+Mat4 mat4_rotate_y(float r) {
+  const float a[16] = {std::cos(r), 0, std::sin(r), 0, 0, 1, 0, 0, -std::sin(r), 0, std::cos(r), 0, 0, 0, 0, 1};
+  return Mat4::from_rows(a);
+}
+Mat4 mat4_rotate_z(float r) {
+  const float a[16] = {std::cos(r), -std::sin(r), 0, 0, std::sin(r), std::cos(r), 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  return Mat4::from_rows(a);
+}
+Mat4 mat4_look_at(f3 from, f3 at) {  // vecmath.h:1172-1180, up = (0,1,0)
+  f3 up = mk3(0, 1, 0);
+  f3 z = normalize(at - from);
+  if (std::abs(dot(z, up)) > 0.999f) z = normalize(z + mk3(0.0f, 0.0f, 1e-5f));
+  f3 x = normalize(cross(up, z));
+  f3 y = cross(z, x);
+  Mat4 r{};
+  const f3 cols[3] = {x, y, z};
+  for (int c = 0; c < 3; c++) {
+    r.m[c][0] = cols[c].x;
+    r.m[c][1] = cols[c].y;
+    r.m[c][2] = cols[c].z;
+    r.m[c][3] = 0.0f;
+  }
+  r.m[3][0] = from.x;
+  r.m[3][1] = from.y;
+  r.m[3][2] = from.z;
+  r.m[3][3] = 1.0f;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scene
+// ------------------------------------------------------------------------------------------------
+int SceneHost::find_material(const char* name) const {
+  for (int i = int(material_names.size()) - 1; i >= 0; i--)
+    if (material_names[i] == name) return i;
+  return -1;
+}
+int SceneHost::add_material(const char* name, const DMaterial& m, const std::string& desc) {
+  materials.push_back(m);
+  material_names.push_back(name ? name : "");
+  material_describe.push_back(desc);
+  accel.built = false;
+  return int(materials.size()) - 1;
+}
+int SceneHost::add_geometry(HostGeometry g) {
+  if (g.shape.material < 0 || g.shape.material >= int(materials.size())) {
+    set_error("scene.add: invalid material id");
+    return -1;
+  }
+  geometries.push_back(std::move(g));
+  int id = int(geometries.size()) - 1;
+  // Scene::add_geometry (scene.cpp:19-20): emissive geometry becomes an AreaLight
+  if (materials[geometries[id].shape.material].kind == MAT_EMISSIVE) lights.push_back(id);
+  accel.built = false;
+  return id;
+}
+
+static HostAABB sphere_aabb(f3 c, float r) {
+  HostAABB b;
+  b.lower = c - mk3(r);
+  b.upper = c + mk3(r);
+  return b;
+}
+
+HostAABB SceneHost::geometry_aabb(int gi) const {
+  const DShape& s = geometries[gi].shape;
+  const float* f = s.f;
+  HostAABB b;
+  switch (s.kind) {
+    case SHAPE_RECT: {  // Rect::get_aabb geometry.cpp:401-408
+      f3 position = ld3(f), ex = ld3(f + 3), ey = ld3(f + 6);
+      float lx = f[12], ly = f[13];
+      b.extend(position - ex * lx / 2.0f - ey * ly / 2.0f);
+      b.extend(position - ex * lx / 2.0f + ey * ly / 2.0f);
+      b.extend(position + ex * lx / 2.0f - ey * ly / 2.0f);
+      b.extend(position + ex * lx / 2.0f + ey * ly / 2.0f);
+      break;
+    }
+    case SHAPE_AABB:  // bbox.h:77: padded by epsilon
+      b.lower = ld3(f) - mk3(kEpsilon);
+      b.upper = ld3(f + 3) + mk3(kEpsilon);
+      break;
+    case SHAPE_OBB: {  // AABB(OBB) bbox.cpp:8-16, no pad (bbox.h:93)
+      f3 lo = ld3(f), hi = ld3(f + 3);
+      m34 m = ld34(f + 6);
+      for (int i = 0; i < 8; i++) {
+        f3 p = lo;
+        if (i % 2 >= 1) p.x = hi.x;
+        if (i % 4 >= 2) p.y = hi.y;
+        if (i % 8 >= 4) p.z = hi.z;
+        b.extend(mul_point(m, p));
+      }
+      break;
+    }
+    case SHAPE_SPHERE: b = sphere_aabb(ld3(f), f[3]); break;
+    case SHAPE_DISK: b = sphere_aabb(ld3(f), f[12]); break;  // Disk::get_aabb geometry.cpp:169
+    case SHAPE_CONE: {  // geometry.h:129: bottom.get_aabb().extend(apex); bottom centre = p - n_*h
+      // the bottom disk centre is kept in f[12..14]
+      b = sphere_aabb(ld3(f + 12), f[6]);
+      b.extend(ld3(f));
+      break;
+    }
+    case SHAPE_MESH: {
+      const HostMesh& m = meshes[geometries[gi].mesh];
+      for (size_t i = 0; i < m.vertices.size() / 3; i++) b.extend(ld3(&m.vertices[3 * i]));
+      break;
+    }
+  }
+  return b;
+}
+
+// ---- pine's BVH build (bvh.cpp:43-147), emitting the flattened layout directly ---------------
+namespace {
+struct Prim {
+  HostAABB aabb;
+  int index;
+};
+struct ChildRef {
+  bool leaf;
+  int a;  // inner: node index; leaf: prim start
+  int n;  // leaf: count
+};
+struct Builder {
+  std::vector<DNode>& nodes;
+  std::vector<int>& prims;
+  ChildRef build(Prim* begin, Prim* end, const HostAABB& aabb) {
+    int n = int(end - begin);
+    auto make_leaf = [&]() {
+      ChildRef r{true, int(prims.size()), n};
+      for (int i = 0; i < n; i++) prims.push_back(begin[i].index);
+      return r;
+    };
+    if (n == 1) return make_leaf();
+    HostAABB cb;
+    for (int i = 0; i < n; i++) cb.extend(begin[i].aabb.centroid());
+    float surfaceArea = aabb.surface_area();
+    const int nBuckets = 16;
+    float minCost = kFloatMax;
+    int bestAxis = -1, splitBucket = -1;
+    for (int axis = 0; axis < 3; axis++) {
+      if (cb.degenerated(axis)) continue;
+      struct Bucket {
+        int count = 0;
+        HostAABB aabb;
+      } buckets[nBuckets];
+      for (int i = 0; i < n; i++) {
+        int b = std::min(int(nBuckets * cb.relative_position(begin[i].aabb.centroid(axis), axis)),
+                         nBuckets - 1);
+        buckets[b].count++;
+        buckets[b].aabb.extend(begin[i].aabb);
+      }
+      float cost[nBuckets - 1] = {};
+      HostAABB bF;
+      int cF = 0;
+      for (int i = 0; i < nBuckets - 1; i++) {
+        bF.extend(buckets[i].aabb);
+        cF += buckets[i].count;
+        cost[i] += cF * bF.surface_area();
+      }
+      HostAABB bB;
+      int cB = 0;
+      for (int i = nBuckets - 1; i >= 1; i--) {
+        bB.extend(buckets[i].aabb);
+        cB += buckets[i].count;
+        cost[i - 1] += cB * bB.surface_area();
+      }
+      for (int i = 0; i < nBuckets - 1; i++) cost[i] = 1.0f + cost[i] / surfaceArea;
+      float axisMin = kFloatMax;
+      int axisSplit = -1;
+      for (int i = 0; i < nBuckets - 1; i++)
+        if (cost[i] < axisMin) {
+          axisMin = cost[i];
+          axisSplit = i;
+        }
+      if (axisMin < minCost) {
+        minCost = axisMin;
+        bestAxis = axis;
+        splitBucket = axisSplit;
+      }
+    }
+    if (minCost > float(n)) return make_leaf();
+    // Lomuto partition (src/psl/algorithm.h:394-402): primitive order after the split matters,
+    // because leaf primitives are tested in stored order.
+    Prim* tail = begin;
+    for (Prim* i = begin; i != end; ++i) {
+      int b = int(nBuckets * cb.relative_position(i->aabb.centroid(bestAxis), bestAxis));
+      if (b == nBuckets) b = nBuckets - 1;
+      if (b <= splitBucket) std::swap(*tail++, *i);
+    }
+    Prim* pmid = tail;
+    HostAABB a0, a1;
+    for (Prim* p = begin; p != pmid; p++) a0.extend(p->aabb);
+    for (Prim* p = pmid; p != end; p++) a1.extend(p->aabb);
+    ChildRef c0 = build(begin, pmid, a0);
+    ChildRef c1 = build(pmid, end, a1);
+    DNode nd{};
+    nd.lo0[0] = a0.lower.x, nd.lo0[1] = a0.lower.y, nd.lo0[2] = a0.lower.z;
+    nd.hi0[0] = a0.upper.x, nd.hi0[1] = a0.upper.y, nd.hi0[2] = a0.upper.z;
+    nd.lo1[0] = a1.lower.x, nd.lo1[1] = a1.lower.y, nd.lo1[2] = a1.lower.z;
+    nd.hi1[0] = a1.upper.x, nd.hi1[1] = a1.upper.y, nd.hi1[2] = a1.upper.z;
+    nd.child[0] = c0.a;
+    nd.count[0] = c0.leaf ? c0.n : 0;
+    nd.child[1] = c1.a;
+    nd.count[1] = c1.leaf ? c1.n : 0;
+    nodes.push_back(nd);
+    return ChildRef{false, int(nodes.size()) - 1, 0};
+  }
+};
+DBvh build_one(std::vector<Prim> prims, std::vector<DNode>& nodes, std::vector<int>& plist,
+               int prim_base, HostAABB* bounds_out) {
+  HostAABB aabb;
+  for (auto& p : prims) aabb.extend(p.aabb);
+  Builder b{nodes, plist};
+  ChildRef r = b.build(prims.data(), prims.data() + prims.size(), aabb);
+  DBvh out{};
+  out.prim_base = prim_base;
+  if (r.leaf) {
+    out.root = -1;
+    out.root_start = r.a;
+    out.root_count = r.n;
+  } else {
+    out.root = r.a;
+    out.root_start = 0;
+    out.root_count = 0;
+  }
+  // BVHImpl::get_aabb (bvh.h:50-52): union of the root's two child boxes (== bounds of all prims)
+  if (bounds_out) *bounds_out = aabb;
+  return out;
+}
+}  // namespace
+
+void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
+  accel = FlatAccel();
+  accel.bvhs.push_back(DBvh{-1, 0, 0, 0});  // slot 0 = top level, filled below
+  std::vector<Prim> top;
+  std::vector<int> top_geom;  // `indices` of the reference: top-level primitive -> geometry
+  // 1. one BVH per non-empty mesh, in geometry order
+  for (size_t gi = 0; gi < geometries.size(); gi++) {
+    if (geometries[gi].shape.kind != SHAPE_MESH) continue;
+    const HostMesh& m = meshes[geometries[gi].mesh];
+    size_t nt = m.indices.size() / 3;
+    if (nt == 0) continue;
+    int first_tri = int(accel.tri_verts.size() / 9);
+    std::vector<Prim> prims;
+    for (size_t t = 0; t < nt; t++) {
+      Prim p;
+      for (int k = 0; k < 3; k++) {
+        const float* v = &m.vertices[3 * m.indices[3 * t + k]];
+        p.aabb.extend(ld3(v));
+        accel.tri_verts.insert(accel.tri_verts.end(), v, v + 3);
+      }
+      p.index = int(t);
+      prims.push_back(p);
+    }
+    HostAABB bounds;
+    DBvh b = build_one(std::move(prims), accel.nodes, accel.prims, first_tri, &bounds);
+    accel.bvhs.push_back(b);
+    int bvh_id = int(accel.bvhs.size()) - 1;
+    int32_t tmp;
+    tmp = first_tri;
+    memcpy(&geometries[gi].shape.f[0], &tmp, 4);
+    tmp = int(nt);
+    memcpy(&geometries[gi].shape.f[1], &tmp, 4);
+    tmp = bvh_id;
+    memcpy(&geometries[gi].shape.f[2], &tmp, 4);
+    Prim tp;
+    tp.aabb = bounds;
+    tp.index = int(gi);
+    top.push_back(tp);
+  }
+  // 2. then every non-mesh geometry, in geometry order
+  for (size_t gi = 0; gi < geometries.size(); gi++) {
+    if (geometries[gi].shape.kind == SHAPE_MESH) continue;
+    Prim tp;
+    tp.aabb = geometry_aabb(int(gi));
+    tp.index = int(gi);
+    top.push_back(tp);
+  }
+  if (!top.empty()) accel.bvhs[0] = build_one(std::move(top), accel.nodes, accel.prims, 0, nullptr);
+  accel.built = true;
+}
+
+std::string SceneHost::describe() const {
+  std::string s = "# pine scene description v1 (hexfloat); written by libpine_gpu\n";
+  // materials and geometry interleaved in creation order is not needed: materials first
+  for (auto& d : material_describe) s += d + "\n";
+  for (auto& g : geometries) s += g.describe + "\n";
+  if (has_camera) s += camera_describe + "\n";
+  return s;
+}
+
+}  // namespace pine_gpu
+
+// ================================================================================================
+// C ABI (host part)
+// ================================================================================================
+using namespace pine_gpu;
+
+struct pine_gpu_scene {
+  SceneHost host;
+};
+
+extern "C" {
+
+const char* pine_gpu_last_error(void) { return g_last_error.c_str(); }
+int pine_gpu_abi_version(void) { return PINE_GPU_ABI_VERSION; }
+
+void pine_gpu_mat4_identity(float out[16]) { Mat4::identity().to_storage(out); }
+void pine_gpu_mat4_translate(const float v[3], float out[16]) { mat4_translate(ld3(v)).to_storage(out); }
+void pine_gpu_mat4_scale(const float v[3], float out[16]) { mat4_scale(ld3(v)).to_storage(out); }
+void pine_gpu_mat4_rotate_x(float rad, float out[16]) { mat4_rotate_x(rad).to_storage(out); }
+void pine_gpu_mat4_rotate_y(float rad, float out[16]) { mat4_rotate_y(rad).to_storage(out); }
+void pine_gpu_mat4_rotate_z(float rad, float out[16]) { mat4_rotate_z(rad).to_storage(out); }
+void pine_gpu_mat4_mul(const float a[16], const float b[16], float out[16]) {
+  mat4_mul(Mat4::from_storage(a), Mat4::from_storage(b)).to_storage(out);
+}
+void pine_gpu_mat4_inverse(const float m[16], float out[16]) {
+  mat4_inverse(Mat4::from_storage(m)).to_storage(out);
+}
+void pine_gpu_mat4_look_at(const float from[3], const float at[3], float out[16]) {
+  mat4_look_at(ld3(from), ld3(at)).to_storage(out);
+}
+
+pine_gpu_scene* pine_gpu_scene_create(void) { return new pine_gpu_scene(); }
+void pine_gpu_scene_destroy(pine_gpu_scene* s) { delete s; }
+
+static bool check(pine_gpu_scene* s, const void* p = (const void*)1) {
+  if (!s || !p) {
+    set_error("null argument");
+    return false;
+  }
+  return true;
+}
+static std::string mat_name(pine_gpu_scene* s, const char* name) {
+  if (name && *name) return name;
+  return fmt("_anon%d", int(s->host.materials.size()));
+}
+
+int pine_gpu_scene_add_material_emissive(pine_gpu_scene* s, const char* name, const float c[3]) {
+  if (!check(s, c)) return -1;
+  DMaterial m{};
+  m.kind = MAT_EMISSIVE;
+  memcpy(m.color, c, 12);
+  std::string n = mat_name(s, name);
+  return s->host.add_material(n.c_str(), m, "material " + n + " emissive " + hex3(c));
+}
+int pine_gpu_scene_add_material_diffuse(pine_gpu_scene* s, const char* name, const float c[3]) {
+  if (!check(s, c)) return -1;
+  DMaterial m{};
+  m.kind = MAT_DIFFUSE;
+  memcpy(m.color, c, 12);
+  std::string n = mat_name(s, name);
+  return s->host.add_material(n.c_str(), m, "material " + n + " diffuse " + hex3(c));
+}
+int pine_gpu_scene_add_material_uber(pine_gpu_scene* s, const char* name, const float c[3],
+                                     float roughness, float metallic, float transmission, float ior) {
+  if (!check(s, c)) return -1;
+  DMaterial m{};
+  m.kind = MAT_UBER;
+  memcpy(m.color, c, 12);
+  m.roughness = roughness;
+  m.metallic = metallic;
+  m.transmission = transmission;
+  m.ior = ior;
+  std::string n = mat_name(s, name);
+  return s->host.add_material(n.c_str(), m,
+                              "material " + n + " uber " + hex3(c) +
+                                  fmt(" %a %a %a %a", roughness, metallic, transmission, ior));
+}
+int pine_gpu_scene_add_material_subsurface(pine_gpu_scene* s, const char* name, const float c[3],
+                                           float roughness, const float sigma_s[3]) {
+  if (!check(s, c) || !check(s, sigma_s)) return -1;
+  DMaterial m{};
+  m.kind = MAT_SUBSURFACE;
+  memcpy(m.color, c, 12);
+  m.roughness = roughness;
+  m.ior = 1.4f;  // material.h:110
+  memcpy(m.sigma_s, sigma_s, 12);
+  std::string n = mat_name(s, name);
+  return s->host.add_material(
+      n.c_str(), m, "material " + n + " subsurface " + hex3(c) + fmt(" %a ", roughness) + hex3(sigma_s));
+}
+int pine_gpu_scene_find_material(pine_gpu_scene* s, const char* name) {
+  if (!check(s, name)) return -1;
+  int id = s->host.find_material(name);
+  if (id < 0) set_error(std::string("Can't find material `") + name + "`");  // scene.cpp:53
+  return id;
+}
+
+static std::string matref(pine_gpu_scene* s, int material) {
+  if (material < 0 || material >= int(s->host.material_names.size())) return "?";
+  return s->host.material_names[material];
+}
+
+int pine_gpu_scene_add_rect(pine_gpu_scene* s, const float position[3], const float ex_[3],
+                            const float ey_[3], int flip, int material) {
+  if (!check(s, position) || !check(s, ex_) || !check(s, ey_)) return -1;
+  HostGeometry g{};
+  DShape& d = g.shape;
+  d.kind = SHAPE_RECT;
+  d.material = material;
+  // Rect::Rect geometry.cpp:255-267
+  f3 ex = normalize(ld3(ex_)), ey = normalize(ld3(ey_));
+  f3 n = normalize(cross(ex, ey)) * float(flip ? -1 : 1);
+  float lx = length(ld3(ex_)), ly = length(ld3(ey_));
+  f3 rx = ex / lx, ry = ey / ly;
+  if (std::abs(length(n) - 1.0f) > 1e-6f) {
+    set_error("`Rect` has degenerated shape");
+    return -1;
+  }
+  float* f = d.f;
+  memcpy(f, position, 12);
+  f[3] = ex.x, f[4] = ex.y, f[5] = ex.z;
+  f[6] = ey.x, f[7] = ey.y, f[8] = ey.z;
+  f[9] = n.x, f[10] = n.y, f[11] = n.z;
+  f[12] = lx, f[13] = ly;
+  f[14] = rx.x, f[15] = rx.y, f[16] = rx.z;
+  f[17] = ry.x, f[18] = ry.y, f[19] = ry.z;
+  f[20] = lx * ly;  // Rect::area geometry.h:97
+  g.describe = "shape rect " + matref(s, material) + " " + hex3(position) + " " + hex3(ex_) + " " +
+               hex3(ey_) + fmt(" %d", flip ? 1 : 0);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_aabb(pine_gpu_scene* s, const float lo[3], const float hi[3], int material) {
+  if (!check(s, lo) || !check(s, hi)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_AABB;
+  g.shape.material = material;
+  memcpy(g.shape.f, lo, 12);
+  memcpy(g.shape.f + 3, hi, 12);
+  g.describe = "shape box " + matref(s, material) + " " + hex3(lo) + " " + hex3(hi);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_obb(pine_gpu_scene* s, const float lo[3], const float hi[3],
+                           const float m[16], int material) {
+  if (!check(s, lo) || !check(s, hi) || !check(s, m)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_OBB;
+  g.shape.material = material;
+  float* f = g.shape.f;
+  memcpy(f, lo, 12);
+  memcpy(f + 3, hi, 12);
+  Mat4 M = Mat4::from_storage(m);
+  Mat4 Mi = mat4_inverse(M);  // OBB::OBB bbox.cpp:144
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 3; r++) {
+      f[6 + c * 3 + r] = M.m[c][r];
+      f[18 + c * 3 + r] = Mi.m[c][r];
+    }
+  // describe with row-major constructor arguments (what `mat4(...)` takes)
+  std::string ms;
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) ms += fmt(" %a", M.m[c][r]);
+  g.describe = "shape obb " + matref(s, material) + " " + hex3(lo) + " " + hex3(hi) + ms;
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_sphere(pine_gpu_scene* s, const float c[3], float r, int material) {
+  if (!check(s, c)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_SPHERE;
+  g.shape.material = material;
+  memcpy(g.shape.f, c, 12);
+  g.shape.f[3] = r;
+  g.describe = "shape sphere " + matref(s, material) + " " + hex3(c) + fmt(" %a", r);
+  return s->host.add_geometry(std::move(g));
+}
+static bool fill_disk(float* f, f3 position, f3 normal, float r) {  // Disk::Disk geometry.cpp:123-127
+  if (r < 0.0f) {
+    set_error("`Disk` can't have negative radius");
+    return false;
+  }
+  f3 n = normalize(normal);
+  if (length(n) == 0.0f) {
+    set_error("`Disk` can't have degenerated normal");
+    return false;
+  }
+  f3 u, v;
+  coordinate_system(n, u, v);
+  f[0] = position.x, f[1] = position.y, f[2] = position.z;
+  f[3] = n.x, f[4] = n.y, f[5] = n.z;
+  f[6] = u.x, f[7] = u.y, f[8] = u.z;
+  f[9] = v.x, f[10] = v.y, f[11] = v.z;
+  f[12] = r;
+  f[13] = kPi * r * r;  // Disk::area geometry.h:54
+  return true;
+}
+int pine_gpu_scene_add_disk(pine_gpu_scene* s, const float p[3], const float n[3], float r, int material) {
+  if (!check(s, p) || !check(s, n)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_DISK;
+  g.shape.material = material;
+  if (!fill_disk(g.shape.f, ld3(p), ld3(n), r)) return -1;
+  g.describe = "shape disk " + matref(s, material) + " " + hex3(p) + " " + hex3(n) + fmt(" %a", r);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_cone(pine_gpu_scene* s, const float p_[3], const float n_[3], float r, float h,
+                            int material) {
+  if (!check(s, p_) || !check(s, n_)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_CONE;
+  g.shape.material = material;
+  // Cone::Cone geometry.cpp:409-414: apex = p + n*h (n as given), n normalised afterwards
+  float bottom[14];
+  if (!fill_disk(bottom, ld3(p_), ld3(n_), r)) return -1;
+  f3 apex = ld3(p_) + ld3(n_) * h;
+  f3 n = normalize(ld3(n_));
+  float A2 = sqr(r / h) + 1;
+  float A = std::sqrt(A2);
+  float S = r / std::sqrt(r * r + h * h);
+  float area = std::sqrt(r * r + h * h) * kPi * r + bottom[13];  // geometry.h:132
+  float* f = g.shape.f;
+  f[0] = apex.x, f[1] = apex.y, f[2] = apex.z;
+  f[3] = n.x, f[4] = n.y, f[5] = n.z;
+  f[6] = r, f[7] = h, f[8] = A, f[9] = A2, f[10] = S, f[11] = area;
+  f[12] = p_[0], f[13] = p_[1], f[14] = p_[2];  // bottom disk centre (AABB only)
+  g.describe = "shape cone " + matref(s, material) + " " + hex3(p_) + " " + hex3(n_) + fmt(" %a %a", r, h);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_mesh(pine_gpu_scene* s, const float* vertices, int nv, const uint32_t* indices,
+                            int nt, int material) {
+  if (!check(s, vertices) || !check(s, indices)) return -1;
+  for (int i = 0; i < 3 * nt; i++)
+    if (indices[i] >= uint32_t(nv)) {
+      set_error("mesh index out of range");
+      return -1;
+    }
+  HostMesh m;
+  m.vertices.assign(vertices, vertices + 3 * size_t(nv));
+  m.indices.assign(indices, indices + 3 * size_t(nt));
+  HostGeometry g{};
+  g.shape.kind = SHAPE_MESH;
+  g.shape.material = material;
+  if (nt > 0) {  // Mesh::area geometry.h:167-169: first triangle's area x count
+    f3 a = ld3(&vertices[3 * indices[0]]), b = ld3(&vertices[3 * indices[1]]), c = ld3(&vertices[3 * indices[2]]);
+    g.shape.f[3] = length(cross(b - a, c - a)) / 2 * float(size_t(nt));
+  }
+  std::string d = "shape mesh " + matref(s, material) + fmt(" %d %d", nv, nt);
+  for (int i = 0; i < 3 * nv; i++) d += fmt(" %a", vertices[i]);
+  for (int i = 0; i < 3 * nt; i++) d += fmt(" %u", indices[i]);
+  g.describe = std::move(d);
+  s->host.meshes.push_back(std::move(m));
+  g.mesh = int(s->host.meshes.size()) - 1;
+  return s->host.add_geometry(std::move(g));
+}
+
+int pine_gpu_scene_set_camera_thinlens(pine_gpu_scene* s, int w, int h, int tonemapper, const float from[3],
+                                       const float to[3], float fov, float len_radius, float focus) {
+  if (!check(s, from) || !check(s, to)) return -1;
+  if (w <= 0 || h <= 0) {
+    set_error("film size must be positive");
+    return -1;
+  }
+  DCamera& c = s->host.camera;
+  memcpy(c.position, from, 12);
+  Mat4 L = mat4_look_at(ld3(from), ld3(to));  // camera.cpp:9-10
+  for (int col = 0; col < 3; col++)
+    for (int r = 0; r < 3; r++) c.c2w[col * 3 + r] = L.m[col][r];
+  float aspect = float(w) / h;  // Film::aspect film.h:32
+  c.fov2d[0] = fov * aspect;
+  c.fov2d[1] = fov;
+  c.len_radius = len_radius;
+  c.focus_distance = focus;
+  c.W = w;
+  c.H = h;
+  s->host.has_camera = true;
+  s->host.tonemapper = tonemapper;
+  s->host.camera_describe = fmt("camera thinlens %d %d ", w, h) + hex3(from) + " " + hex3(to) +
+                            fmt(" %a %a %a", fov, len_radius, focus);
+  return 0;
+}
+
+int64_t pine_gpu_scene_describe(pine_gpu_scene* s, char* buf, int64_t capacity) {
+  if (!check(s)) return -1;
+  std::string d = s->host.describe();
+  if (buf && capacity > 0) {
+    int64_t n = std::min<int64_t>(capacity - 1, int64_t(d.size()));
+    memcpy(buf, d.data(), size_t(n));
+    buf[n] = 0;
+  }
+  return int64_t(d.size());
+}
+
+int pine_gpu_scene_build_accel(pine_gpu_scene* s) {
+  if (!check(s)) return -1;
+  s->host.build_accel();
+  return int(s->host.accel.nodes.size());
+}
+int64_t pine_gpu_scene_accel_dump(pine_gpu_scene* s, void* nodes_out, int64_t node_cap, int32_t* prims_out,
+                                  int64_t prim_cap) {
+  if (!check(s)) return -1;
+  if (!s->host.accel.built) s->host.build_accel();
+  const FlatAccel& a = s->host.accel;
+  if (nodes_out && node_cap >= int64_t(a.nodes.size() * sizeof(DNode)))
+    memcpy(nodes_out, a.nodes.data(), a.nodes.size() * sizeof(DNode));
+  if (prims_out && prim_cap >= int64_t(a.prims.size()))
+    memcpy(prims_out, a.prims.data(), a.prims.size() * 4);
+  return int64_t(a.prims.size());
+}
+
+// Film::finalize + tone mapping + to_uint8_array (film.cpp:21-27,66-68; color.cpp:6-23;
+// fileio.cpp:42-54 with flip_y = true, apply_gamma = true)
+int pine_gpu_film_finalize_u8(const float* film, int w, int h, int tonemapper, uint8_t* out) {
+  if (!film || !out || w <= 0 || h <= 0) {
+    set_error("bad argument");
+    return -1;
+  }
+  auto unch = [](float x) {
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return (x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F) - E / F;
+  };
+  const float white = unch(11.2f);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int ys = h - 1 - y;  // y flip
+      const float* p = film + (size_t(ys) * w + x) * 4;
+      float v[4];
+      for (int c = 0; c < 3; c++) {
+        float t;
+        if (tonemapper == 1) {  // ACES color.cpp:14-23
+          const float a = 2.51f, b = 0.03f, cc = 2.43f, d = 0.59f, e = 0.14f;
+          float xx = p[c];
+          float r = (xx * (a * xx + b)) / (xx * (cc * xx + d) + e);
+          t = pmin(pmax(r, 0.0f), 1.0f);
+        } else {  // Uncharted2 color.cpp:6-13
+          t = unch(p[c] * 2.0f) * 1.0f / white;
+        }
+        v[c] = t;
+      }
+      v[3] = 1.0f;  // finalize sets w = 1
+      for (int c = 0; c < 4; c++) {
+        float g = std::pow(v[c], 1 / 2.2f);
+        out[(size_t(y) * w + x) * 4 + c] = uint8_t(pmin(pmax(g * 256.0f, 0.0f), 255.0f));
+      }
+    }
+  return 0;
+}
+
+}  // extern "C"
+
+// accessor used by the GPU side (pine_kernels.hip)
+namespace pine_gpu {
+SceneHost& scene_host(pine_gpu_scene* s) { return s->host; }
+}  // namespace pine_gpu

@@ -1,0 +1,98 @@
+// pine_amd/csrc/pine_host.h -- host-side scene model behind the C ABI (include/pine_gpu.h).
+// Mirrors what the reference computes on the host before rendering: shape constructors
+// (derived quantities), camera setup, area-light list, and pine's BVH build, flattened into the
+// GPU records of pine_types.h.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "pine_math.h"
+#include "pine_types.h"
+
+namespace pine_gpu {
+
+// Full 4x4 host matrix in the reference's storage order: m[c][r] (column vectors).
+struct Mat4 {
+  float m[4][4];
+  static Mat4 identity();
+  static Mat4 from_rows(const float r[16]);  // the reference's scalar ctor (row-major arguments)
+  static Mat4 from_storage(const float s[16]);
+  void to_storage(float s[16]) const;
+};
+Mat4 mat4_mul(const Mat4& l, const Mat4& r);
+Mat4 mat4_inverse(const Mat4& m);
+Mat4 mat4_translate(f3 v);
+Mat4 mat4_scale(f3 v);
+Mat4 mat4_rotate_x(float rad);
+Mat4 mat4_rotate_y(float rad);
+Mat4 mat4_rotate_z(float rad);
+Mat4 mat4_look_at(f3 from, f3 at);
+
+struct HostAABB {
+  f3 lower{kFloatMax, kFloatMax, kFloatMax};
+  f3 upper{-kFloatMax, -kFloatMax, -kFloatMax};
+  void extend(f3 p) {
+    lower = vmin(lower, p);
+    upper = vmax(upper, p);
+  }
+  void extend(const HostAABB& b) {
+    lower = vmin(lower, b.lower);
+    upper = vmax(upper, b.upper);
+  }
+  f3 centroid() const { return (lower + upper) / 2.0f; }
+  float centroid(int d) const { return (get(lower, d) + get(upper, d)) / 2; }
+  float surface_area() const {
+    f3 d = upper - lower;
+    return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z);
+  }
+  bool degenerated(int d) const { return get(upper, d) <= get(lower, d); }
+  float relative_position(float p, int dim) const {
+    float o = p - get(lower, dim);
+    float d = get(upper, dim) - get(lower, dim);
+    return d > 0.0f ? o / d : o;
+  }
+};
+
+struct HostMesh {
+  std::vector<float> vertices;    // 3 per vertex
+  std::vector<uint32_t> indices;  // 3 per triangle
+};
+
+struct HostGeometry {
+  DShape shape;
+  std::string describe;  // the .pscene line that recreates it (user-level parameters, hexfloat)
+  int mesh = -1;         // index into SceneHost::meshes for SHAPE_MESH
+};
+
+struct FlatAccel {
+  std::vector<DNode> nodes;
+  std::vector<int> prims;  // leaf primitive ids (top level: geometry index; mesh: triangle index)
+  std::vector<DBvh> bvhs;  // [0] = top level, then one per mesh in lbvh order
+  std::vector<float> tri_verts;    // all meshes: 9 floats per triangle (v0,v1,v2), mesh after mesh
+  bool built = false;
+};
+
+struct SceneHost {
+  std::vector<DMaterial> materials;
+  std::vector<std::string> material_names;
+  std::vector<std::string> material_describe;
+  std::vector<HostGeometry> geometries;
+  std::vector<HostMesh> meshes;
+  std::vector<int> lights;  // geometry indices, in add order
+  DCamera camera{};
+  bool has_camera = false;
+  int tonemapper = 0;
+  std::string camera_describe;
+  FlatAccel accel;
+
+  int find_material(const char* name) const;
+  int add_material(const char* name, const DMaterial& m, const std::string& desc);
+  int add_geometry(HostGeometry g);
+  HostAABB geometry_aabb(int g) const;
+  void build_accel();
+  std::string describe() const;
+};
+
+void set_error(const std::string& msg);
+
+}  // namespace pine_gpu

@@ -1,0 +1,1171 @@
+// pine_amd/csrc/pine_kernels.hip -- the PathIntegrator hot path on gfx950 (MI355X).
+//
+// Formulation (DESIGN.md has the long version):
+//  * A persistent grid of 64-lane waves.  Each lane owns one *work item* = `samples_per_item`
+//    consecutive camera samples of one pixel, and runs the reference's radiance() recursion as an
+//    iterative state machine: one radiance() invocation ("path vertex") per loop trip.  A lane
+//    whose path ends regenerates immediately (next sample of its item, or a new item pulled from a
+//    global queue with one wave-aggregated atomic), so all 64 lanes stay busy until the queue runs
+//    dry -- the exit condition every wave reaches.
+//  * The per-level firefly clamp of the reference (path.cpp:121) forces a backward fold of
+//    per-vertex terms; each non-terminal vertex spills a 32-byte FoldEntry to a lane-interleaved
+//    global stack and the terminal vertex folds it back.
+//  * Per-sample radiance goes to a [tile][sample][pixel-in-tile] buffer; a second kernel sums each
+//    pixel's samples in sample order (the reference's `L += ...` order, path.cpp:34-37) so the
+//    film is independent of scheduling and of the number of GPUs.
+//  * The per-pixel RNG stream (pixel jitter) is sequential across a pixel's samples; a prepass
+//    computes its state at every item boundary when the scene has no in-path RNG consumer,
+//    otherwise one item = the whole pixel.
+//
+// No MFMA (no dense contraction here); the kernel is VALU/latency bound on cbox-class scenes.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pine_gpu.h"
+#include "pine_device.h"
+#include "pine_host.h"
+
+struct pine_gpu_scene;
+namespace pine_gpu {
+SceneHost& scene_host(pine_gpu_scene* s);
+
+constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kTile = 8;         // 8x8 pixel tiles = 64 pixels = one wave's worth of items
+constexpr int kMaxDepth = 32;    // max_path_length supported (2 beta bits per level in one u64)
+
+struct DeviceScene {
+  const DShape* shapes;
+  const DMaterial* materials;
+  const DNode* nodes;
+  const int* prims;
+  const DBvh* bvhs;
+  const float* tri_verts;
+  const int* lights;
+  int num_lights;
+  int num_shapes;
+  DCamera cam;
+  DTables tables;
+  int spp;              // effective
+  int max_path_length;
+  int stack_top;        // traversal stack entries needed by the top-level BVH
+  int stack_total;      // top + deepest mesh BVH
+};
+
+struct WorkParams {
+  int tiles_x, tiles_y;
+  int num_local_tiles;   // tiles owned by this shard
+  int shard_rank, shard_world;
+  int samples_per_item;  // k
+  int items_per_pixel;   // spp / k
+  unsigned long long total_items;  // num_local_tiles * items_per_pixel * 64
+};
+
+// ------------------------------------------------------------------------------------------------
+// BVH traversal -- pine's ordered stack traversal (src/pine/impl/accel/bvh.cpp:321-451), with the
+// node's two child boxes tested against the tmax captured when the node is visited, leaf children
+// tested inline in stored primitive order, nearer-exit child first.  The stack lives in LDS,
+// lane-interleaved ([slot][thread]) so pushes/pops are bank-conflict free.
+// ------------------------------------------------------------------------------------------------
+template <bool ANY>
+__device__ __forceinline__ bool mesh_traverse(const DeviceScene& S, const DBvh bvh, DRay& ray,
+                                              const DRayOct& oct, int* stack, int sp0, int& prim_out) {
+  bool hit = false;
+  auto leaf = [&](int start, int count) -> bool {
+    for (int i = start; i < start + count; i++) {
+      const int tri = S.prims[i] + bvh.prim_base;
+      const float* v = S.tri_verts + size_t(tri) * 9;
+      if (ANY) {
+        if (tri_hit(v, ray)) return true;
+      } else if (tri_intersect(v, ray)) {
+        hit = true;
+        prim_out = tri;
+      }
+    }
+    return false;
+  };
+  if (bvh.root_count > 0) {
+    if (leaf(bvh.root_start, bvh.root_count)) return true;
+    return hit;
+  }
+  int sp = sp0;
+  int next = bvh.root;
+  while (true) {
+    const DNode* node = &S.nodes[next];
+    int l = -1, r = -1;
+    float t0 = ray.tmax, t1 = ray.tmax;
+    if (box_hit_oct(node->lo0, node->hi0, oct, ray.tmin, t0)) {
+      if (node->count[0] == 0) l = node->child[0];
+      else if (leaf(node->child[0], node->count[0])) return true;
+    }
+    if (box_hit_oct(node->lo1, node->hi1, oct, ray.tmin, t1)) {
+      if (node->count[1] == 0) r = node->child[1];
+      else if (leaf(node->child[1], node->count[1])) return true;
+    }
+    if (l != -1) {
+      if (r != -1) {
+        if (t0 > t1) {
+          stack[sp * kBlock] = l;
+          next = r;
+        } else {
+          stack[sp * kBlock] = r;
+          next = l;
+        }
+        sp++;
+      } else next = l;
+    } else if (r != -1) next = r;
+    else {
+      if (sp == sp0) break;
+      next = stack[(--sp) * kBlock];
+    }
+  }
+  return hit;
+}
+
+// ANY: BVH::hit (bvh.cpp:497-511).  !ANY: BVH::intersect (bvh.cpp:513-548) minus the final
+// compute_surface_info, which the caller does once for the winning primitive.
+template <bool ANY>
+__device__ __forceinline__ bool scene_traverse(const DeviceScene& S, DRay& ray, int* stack, int& geom_out,
+                                               int& prim_out) {
+  if (S.num_shapes == 0) return false;
+  const DRayOct oct = make_oct(ray);
+  const DBvh top = S.bvhs[0];
+  bool hit = false;
+  auto leaf = [&](int start, int count) -> bool {
+    for (int i = start; i < start + count; i++) {
+      const int g = S.prims[i];
+      const DShape* sh = &S.shapes[g];
+      if (sh->kind == SHAPE_MESH) {
+        const DBvh mb = S.bvhs[as_int(sh->f[2])];
+        int prim = 0;
+        const bool h = mesh_traverse<ANY>(S, mb, ray, oct, stack, S.stack_top, prim);
+        if (ANY) {
+          if (h) return true;
+        } else if (h) {
+          hit = true;
+          geom_out = g;
+          prim_out = prim;
+        }
+      } else if (ANY) {
+        if (shape_hit(sh, ray)) return true;
+      } else if (shape_intersect(sh, ray)) {
+        hit = true;
+        geom_out = g;
+      }
+    }
+    return false;
+  };
+  if (top.root_count > 0) {
+    if (leaf(top.root_start, top.root_count)) return true;
+    return hit;
+  }
+  int sp = 0;
+  int next = top.root;
+  while (true) {
+    const DNode* node = &S.nodes[next];
+    int l = -1, r = -1;
+    float t0 = ray.tmax, t1 = ray.tmax;
+    if (box_hit_oct(node->lo0, node->hi0, oct, ray.tmin, t0)) {
+      if (node->count[0] == 0) l = node->child[0];
+      else if (leaf(node->child[0], node->count[0])) return true;
+    }
+    if (box_hit_oct(node->lo1, node->hi1, oct, ray.tmin, t1)) {
+      if (node->count[1] == 0) r = node->child[1];
+      else if (leaf(node->child[1], node->count[1])) return true;
+    }
+    if (l != -1) {
+      if (r != -1) {
+        if (t0 > t1) {
+          stack[sp * kBlock] = l;
+          next = r;
+        } else {
+          stack[sp * kBlock] = r;
+          next = l;
+        }
+        sp++;
+      } else next = l;
+    } else if (r != -1) next = r;
+    else {
+      if (sp == 0) break;
+      next = stack[(--sp) * kBlock];
+    }
+  }
+  return hit;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Item <-> pixel mapping.  Items are ordered [local tile][chunk][pixel in tile] so that the 64
+// consecutive items a fresh wave pulls are one 8x8 tile at one sample range: coherent rays,
+// contiguous sampler-tile bytes, contiguous sample-buffer rows.
+// ------------------------------------------------------------------------------------------------
+struct ItemInfo {
+  int px, py;
+  int chunk;
+  unsigned long long sample_base;  // index of sample 0 of this pixel row in the samples buffer / 64-strided
+  bool valid;
+};
+__device__ __forceinline__ ItemInfo decode_item(const WorkParams& W, int film_w, int film_h, int spp,
+                                                unsigned long long item) {
+  ItemInfo it;
+  const int p = int(item & 63);
+  const unsigned long long tc = item >> 6;
+  const int chunk = int(tc % (unsigned)W.items_per_pixel);
+  const int ltile = int(tc / (unsigned)W.items_per_pixel);
+  const int tile = ltile * W.shard_world + W.shard_rank;
+  const int tx = tile % W.tiles_x, ty = tile / W.tiles_x;
+  it.px = tx * kTile + (p & 7);
+  it.py = ty * kTile + (p >> 3);
+  it.chunk = chunk;
+  it.sample_base = (unsigned long long)ltile * (unsigned)spp * 64ull + (unsigned)p;
+  it.valid = it.px < film_w && it.py < film_h;
+  return it;
+}
+
+// RNG state at the start of every item: the reference reseeds per pixel (sampler.h:286-290) and
+// then draws 4 floats per camera sample (path.cpp:35); when nothing inside radiance() touches the
+// RNG the state at sample s is the seed advanced 4*s steps.
+__global__ void __launch_bounds__(kBlock) rng_checkpoint_kernel(WorkParams W, int film_w, int film_h, int spp,
+                                                               ulonglong2* ckpt) {
+  // one thread per (local tile, pixel in tile); walks the whole pixel, storing at chunk starts
+  const unsigned long long t = blockIdx.x * (unsigned long long)kBlock + threadIdx.x;
+  const unsigned long long n = (unsigned long long)W.num_local_tiles * 64ull;
+  if (t >= n) return;
+  const int p = int(t & 63);
+  const int ltile = int(t >> 6);
+  const int tile = ltile * W.shard_world + W.shard_rank;
+  const int px = (tile % W.tiles_x) * kTile + (p & 7), py = (tile / W.tiles_x) * kTile + (p >> 3);
+  DRng g = rng_seed(hash_pixel(px, py, 0));
+  for (int c = 0; c < W.items_per_pixel; c++) {
+    const unsigned long long item = ((unsigned long long)ltile * W.items_per_pixel + c) * 64ull + p;
+    ckpt[item] = make_ulonglong2(g.s0, g.s1);
+    for (int i = 0; i < 4 * W.samples_per_item; i++) rng_next64(g);
+  }
+  (void)film_w, (void)film_h, (void)spp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The path kernel
+// ------------------------------------------------------------------------------------------------
+struct Counters {
+  unsigned long long next_item;
+  unsigned long long vertices;
+  unsigned long long shadow_rays;
+  unsigned long long pad;
+};
+
+__device__ __forceinline__ f3 material_le(const DMaterial* m, f3 n, f3 wo) {  // material.h:22-25
+  if (m->kind != MAT_EMISSIVE) return mk3(0.0f);
+  if (dot(wo, n) < 0.0f) return mk3(0.0f);
+  return ld3(m->color);
+}
+
+__global__ void __launch_bounds__(kBlock)
+path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
+                  float* __restrict__ fold, Counters* __restrict__ counters) {
+  extern __shared__ int lds_stack[];
+  int* stack = lds_stack + threadIdx.x;
+  const unsigned lane_slot = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned fold_stride = gridDim.x * kBlock;
+  auto fold_at = [&](int level, int field) -> float& {
+    return fold[(size_t(level) * 8 + field) * fold_stride + lane_slot];
+  };
+
+  // ---- lane state ----
+  bool lane_done = false;   // queue exhausted for this lane
+  bool have_item = false;
+  bool alive = false;       // a path is in flight
+  int s_cur = 0, s_end = 0;
+  unsigned long long sample_base = 0;
+  DSampler sampler;
+  sampler.px = sampler.py = sampler.index = sampler.dimension = 0;
+  sampler.rng = DRng{0, 0};
+  DRay ray;
+  ray.o = ray.d = mk3(0.0f);
+  ray.tmin = 0;
+  ray.tmax = 0;
+  int pv_length = 0, pv_diffuse_length = 0;
+  bool pv_is_delta = true;
+  unsigned long long beta_flags = 0;  // 2 bits per level: 0 = beta (1,1,1); 1..3 = beta 3 on channel-1 (BSSRDF)
+  unsigned vcount = 0;      // radiance() invocations of the current sample
+  unsigned long long shadow_count = 0, vertex_count = 0;
+
+  while (true) {
+    // ---------------- regeneration ----------------
+    if (!alive && !lane_done) {
+      if (!(have_item && s_cur < s_end)) {
+        have_item = false;
+        // pull one item; hipcc turns the per-lane atomicAdd into one wave-aggregated atomic
+        const unsigned long long item = atomicAdd(&counters->next_item, 1ull);
+        if (item >= W.total_items) {
+          lane_done = true;
+        } else {
+          const ItemInfo it = decode_item(W, S.cam.W, S.cam.H, S.spp, item);
+          if (it.valid) {
+            have_item = true;
+            sampler.px = it.px;
+            sampler.py = it.py;
+            s_cur = it.chunk * W.samples_per_item;
+            s_end = s_cur + W.samples_per_item;
+            sample_base = it.sample_base;
+            if (W.items_per_pixel == 1) {
+              sampler.rng = rng_seed(hash_pixel(it.px, it.py, 0));  // Sampler::start_pixel
+            } else {
+              const ulonglong2 c = ckpt[item];
+              sampler.rng = DRng{c.x, c.y};
+            }
+          }
+        }
+      }
+      if (have_item && s_cur < s_end) {
+        // start sample s_cur: BlueSobolSampler index = s, dimension = 0 (sampler.h:174-181)
+        sampler.index = s_cur;
+        sampler.dimension = 0;
+        // g++ evaluates gen_ray's arguments right to left (path.cpp:35): lens first, then jitter
+        const float lx = rng_nextf(sampler.rng);
+        const float ly = rng_nextf(sampler.rng);
+        const float jx = rng_nextf(sampler.rng);
+        const float jy = rng_nextf(sampler.rng);
+        const f2 pf{(float(sampler.px) + jx) / float(S.cam.W), (float(sampler.py) + jy) / float(S.cam.H)};
+        ray = camera_gen_ray(S.cam, pf, f2{lx, ly});
+        pv_length = 0;
+        pv_diffuse_length = 0;
+        pv_is_delta = true;
+        beta_flags = 0;
+        vcount = 0;
+        alive = true;
+      }
+    }
+    if (__all(lane_done && !alive)) break;
+    if (!alive) continue;
+
+    // ---------------- one radiance() invocation (path.cpp:42-124) ----------------
+    vcount++;
+    const f3 wi = -ray.d;
+    int geom = -1, prim = 0;
+    const bool hit = scene_traverse<false>(S, ray, stack, geom, prim);
+
+    // terminal result of this vertex, if it terminates
+    bool terminal = false;
+    f3 Lo = mk3(0.0f);
+    bool has_light_pdf = false;
+    float light_pdf = 0.0f;
+
+    DSurface it;
+    it.p = it.n = mk3(0.0f);
+    it.uv = f2{0, 0};
+    const DShape* shape = nullptr;
+    const DMaterial* mat = nullptr;
+    if (!hit) {
+      terminal = true;  // no environment light (path.cpp:75-81)
+    } else {
+      shape = &S.shapes[geom];
+      mat = &S.materials[shape->material];
+      const f3 ph = ray_at(ray, ray.tmax);
+      if (shape->kind == SHAPE_MESH) tri_surface_info(S.tri_verts + size_t(prim) * 9, ph, it);
+      else shape_surface_info(shape, ph, it);
+      if (mat->kind == MAT_EMISSIVE) {  // path.cpp:83-87
+        Lo = mk3(1.0f) * material_le(mat, it.n, wi);
+        if (!pv_is_delta) {
+          has_light_pdf = true;
+          light_pdf = shape_pdf(shape, ray, it.n) / float(size_t(S.num_lights));  // lightsampler.cpp:27-29
+        }
+        terminal = true;
+      } else if (pv_length + 1 >= S.max_path_length) {  // path.cpp:89
+        terminal = true;
+      }
+    }
+
+    if (!terminal) {
+      m3 l2w = coordinate_system(it.n);  // interaction.h:14-17
+      m3 w2l = transpose(l2w);
+      // ---- material.sample_bxdf (material.h:30-131, material.cpp:9-28) ----
+      const bool diffused = pv_diffuse_length > 0;
+      const float min_roughness = diffused ? 0.6f : 0.0f;  // bxdf.h:15
+      DBxdf bx;
+      bx.kind = BX_DIFFUSE;
+      bx.albedo = ld3(mat->color);
+      bx.roughness = 0.0f;
+      bx.ior = 1.0f;
+      if (mat->kind == MAT_UBER) {
+        if (with_probability(mat->metallic, sampler)) {
+          bx.kind = BX_CONDUCTOR;
+          bx.roughness = mat->roughness;
+        } else if (with_probability(mat->transmission, sampler)) {
+          bx.kind = BX_REFR_DIEL;
+          bx.roughness = mat->roughness;
+          bx.ior = mat->ior;
+        } else {
+          bx.kind = BX_DIFF_DIEL;
+          bx.roughness = mat->roughness;
+          bx.ior = mat->ior;
+        }
+      } else if (mat->kind == MAT_SUBSURFACE) {
+        const float fr = FrDielectric(dot(wi, it.n), mat->ior);
+        if (sampler_get1d(S.tables, sampler) < fr) {
+          bx.kind = BX_REFRACTIVE;
+          bx.roughness = pmax(mat->roughness, min_roughness);
+          bx.ior = mat->ior;
+        } else if (diffused) {
+          bx.kind = BX_DIFFUSE;
+        } else {
+          bx.kind = BX_BSSRDF;
+          bx.ior = mat->ior;
+        }
+      }
+      bx.wi = mul(w2l, wi);  // material.h:119
+
+      // ---- BSSRDF random walk inside the same shape (bxdf.cpp:329-353, :375-382) ----
+      int beta_channel = 0;
+      if (bx.kind == BX_BSSRDF) {
+        f3 p = it.p;
+        f3 w = -wi;
+        if (Refract(wi, it.n, bx.ior, w, nullptr)) {
+          const int channel = int(rng_nextf(sampler.rng) * 3);
+          const float sigma_t_inv = 1 / mat->sigma_s[channel];
+          const f3 n0 = it.n;
+          for (int i = 0;; i++) {
+            DRay wr = i == 0 ? spawn_ray_raw(p, n0, w) : DRay{p, w, 0.0f, kFloatMax};
+            DSurface sit;
+            sit.p = sit.n = mk3(0.0f);  // non-mesh shapes leave them zero (Appendix A5)
+            bool h;
+            if (shape->kind == SHAPE_MESH) {
+              const DRayOct oct = make_oct(wr);
+              int wprim = 0;
+              h = mesh_traverse<false>(S, S.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
+              if (h) tri_surface_info(S.tri_verts + size_t(wprim) * 9, ray_at(wr, wr.tmax), sit);
+            } else {
+              h = shape_intersect(shape, wr);
+            }
+            if (!h) break;  // sample_p returns nullopt: nothing changes
+            const float t = -logf(1 - sampler_get1d(S.tables, sampler)) * sigma_t_inv;
+            if (wr.tmax < t) {
+              beta_channel = channel + 1;
+              it.p = sit.p;
+              it.n = sit.n;
+              l2w = coordinate_system(it.n);
+              w2l = transpose(l2w);
+              bx.wi = mul(w2l, -w);
+              break;
+            }
+            p = ray_at(wr, t);
+            w = uniform_sphere(sampler_get2d(S.tables, sampler));
+          }
+        }
+      }
+
+      // ---- next-event estimation (path.cpp:98-113) ----
+      f3 nee = mk3(0.0f);
+      if (!bxdf_is_delta(bx)) {
+        // g++ order for LightSampler::sample's arguments (lightsampler.h:27): get2d, then get1d
+        const f2 u2 = sampler_get2d(S.tables, sampler);
+        float u1 = sampler_get1d(S.tables, sampler);
+        if (S.num_lights > 0) {  // UniformLightSampler::sample lightsampler.cpp:12-26
+          u1 *= float(S.num_lights);
+          const int index = int(u1);
+          const DShape* lshape = &S.shapes[S.lights[index]];
+          DShapeSample gs;
+          if (shape_sample(lshape, S.tri_verts, it.p, u2, u1 - float(index), gs)) {
+            // AreaLight::sample light.cpp:55-69
+            const f3 le = material_le(&S.materials[lshape->material], gs.n, -gs.w);
+            if (!is_zero(le)) {
+              const float ls_pdf = gs.pdf / float(S.num_lights);
+              shadow_count++;
+              DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
+              int g2, p2;
+              if (!scene_traverse<true>(S, sr, stack, g2, p2)) {
+                const float cosine = absdot(gs.w, it.n);
+                const f3 wo = mul(w2l, gs.w);
+                const f3 f = bxdf_f(bx, wo);
+                const float mis = balance_heuristic(ls_pdf, bxdf_pdf(bx, wo));
+                nee = mk3(0.0f) + le * mk3(1.0f) * cosine * f / ls_pdf * mis;
+              }
+            }
+          }
+        }
+      }
+
+      // ---- BSDF sampling + continuation (path.cpp:114-120) ----
+      DBsdfSample bs;
+      if (bxdf_sample(bx, S.tables, sampler, bs)) {
+        const f3 wo_world = mul(l2w, bs.wo);
+        const float cosine = absdot(wo_world, it.n);
+        const int level = pv_length;
+        fold_at(level, 0) = nee.x;
+        fold_at(level, 1) = nee.y;
+        fold_at(level, 2) = nee.z;
+        fold_at(level, 3) = bs.f.x;
+        fold_at(level, 4) = bs.f.y;
+        fold_at(level, 5) = bs.f.z;
+        fold_at(level, 6) = cosine / bs.pdf;
+        fold_at(level, 7) = bs.pdf;
+        beta_flags = (beta_flags & ~(3ull << (2 * level))) | ((unsigned long long)beta_channel << (2 * level));
+        ray = spawn_ray(it.p, it.n, wo_world, kFloatMax);
+        pv_length = level + 1;
+        pv_diffuse_length += bs.is_delta ? 0 : 1;
+        pv_is_delta = bs.is_delta;
+      } else {
+        // no continuation: this vertex resolves now with lo = nee (path.cpp:121)
+        f3 beta = mk3(1.0f);
+        if (beta_channel) {
+          beta = mk3(0.0f);
+          set(beta, beta_channel - 1, 3.0f);
+        }
+        Lo = mk3(0.0f) + vmin(mk3(1.0f) * beta * nee, mk3(8.0f));
+        terminal = true;
+      }
+    }
+
+    if (terminal) {
+      // ---- backward fold through the pending levels (path.cpp:114-121, Appendix A1) ----
+      f3 Li = Lo;
+      bool lp_valid = has_light_pdf;
+      float lp = light_pdf;
+      for (int level = pv_length - 1; level >= 0; level--) {
+        const f3 e_nee{fold_at(level, 0), fold_at(level, 1), fold_at(level, 2)};
+        const f3 e_f{fold_at(level, 3), fold_at(level, 4), fold_at(level, 5)};
+        const float e_cp = fold_at(level, 6), e_pdf = fold_at(level, 7);
+        const float mis = lp_valid ? balance_heuristic(e_pdf, lp) : 1.0f;
+        const f3 lo = e_nee + Li * e_f * (e_cp * mis);
+        f3 beta = mk3(1.0f);
+        const unsigned bc = unsigned(beta_flags >> (2 * level)) & 3u;
+        if (bc) {
+          beta = mk3(0.0f);
+          set(beta, int(bc) - 1, 3.0f);
+        }
+        Li = mk3(0.0f) + vmin(mk3(1.0f) * beta * lo, mk3(8.0f));
+        lp_valid = false;
+      }
+      samples[sample_base + (unsigned long long)s_cur * 64ull] = make_float4(Li.x, Li.y, Li.z, float(vcount));
+      vertex_count += vcount;
+      s_cur++;
+      alive = false;
+    }
+  }
+
+  // per-wave reduction of the counters, one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) {
+    vertex_count += __shfl_down(vertex_count, off);
+    shadow_count += __shfl_down(shadow_count, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counters->vertices, vertex_count);
+    atomicAdd(&counters->shadow_rays, shadow_count);
+  }
+}
+
+// Ordered per-pixel sum: film[p] = (sum_{s=0..spp-1, in order} L_s) / spp  (path.cpp:34-38).
+// One wave per tile, lane = pixel in tile: every sample row is one coalesced 1 KiB read.
+__global__ void __launch_bounds__(kBlock) resolve_kernel(WorkParams W, int film_w, int film_h, int spp,
+                                                        const float4* __restrict__ samples, float4* __restrict__ film) {
+  const unsigned long long t = blockIdx.x * (unsigned long long)kBlock + threadIdx.x;
+  const int ltile = int(t >> 6);
+  if (ltile >= W.num_local_tiles) return;
+  const int p = int(t & 63);
+  const int tile = ltile * W.shard_world + W.shard_rank;
+  const int px = (tile % W.tiles_x) * kTile + (p & 7), py = (tile / W.tiles_x) * kTile + (p >> 3);
+  if (px >= film_w || py >= film_h) return;
+  const float4* row = samples + (unsigned long long)ltile * (unsigned)spp * 64ull + p;
+  f3 L = mk3(0.0f);
+  for (int s = 0; s < spp; s++) {
+    const float4 v = row[(unsigned long long)s * 64ull];
+    L = L + f3{v.x, v.y, v.z};
+  }
+  const f3 m = L / float(spp);
+  film[size_t(py) * film_w + px] = make_float4(m.x, m.y, m.z, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side unit-test kernels (parity of the building blocks against the oracle)
+// ------------------------------------------------------------------------------------------------
+__global__ void test_sincos_kernel(const float* x, long long n, float* s, float* c) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) {
+    s[i] = psin(x[i]);
+    c[i] = pcos(x[i]);
+  }
+}
+__constant__ int kTestPixels[6][2] = {{0, 0}, {1, 0}, {3, 5}, {127, 127}, {128, 5}, {639, 639}};
+__global__ void test_sampler_kernel(DTables T, int spp, float* out) {
+  // one thread per (pixel, pass); layout identical to oracle_sampler_stream
+  const int pix = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  float* o = out + size_t(pix) * spp * (260 + 270);
+  DSampler s;
+  s.px = kTestPixels[pix][0];
+  s.py = kTestPixels[pix][1];
+  s.dimension = 0;
+  s.index = 0;
+  s.rng = DRng{0, 0};
+  size_t k = 0;
+  for (int i = 0; i < spp; i++) {
+    for (int d = 0; d < 130; d++) {
+      const f2 v = sampler_get2d(T, s);
+      o[k++] = v.x;
+      o[k++] = v.y;
+    }
+    s.dimension = 0;
+    s.index++;
+  }
+  s.index = 0;
+  for (int i = 0; i < spp; i++) {
+    for (int d = 0; d < 90; d++) {
+      o[k++] = sampler_get1d(T, s);
+      const f2 v = sampler_get2d(T, s);
+      o[k++] = v.x;
+      o[k++] = v.y;
+    }
+    s.dimension = 0;
+    s.index++;
+  }
+}
+__global__ void test_rng_kernel(unsigned long long* out) {
+  const int pix = threadIdx.x;
+  if (pix >= 6) return;
+  unsigned long long* o = out + pix * 19;
+  const uint64_t h = hash_pixel(kTestPixels[pix][0], kTestPixels[pix][1], 0);
+  o[0] = h;
+  DRng g = rng_seed(h);
+  o[1] = g.s0;
+  o[2] = g.s1;
+  for (int i = 0; i < 16; i++) o[3 + i] = (unsigned long long)(uint32_t)as_int(rng_nextf(g));
+}
+__global__ void test_shapes_kernel(const DShape* shapes, int num_shapes, const float* rays, long long nrays,
+                                   float* out) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= nrays * num_shapes) return;
+  const int g = int(i / nrays);
+  const long long r = i % nrays;
+  const float* q = rays + r * 8;
+  DRay ray{f3{q[0], q[1], q[2]}, f3{q[3], q[4], q[5]}, q[6], q[7]};
+  float* o = out + i * 11;
+  const DShape* S = &shapes[g];
+  o[0] = shape_hit(S, ray) ? 1.0f : 0.0f;
+  DRay r2 = ray;
+  const bool h = shape_intersect(S, r2);
+  o[1] = h ? 1.0f : 0.0f;
+  o[2] = r2.tmax;
+  DSurface it;
+  it.p = it.n = mk3(0.0f);
+  it.uv = f2{0, 0};
+  if (h) shape_surface_info(S, ray_at(r2, r2.tmax), it);
+  o[3] = it.p.x, o[4] = it.p.y, o[5] = it.p.z;
+  o[6] = it.n.x, o[7] = it.n.y, o[8] = it.n.z;
+  o[9] = it.uv.x, o[10] = it.uv.y;
+}
+
+// ================================================================================================
+// Host side: plans, launches
+// ================================================================================================
+#define HIP_OK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+      return -1;                                                                              \
+    }                                                                                         \
+  } while (0)
+
+static std::string g_table_path;
+static std::vector<uint8_t> g_tables;
+static std::mutex g_table_mutex;
+static std::atomic<float> g_progress{0.0f};
+
+static int load_tables() {
+  std::lock_guard<std::mutex> lock(g_table_mutex);
+  if (!g_tables.empty()) return 0;
+  if (g_table_path.empty()) {
+    set_error("BlueSobol table path not set (pine_gpu_set_table_path)");
+    return -1;
+  }
+  FILE* f = fopen(g_table_path.c_str(), "rb");
+  if (!f) {
+    set_error("cannot open " + g_table_path);
+    return -1;
+  }
+  std::vector<uint8_t> buf(65536 + 9 * 262144);
+  size_t n = fread(buf.data(), 1, buf.size(), f);
+  fclose(f);
+  if (n != buf.size()) {
+    set_error("short read of " + g_table_path);
+    return -1;
+  }
+  g_tables.swap(buf);
+  return 0;
+}
+static int effective_spp(int spp) {  // BlueSobolSampler ctor sampler.cpp:115-121
+  if (spp > 256) spp = 256;
+  if (spp <= 0) return 0;
+  int x = spp - 1;
+  for (unsigned i = 1; i < 32; i <<= 1) x |= x >> i;
+  return x + 1;
+}
+
+template <class T>
+static int upload(T*& dptr, const std::vector<T>& v) {
+  dptr = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  HIP_OK(hipMalloc((void**)&dptr, bytes));
+  if (!v.empty()) HIP_OK(hipMemcpy(dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// depth of the inner-node tree below `node` (= traversal stack entries that can be live)
+static int bvh_depth(const std::vector<DNode>& nodes, int node) {
+  const DNode& n = nodes[node];
+  int d = 0;
+  for (int c = 0; c < 2; c++)
+    if (n.count[c] == 0) d = std::max(d, bvh_depth(nodes, n.child[c]));
+  return d + 1;
+}
+
+}  // namespace pine_gpu
+
+using namespace pine_gpu;
+
+struct pine_gpu_plan {
+  int device = 0;
+  pine_gpu_render_params params{};
+  DeviceScene S{};
+  WorkParams W{};
+  int film_w = 0, film_h = 0;
+  // device buffers
+  DShape* d_shapes = nullptr;
+  DMaterial* d_materials = nullptr;
+  DNode* d_nodes = nullptr;
+  int* d_prims = nullptr;
+  DBvh* d_bvhs = nullptr;
+  float* d_tri = nullptr;
+  int* d_lights = nullptr;
+  uint8_t* d_tables = nullptr;
+  ulonglong2* d_ckpt = nullptr;
+  float4* d_samples = nullptr;
+  float* d_fold = nullptr;
+  Counters* d_counters = nullptr;
+  int grid = 0;
+  size_t lds_bytes = 0;
+  bool serial_rng = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool timed = false;
+  bool launched = false;
+  hipStream_t last_stream = nullptr;
+};
+
+extern "C" {
+
+float pine_gpu_progress(void) { return g_progress.load(); }
+
+int pine_gpu_set_table_path(const char* path) {
+  if (!path) {
+    set_error("null path");
+    return -1;
+  }
+  std::lock_guard<std::mutex> lock(g_table_mutex);
+  g_table_path = path;
+  g_tables.clear();
+  return 0;
+}
+
+void pine_gpu_plan_destroy(pine_gpu_plan* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  hipFree(p->d_shapes);
+  hipFree(p->d_materials);
+  hipFree(p->d_nodes);
+  hipFree(p->d_prims);
+  hipFree(p->d_bvhs);
+  hipFree(p->d_tri);
+  hipFree(p->d_lights);
+  hipFree(p->d_tables);
+  hipFree(p->d_ckpt);
+  hipFree(p->d_samples);
+  hipFree(p->d_fold);
+  hipFree(p->d_counters);
+  for (auto& e : p->ev)
+    if (e) hipEventDestroy(e);
+  delete p;
+}
+
+static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_render_params* prm) {
+  SceneHost& H = scene_host(scene);
+  if (!H.has_camera) {
+    set_error("scene has no camera");
+    return -1;
+  }
+  if (prm->max_path_length <= 0) {  // path.cpp:12-13
+    set_error("`PathIntegrator` expect `max_path_length` to be positive");
+    return -1;
+  }
+  if (prm->max_path_length > kMaxDepth) {
+    set_error("max_path_length above the supported fold-stack depth (32)");
+    return -1;
+  }
+  const int spp = effective_spp(prm->spp);
+  if (spp <= 0) {
+    set_error("samples per pixel must be positive");
+    return -1;
+  }
+  if (prm->shard_world < 1 || prm->shard_rank < 0 || prm->shard_rank >= prm->shard_world) {
+    set_error("bad shard rank/world");
+    return -1;
+  }
+  if (load_tables()) return -1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    set_error("no HIP device available: the PathIntegrator hot path requires an AMD GPU (no CPU fallback)");
+    return -1;
+  }
+  HIP_OK(hipSetDevice(prm->device));
+  p->device = prm->device;
+  p->params = *prm;
+  if (!H.accel.built) H.build_accel();
+  const FlatAccel& A = H.accel;
+
+  std::vector<DShape> shapes;
+  for (auto& g : H.geometries) shapes.push_back(g.shape);
+  if (upload(p->d_shapes, shapes)) return -1;
+  if (upload(p->d_materials, H.materials)) return -1;
+  if (upload(p->d_nodes, A.nodes)) return -1;
+  if (upload(p->d_prims, A.prims)) return -1;
+  if (upload(p->d_bvhs, A.bvhs)) return -1;
+  if (upload(p->d_tri, A.tri_verts)) return -1;
+  if (upload(p->d_lights, H.lights)) return -1;
+  // tables: sobol + the selected spp variant
+  int k = 0;
+  while ((1 << k) < spp) k++;
+  HIP_OK(hipMalloc((void**)&p->d_tables, 65536 + 262144));
+  HIP_OK(hipMemcpy(p->d_tables, g_tables.data(), 65536, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(p->d_tables + 65536, g_tables.data() + 65536 + size_t(k) * 262144, 262144, hipMemcpyHostToDevice));
+
+  DeviceScene& S = p->S;
+  S.shapes = p->d_shapes;
+  S.materials = p->d_materials;
+  S.nodes = p->d_nodes;
+  S.prims = p->d_prims;
+  S.bvhs = p->d_bvhs;
+  S.tri_verts = p->d_tri;
+  S.lights = p->d_lights;
+  S.num_lights = int(H.lights.size());
+  S.num_shapes = int(shapes.size());
+  S.cam = H.camera;
+  S.tables.sobol = p->d_tables;
+  S.tables.scramble = p->d_tables + 65536;
+  S.tables.rank = p->d_tables + 65536 + 131072;
+  S.spp = spp;
+  S.max_path_length = prm->max_path_length;
+  int d_top = 0, d_mesh = 0;
+  for (size_t b = 0; b < A.bvhs.size(); b++) {
+    if (A.bvhs[b].root_count > 0 || A.bvhs[b].root < 0) continue;
+    int d = bvh_depth(A.nodes, A.bvhs[b].root);
+    if (b == 0) d_top = d;
+    else d_mesh = std::max(d_mesh, d);
+  }
+  S.stack_top = d_top;
+  S.stack_total = std::max(1, d_top + d_mesh);
+  p->lds_bytes = size_t(S.stack_total) * kBlock * sizeof(int);
+  if (p->lds_bytes > 160 * 1024) {
+    set_error("BVH too deep for the LDS traversal stack");
+    return -1;
+  }
+
+  // scenes whose materials draw from the per-pixel RNG inside radiance() (Uber with fractional
+  // metallic/transmission: sampler.h:317-324; BSSRDF channel pick: bxdf.cpp:335) make a pixel's
+  // samples sequentially dependent: one item = the whole pixel.
+  bool in_path_rng = false;
+  for (auto& m : H.materials) {
+    if (m.kind == MAT_SUBSURFACE) in_path_rng = true;
+    if (m.kind == MAT_UBER) {
+      if (m.metallic != 0 && m.metallic != 1) in_path_rng = true;
+      if (m.metallic != 1 && m.transmission != 0 && m.transmission != 1) in_path_rng = true;
+    }
+  }
+  p->serial_rng = in_path_rng;
+  int kspi = prm->samples_per_item;
+  if (in_path_rng) kspi = spp;
+  else if (kspi <= 0) kspi = std::min(spp, 4);
+  if (kspi > spp) kspi = spp;
+  while (spp % kspi) kspi--;  // spp is a power of two; keep k a divisor
+
+  WorkParams& W = p->W;
+  p->film_w = H.camera.W;
+  p->film_h = H.camera.H;
+  W.tiles_x = (p->film_w + kTile - 1) / kTile;
+  W.tiles_y = (p->film_h + kTile - 1) / kTile;
+  const int total_tiles = W.tiles_x * W.tiles_y;
+  W.shard_rank = prm->shard_rank;
+  W.shard_world = prm->shard_world;
+  W.num_local_tiles = (total_tiles - prm->shard_rank + prm->shard_world - 1) / prm->shard_world;
+  W.samples_per_item = kspi;
+  W.items_per_pixel = spp / kspi;
+  W.total_items = (unsigned long long)W.num_local_tiles * W.items_per_pixel * 64ull;
+
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, prm->device));
+  int blocks_per_cu = 0;
+  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, path_trace_kernel, kBlock, p->lds_bytes));
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  if (blocks_per_cu > 4) blocks_per_cu = 4;
+  const char* env_bpc = getenv("PINE_GPU_BLOCKS_PER_CU");
+  if (env_bpc && atoi(env_bpc) > 0) blocks_per_cu = atoi(env_bpc);
+  unsigned long long want = (W.total_items + kBlock - 1) / kBlock;
+  p->grid = int(std::min<unsigned long long>(want, (unsigned long long)prop.multiProcessorCount * blocks_per_cu));
+  if (p->grid < 1) p->grid = 1;
+
+  if (W.items_per_pixel > 1) HIP_OK(hipMalloc((void**)&p->d_ckpt, W.total_items * sizeof(ulonglong2)));
+  HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
+  HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * size_t(p->grid) * kBlock * sizeof(float)));
+  HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
+  p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
+  if (p->timed)
+    for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
+  return 0;
+}
+
+pine_gpu_plan* pine_gpu_plan_create(pine_gpu_scene* scene, const pine_gpu_render_params* prm) {
+  if (!scene || !prm) {
+    set_error("null argument");
+    return nullptr;
+  }
+  pine_gpu_plan* p = new pine_gpu_plan();
+  if (plan_build(p, scene, prm)) {
+    std::string keep = pine_gpu_last_error();
+    pine_gpu_plan_destroy(p);
+    set_error(keep);
+    return nullptr;
+  }
+  return p;
+}
+
+int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_) {
+  if (!p || !film_dev) {
+    set_error("null argument");
+    return -1;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  HIP_OK(hipSetDevice(p->device));
+  g_progress.store(0.0f);
+  const size_t film_bytes = size_t(p->film_w) * p->film_h * sizeof(float4);
+  if (p->W.shard_world > 1) HIP_OK(hipMemsetAsync(film_dev, 0, film_bytes, stream));
+  HIP_OK(hipMemsetAsync(p->d_counters, 0, sizeof(Counters), stream));
+  if (p->timed) HIP_OK(hipEventRecord(p->ev[0], stream));
+  if (p->W.items_per_pixel > 1) {
+    const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
+    hipLaunchKernelGGL(rng_checkpoint_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       p->W, p->film_w, p->film_h, p->S.spp, p->d_ckpt);
+  }
+  if (p->timed) HIP_OK(hipEventRecord(p->ev[1], stream));
+  hipLaunchKernelGGL(path_trace_kernel, dim3(p->grid), dim3(kBlock), p->lds_bytes, stream, p->S, p->W, p->d_ckpt,
+                     p->d_samples, p->d_fold, p->d_counters);
+  if (p->timed) HIP_OK(hipEventRecord(p->ev[2], stream));
+  {
+    const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
+    hipLaunchKernelGGL(resolve_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, p->W,
+                       p->film_w, p->film_h, p->S.spp, p->d_samples, (float4*)film_dev);
+  }
+  if (p->timed) HIP_OK(hipEventRecord(p->ev[3], stream));
+  HIP_OK(hipGetLastError());
+  p->launched = true;
+  p->last_stream = stream;
+  return 0;
+}
+
+int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
+  if (!p || !out) {
+    set_error("null argument");
+    return -1;
+  }
+  memset(out, 0, sizeof *out);
+  HIP_OK(hipSetDevice(p->device));
+  out->camera_samples = (unsigned long long)p->W.num_local_tiles * 64ull * p->S.spp;
+  // tiles on the film border may be partially outside: count real pixels
+  {
+    unsigned long long px = 0;
+    for (int lt = 0; lt < p->W.num_local_tiles; lt++) {
+      int tile = lt * p->W.shard_world + p->W.shard_rank;
+      int tx = tile % p->W.tiles_x, ty = tile / p->W.tiles_x;
+      int w = std::min(kTile, p->film_w - tx * kTile), h = std::min(kTile, p->film_h - ty * kTile);
+      px += (unsigned long long)w * h;
+    }
+    out->camera_samples = px * p->S.spp;
+  }
+  out->spp_effective = p->S.spp;
+  out->samples_per_item = p->W.samples_per_item;
+  out->grid_blocks = p->grid;
+  out->block_threads = kBlock;
+  out->lds_bytes = int(p->lds_bytes);
+  if (p->launched) {
+    HIP_OK(hipStreamSynchronize(p->last_stream));
+    Counters c;
+    HIP_OK(hipMemcpy(&c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    out->vertices = c.vertices;
+    out->shadow_rays = c.shadow_rays;
+    if (p->timed) {
+      HIP_OK(hipEventElapsedTime(&out->prepass_ms, p->ev[0], p->ev[1]));
+      HIP_OK(hipEventElapsedTime(&out->trace_ms, p->ev[1], p->ev[2]));
+      HIP_OK(hipEventElapsedTime(&out->resolve_ms, p->ev[2], p->ev[3]));
+    }
+  }
+  return 0;
+}
+
+int pine_gpu_plan_read_samples(pine_gpu_plan* p, float* out, int64_t capacity) {
+  if (!p || !out) {
+    set_error("null argument");
+    return -1;
+  }
+  const int spp = p->S.spp;
+  const int64_t need = int64_t(p->film_w) * p->film_h * spp * 4;
+  if (capacity < need) {
+    set_error("capacity too small");
+    return -1;
+  }
+  HIP_OK(hipSetDevice(p->device));
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<float> tmp(size_t(p->W.num_local_tiles) * spp * 64 * 4);
+  HIP_OK(hipMemcpy(tmp.data(), p->d_samples, tmp.size() * 4, hipMemcpyDeviceToHost));
+  memset(out, 0, size_t(need) * 4);
+  for (int lt = 0; lt < p->W.num_local_tiles; lt++) {
+    int tile = lt * p->W.shard_world + p->W.shard_rank;
+    int tx = tile % p->W.tiles_x, ty = tile / p->W.tiles_x;
+    for (int q = 0; q < 64; q++) {
+      int px = tx * kTile + (q & 7), py = ty * kTile + (q >> 3);
+      if (px >= p->film_w || py >= p->film_h) continue;
+      for (int s = 0; s < spp; s++)
+        memcpy(out + ((size_t(py) * p->film_w + px) * spp + s) * 4,
+               tmp.data() + ((size_t(lt) * spp + s) * 64 + q) * 4, 16);
+    }
+  }
+  return 0;
+}
+
+int pine_gpu_path_render(pine_gpu_scene* scene, const pine_gpu_render_params* prm, float* film_out) {
+  if (!scene || !prm || !film_out) {
+    set_error("null argument");
+    return -1;
+  }
+  pine_gpu_plan* p = pine_gpu_plan_create(scene, prm);
+  if (!p) return -1;
+  int rc = -1;
+  void* d_film = nullptr;
+  const size_t bytes = size_t(p->film_w) * p->film_h * 16;
+  do {
+    if (hipMalloc(&d_film, bytes) != hipSuccess) {
+      set_error("hipMalloc(film) failed");
+      break;
+    }
+    if (pine_gpu_plan_launch(p, d_film, nullptr)) break;
+    if (hipMemcpy(film_out, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      set_error("film download failed");
+      break;
+    }
+    g_progress.store(1.0f);
+    rc = 0;
+  } while (0);
+  std::string keep = rc ? pine_gpu_last_error() : "";
+  hipFree(d_film);
+  pine_gpu_plan_destroy(p);
+  if (rc) set_error(keep);
+  return rc;
+}
+
+// ---- device unit-test hooks -------------------------------------------------------------------
+static int need_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    set_error("no HIP device available");
+    return -1;
+  }
+  HIP_OK(hipSetDevice(device));
+  return 0;
+}
+int pine_gpu_test_sincos(int device, const float* x, int64_t n, float* s, float* c) {
+  if (need_device(device)) return -1;
+  float *dx, *ds, *dc;
+  HIP_OK(hipMalloc((void**)&dx, n * 4));
+  HIP_OK(hipMalloc((void**)&ds, n * 4));
+  HIP_OK(hipMalloc((void**)&dc, n * 4));
+  HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(test_sincos_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, 0, dx, (long long)n, ds, dc);
+  HIP_OK(hipMemcpy(s, ds, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(c, dc, n * 4, hipMemcpyDeviceToHost));
+  hipFree(dx);
+  hipFree(ds);
+  hipFree(dc);
+  return 0;
+}
+int pine_gpu_test_sampler(int device, int spp_req, float* out, int64_t capacity) {
+  if (need_device(device)) return -1;
+  if (load_tables()) return -1;
+  const int spp = effective_spp(spp_req);
+  const int64_t need = int64_t(6) * spp * (260 + 270);
+  if (capacity < need) {
+    set_error("capacity too small");
+    return -1;
+  }
+  int k = 0;
+  while ((1 << k) < spp) k++;
+  uint8_t* dt;
+  float* dout;
+  HIP_OK(hipMalloc((void**)&dt, 65536 + 262144));
+  HIP_OK(hipMemcpy(dt, g_tables.data(), 65536, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dt + 65536, g_tables.data() + 65536 + size_t(k) * 262144, 262144, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc((void**)&dout, need * 4));
+  DTables T{dt, dt + 65536, dt + 65536 + 131072};
+  hipLaunchKernelGGL(test_sampler_kernel, dim3(6), dim3(64), 0, 0, T, spp, dout);
+  HIP_OK(hipMemcpy(out, dout, need * 4, hipMemcpyDeviceToHost));
+  hipFree(dt);
+  hipFree(dout);
+  return 0;
+}
+int pine_gpu_test_rng(int device, uint64_t* out, int64_t capacity) {
+  if (need_device(device)) return -1;
+  if (capacity < 6 * 19) {
+    set_error("capacity too small");
+    return -1;
+  }
+  unsigned long long* d;
+  HIP_OK(hipMalloc((void**)&d, 6 * 19 * 8));
+  hipLaunchKernelGGL(test_rng_kernel, dim3(1), dim3(64), 0, 0, d);
+  HIP_OK(hipMemcpy(out, d, 6 * 19 * 8, hipMemcpyDeviceToHost));
+  hipFree(d);
+  return 0;
+}
+int pine_gpu_test_shapes(pine_gpu_scene* scene, int device, const float* rays, int64_t nrays, float* out,
+                         int64_t capacity) {
+  if (!scene || !rays || !out) {
+    set_error("null argument");
+    return -1;
+  }
+  if (need_device(device)) return -1;
+  SceneHost& H = scene_host(scene);
+  std::vector<DShape> shapes;
+  for (auto& g : H.geometries)
+    if (g.shape.kind != SHAPE_MESH) shapes.push_back(g.shape);
+  const int64_t need = int64_t(shapes.size()) * nrays * 11;
+  if (capacity < need) {
+    set_error("capacity too small");
+    return -1;
+  }
+  DShape* ds;
+  float *dr, *dout;
+  if (upload(ds, shapes)) return -1;
+  HIP_OK(hipMalloc((void**)&dr, nrays * 32));
+  HIP_OK(hipMemcpy(dr, rays, nrays * 32, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc((void**)&dout, std::max<int64_t>(need, 1) * 4));
+  const long long total = (long long)shapes.size() * nrays;
+  if (total > 0)
+    hipLaunchKernelGGL(test_shapes_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, 0, ds,
+                       int(shapes.size()), dr, (long long)nrays, dout);
+  HIP_OK(hipMemcpy(out, dout, need * 4, hipMemcpyDeviceToHost));
+  hipFree(ds);
+  hipFree(dr);
+  hipFree(dout);
+  return 0;
+}
+
+}  // extern "C"

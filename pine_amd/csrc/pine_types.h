@@ -1,0 +1,95 @@
+// pine_amd/csrc/pine_types.h -- plain-old-data records shared by the host scene builder and the
+// gfx950 kernels.  Layouts are chosen for the GPU: fixed-size 16-byte-aligned records that one lane
+// fetches with a few dwordx4 loads (from LDS when the scene is staged there, else L1/L2).
+//
+// Reference counterparts (paths relative to /root/reference/): Shape variants
+// src/pine/core/geometry.h:297-349, Material variants src/pine/core/material.h:112-131, BVH node
+// src/pine/impl/accel/bvh.h:14-30, ThinLenCamera src/pine/core/camera.h:12-30.
+#pragma once
+#include <stdint.h>
+
+namespace pine_gpu {
+
+enum ShapeKind : int {
+  SHAPE_RECT = 0,
+  SHAPE_AABB = 1,
+  SHAPE_OBB = 2,
+  SHAPE_SPHERE = 3,
+  SHAPE_DISK = 4,
+  SHAPE_CONE = 5,
+  SHAPE_MESH = 6,
+};
+
+// 128-byte shape record.  Field use per kind:
+//  RECT  : f[0..2] position, [3..5] ex, [6..8] ey, [9..11] n, [12] lx, [13] ly, [14..16] rx,
+//          [17..19] ry, [20] area (= lx*ly)
+//  AABB  : f[0..2] lower, [3..5] upper
+//  OBB   : f[0..2] lower, [3..5] upper, [6..17] m  (columns x,y,z,w; 3 rows each),
+//          [18..29] m_inv (same layout)
+//  SPHERE: f[0..2] c, [3] r
+//  DISK  : f[0..2] position, [3..5] n, [6..8] u, [9..11] v, [12] r, [13] area
+//  CONE  : f[0..2] apex p, [3..5] n, [6] r, [7] h, [8] A, [9] A2, [10] S, [11] area
+//  MESH  : i(0) first_tri, i(1) num_tri, i(2) bvh index, f[3] area (first triangle x count)
+struct alignas(16) DShape {
+  float f[30];
+  int kind;
+  int material;
+};
+static_assert(sizeof(DShape) == 128, "DShape must be 128 bytes");
+
+enum MaterialKind : int {
+  MAT_EMISSIVE = 0,
+  MAT_DIFFUSE = 1,
+  MAT_UBER = 2,
+  MAT_SUBSURFACE = 3,
+};
+
+// 48-byte material record (constant shading nodes folded to literals).
+struct alignas(16) DMaterial {
+  float color[3];  // albedo or emission
+  int kind;
+  float roughness, metallic, transmission, ior;
+  float sigma_s[3];
+  int pad;
+};
+static_assert(sizeof(DMaterial) == 48, "DMaterial must be 48 bytes");
+
+// 64-byte BVH node: the two child boxes live in the parent (as in pine's BVH) so one fetch decides
+// both children.  child[i] >= 0 with count[i] == 0: inner node index.  count[i] > 0: child i is a
+// leaf whose primitives are prim_index[child[i] .. child[i]+count[i]) (stored order = test order).
+struct alignas(16) DNode {
+  float lo0[3], hi0[3];
+  float lo1[3], hi1[3];
+  int child[2];
+  int count[2];
+};
+static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+
+// One BVH (top level or per mesh).  If root_count > 0 the root itself is a leaf
+// (bvh.cpp:331-334,396-399): test prim_index[root_start .. root_start+root_count) and stop.
+struct DBvh {
+  int root;        // inner root node index (valid when root_count == 0)
+  int root_start;  // leaf-root primitive range
+  int root_count;
+  int prim_base;   // added to primitive ids of this BVH (mesh: first triangle; top level: 0)
+};
+
+struct DCamera {
+  float position[3];
+  float c2w[9];  // columns x,y,z
+  float fov2d[2];
+  float len_radius, focus_distance;
+  int W, H;
+};
+
+// Fold-stack entry (SURVEY.md 8(d) "FoldEntry 32 B"): what a non-terminal path vertex must keep
+// until its child subtree has resolved, for the backward per-level clamp (path.cpp:114-121).
+struct FoldEntry {
+  float nee[3];  // direct lighting at this vertex
+  float f[3];    // bs.f
+  float cp;      // cosine / bs.pdf
+  float pdf;     // bs.pdf (for the MIS weight against the child's light_pdf)
+};
+static_assert(sizeof(FoldEntry) == 32, "FoldEntry must be 32 bytes");
+
+}  // namespace pine_gpu

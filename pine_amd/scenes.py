@@ -1,0 +1,133 @@
+"""The BASELINE.json scenes, built through the API mirror exactly as the .pine scripts build them.
+
+cbox: /root/reference/scenes/cbox.pine:4-21 (SURVEY.md 8(d) "Concrete inputs").
+"""
+import numpy as np
+
+from .api import (Scene, Diffuse, Emissive, Uber, Subsurface, Rect, Box, AABB, Sphere, Disk, Cone, Mesh,
+                  Film, Uncharted2, ThinLenCamera, translate, rotate_y, scale)
+
+CAMERAS = {
+    # name: (from, to, fov)
+    "committed": ([0, 0, 0], [0, 0, 1], 0.4),   # scenes/cbox.pine:21
+    "readme": ([0, 1, -4], [0, 1, 0], 0.25),    # README.md:32 / cbox.pine:20 (commented)
+}
+
+
+def cbox(size=(640, 640), camera="committed", boxes=True):
+    """scenes/cbox.pine; boxes=False gives the Rect-only variant (no order-dependent OBBs)."""
+    scene = Scene()
+    scene.add("floor", Diffuse([0.9, 0.9, 0.9]))
+    scene.add("blue", Diffuse([0.2, 0.5, 0.9]))
+    scene.add("red", Diffuse([0.9, 0.1, 0.05]))
+    scene.add("green", Diffuse([0.2, 0.9, 0.05]))
+
+    scene.add(Rect([0, 0, 1], [2, 0, 0], [0, 0, 2], True), "floor")
+    scene.add(Rect([0, 2, 1], [2, 0, 0], [0, 0, 2]), "floor")
+    scene.add(Rect([-1, 1, 1], [0, 0, 2], [0, 2, 0], True), "red")
+    scene.add(Rect([1, 1, 1], [0, 0, 2], [0, 2, 0]), "green")
+    scene.add(Rect([0, 1, 2], [2, 0, 0], [0, 2, 0], True), "blue")
+    if boxes:
+        scene.add(Box(AABB([0, 0, 0], [1, 1, 1]),
+                      translate([0.0, 0.0, 0.6]) * rotate_y(0.4) * scale([0.6, 0.6, 0.6])), "floor")
+        scene.add(Box(AABB([0, 0, 0], [1, 1, 1]),
+                      translate([-0.6, 0.0, 1.0]) * rotate_y(-0.4) * scale([0.6, 1.3, 0.6])), "floor")
+    # 600 * [1.0, 0.64, 0.185] in PRL is float32 arithmetic
+    le = (np.float32(600) * np.array([1.0, 0.64, 0.185], dtype=np.float32)).tolist()
+    scene.add(Rect([0.0, 1.9, 1], [0.1, 0, 0], [0, 0, 0.1]), Emissive(le))
+    frm, to, fov = CAMERAS[camera]
+    scene.set(ThinLenCamera(Film(list(size), Uncharted2()), frm, to, fov))
+    return scene
+
+
+def classic_cones(size=(720, 360), n=100, with_spheres=True):
+    """Config C4: scenes/classic.pine:4-18 materials/shapes with constant-node
+    materials, plus n x n procedurally placed cones Cone([x,0,z], Y, 0.05, 0.05)."""
+    scene = Scene()
+    scene.add("floor", Uber([0.5, 0.7, 1.0], 0.4))
+    scene.add("diffuse", Diffuse([0.8, 0.8, 0.8]))
+    scene.add("metal", Uber([1.0, 1.0, 1.0], 0.0, 1.0))
+    scene.add("glossy", Uber([0.98, 0.55, 0.02], 0.0, 0.0))
+    scene.add(Disk([0, 0, 0], [0, 1, 0], 100), "floor")
+    if with_spheres:
+        scene.add(Sphere([-3, 1, 0], 1), "metal")
+        scene.add(Sphere([0, 1, 0], 1), "diffuse")
+        scene.add(Sphere([3, 1, 0], 1), "glossy")
+    le = (np.array([1, 1, 1], dtype=np.float32) * np.float32(160)).tolist()
+    scene.add(Rect([-1, 3, -1], [1, 0, 0], [0, 0, 1]), Emissive(le))
+    half = np.float32(0.1) * np.float32(n) / np.float32(2)
+    for i in range(n):
+        for j in range(n):
+            x = float(np.float32(-half + np.float32(0.05)) + np.float32(0.1) * np.float32(i))
+            z = float(np.float32(-half + np.float32(0.05)) + np.float32(0.1) * np.float32(j))
+            scene.add(Cone([x, 0, z], [0, 1, 0], 0.05, 0.05), "diffuse")
+    scene.set(ThinLenCamera(Film(list(size)), [0, 4, -8], [0, 1, 0], 0.3))
+    return scene
+
+
+def icosphere(subdiv=3, radius=0.4, center=(0.0, 0.5, 1.0)):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    v = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    verts = (np.array(v) * radius + np.array(center)).astype(np.float32)
+    return verts, np.array(f, dtype=np.uint32)
+
+
+def sss(size=(640, 640), subdiv=3, camera="readme"):
+    """Config C5: Rect-only cbox room + one closed icosphere mesh (1280 triangles at
+    subdiv=3) with Subsurface([1,1,1], 0.0, [40,40,40]) + the cbox emissive Rect."""
+    scene = Scene()
+    scene.add("floor", Diffuse([0.9, 0.9, 0.9]))
+    scene.add("blue", Diffuse([0.2, 0.5, 0.9]))
+    scene.add("red", Diffuse([0.9, 0.1, 0.05]))
+    scene.add("green", Diffuse([0.2, 0.9, 0.05]))
+    scene.add("skin", Subsurface([1, 1, 1], 0.0, [40, 40, 40]))
+    scene.add(Rect([0, 0, 1], [2, 0, 0], [0, 0, 2], True), "floor")
+    scene.add(Rect([0, 2, 1], [2, 0, 0], [0, 0, 2]), "floor")
+    scene.add(Rect([-1, 1, 1], [0, 0, 2], [0, 2, 0], True), "red")
+    scene.add(Rect([1, 1, 1], [0, 0, 2], [0, 2, 0]), "green")
+    scene.add(Rect([0, 1, 2], [2, 0, 0], [0, 2, 0], True), "blue")
+    verts, faces = icosphere(subdiv)
+    scene.add(Mesh(verts, faces), "skin")
+    le = (np.float32(600) * np.array([1.0, 0.64, 0.185], dtype=np.float32)).tolist()
+    scene.add(Rect([0.0, 1.9, 1], [0.1, 0, 0], [0, 0, 0.1]), Emissive(le))
+    frm, to, fov = CAMERAS[camera]
+    scene.set(ThinLenCamera(Film(list(size), Uncharted2()), frm, to, fov))
+    return scene
+
+
+def shapes_zoo(size=(64, 64)):
+    """One of every supported analytic shape + materials: used by the per-shape parity fixtures."""
+    scene = Scene()
+    scene.add("d", Diffuse([0.8, 0.7, 0.6]))
+    scene.add("u", Uber([0.9, 0.6, 0.3], 0.3, 0.0, 0.0))
+    scene.add(Rect([0, 0, 1], [2, 0, 0], [0, 0, 2], True), "d")
+    scene.add(Box([-0.9, 0.0, 0.2], [-0.5, 0.5, 0.6]), "d")
+    scene.add(Box(AABB([0, 0, 0], [1, 1, 1]),
+                  translate([0.0, 0.0, 0.6]) * rotate_y(0.4) * scale([0.6, 0.6, 0.6])), "u")
+    scene.add(Sphere([0.5, 0.3, 1.2], 0.3), "u")
+    scene.add(Disk([0.0, 1.5, 1.0], [0.2, -1.0, 0.1], 0.4), "d")
+    scene.add(Cone([-0.3, 0.0, 1.4], [0, 1, 0], 0.2, 0.5), "d")
+    le = (np.float32(600) * np.array([1.0, 0.64, 0.185], dtype=np.float32)).tolist()
+    scene.add(Rect([0.0, 1.9, 1], [0.1, 0, 0], [0, 0, 0.1]), Emissive(le))
+    scene.set(ThinLenCamera(Film(list(size), Uncharted2()), [0, 1, -4], [0, 1, 0], 0.25))
+    return scene
