@@ -11,6 +11,22 @@
 
 namespace pine_gpu {
 
+// Kernel specialisation flags: the path kernel is compiled once per feature set actually present
+// in a scene (shape kinds, material kinds), so a Rect/Box + Diffuse scene (cbox) does not carry the
+// registers and code of cones, meshes, microfacet lobes or the BSSRDF walk.
+enum : unsigned {
+  F_AABB = 1u << 0,
+  F_OBB = 1u << 1,
+  F_SPHERE = 1u << 2,
+  F_DISK = 1u << 3,
+  F_CONE = 1u << 4,
+  F_MESH = 1u << 5,
+  F_UBER = 1u << 6,
+  F_SSS = 1u << 7,
+  F_LDS_SCENE = 1u << 8,  // scene records staged in LDS
+  F_ALL = 0xffu,
+};
+
 // ------------------------------------------------------------------------------------------------
 // hash + RNG (src/pine/core/rng.h:9-144) -- integer exact
 // ------------------------------------------------------------------------------------------------
@@ -296,6 +312,7 @@ PINE_HD bool cone_quadratic(const float* f, const DRay& ray, float& tmax, float&
   return true;
 }
 
+template <unsigned F = F_ALL>
 PINE_HD bool shape_hit(const DShape* S, const DRay& ray) {
   const float* f = S->f;
   switch (S->kind) {
@@ -303,23 +320,23 @@ PINE_HD bool shape_hit(const DShape* S, const DRay& ray) {
       float t;
       return rect_test(f, ray, t);
     }
-    case SHAPE_AABB: {  // AABB::hit(Ray) bbox.cpp:75-93
+    case SHAPE_AABB: if constexpr (!(F & F_AABB)) __builtin_unreachable(); else {  // AABB::hit(Ray) bbox.cpp:75-93
       float tmin = ray.tmin, tmax = ray.tmax;
       if (tmin > tmax) return false;
       return box_slabs(ld3(f), ld3(f + 3), ray.o, ray.d, tmin, tmax);
     }
-    case SHAPE_OBB: {  // OBB::hit bbox.cpp:145-149
+    case SHAPE_OBB: if constexpr (!(F & F_OBB)) __builtin_unreachable(); else {  // OBB::hit bbox.cpp:145-149
       f3 o, d;
       obb_local_ray(f, ray.o, ray.d, o, d);
       float tmin = ray.tmin, tmax = ray.tmax;
       if (tmin > tmax) return false;
       return box_slabs(ld3(f), ld3(f + 3), o, d, tmin, tmax);
     }
-    case SHAPE_SPHERE: {  // geometry.cpp:84-87
+    case SHAPE_SPHERE: if constexpr (!(F & F_SPHERE)) __builtin_unreachable(); else {  // geometry.cpp:84-87
       const float t = sphere_compute_t(ray.o, ray.d, ray.tmin, ld3(f), f[3]);
       return t > ray.tmin && t < ray.tmax;
     }
-    case SHAPE_DISK: {  // geometry.cpp:128-137
+    case SHAPE_DISK: if constexpr (!(F & F_DISK)) __builtin_unreachable(); else {  // geometry.cpp:128-137
       const f3 position = ld3(f), n = ld3(f + 3);
       const float denom = dot(ray.d, n);
       if (denom == 0.0f) return false;
@@ -330,7 +347,7 @@ PINE_HD bool shape_hit(const DShape* S, const DRay& ray) {
       if (length_squared(p) > sqr(f[12])) return false;
       return true;
     }
-    case SHAPE_CONE: {  // geometry.cpp:415-427
+    case SHAPE_CONE: if constexpr (!(F & F_CONE)) __builtin_unreachable(); else {  // geometry.cpp:415-427
       float tmax, side;
       return cone_quadratic(f, ray, tmax, side) && side <= 0;
     }
@@ -338,6 +355,7 @@ PINE_HD bool shape_hit(const DShape* S, const DRay& ray) {
   }
 }
 
+template <unsigned F = F_ALL>
 PINE_HD bool shape_intersect(const DShape* S, DRay& ray) {
   const float* f = S->f;
   switch (S->kind) {
@@ -347,13 +365,13 @@ PINE_HD bool shape_intersect(const DShape* S, DRay& ray) {
       ray.tmax = t;
       return true;
     }
-    case SHAPE_AABB: {  // bbox.cpp:112-121
+    case SHAPE_AABB: if constexpr (!(F & F_AABB)) __builtin_unreachable(); else {  // bbox.cpp:112-121
       float tmin = ray.tmin, tmax = ray.tmax;
       if (!box_slabs(ld3(f), ld3(f + 3), ray.o, ray.d, tmin, tmax)) return false;
       ray.tmax = tmin > ray.tmin ? tmin : tmax;
       return true;
     }
-    case SHAPE_OBB: {  // bbox.cpp:150-172: endpoints mapped back to world distances
+    case SHAPE_OBB: if constexpr (!(F & F_OBB)) __builtin_unreachable(); else {  // bbox.cpp:150-172: endpoints mapped back to world distances
       f3 o, d;
       obb_local_ray(f, ray.o, ray.d, o, d);
       float tmin = ray.tmin, tmax = ray.tmax;
@@ -366,13 +384,13 @@ PINE_HD bool shape_intersect(const DShape* S, DRay& ray) {
       ray.tmax = tmin > ray.tmin ? tmin : tmax;
       return true;
     }
-    case SHAPE_SPHERE: {  // geometry.cpp:88-93
+    case SHAPE_SPHERE: if constexpr (!(F & F_SPHERE)) __builtin_unreachable(); else {  // geometry.cpp:88-93
       const float t = sphere_compute_t(ray.o, ray.d, ray.tmin, ld3(f), f[3]);
       if (t < ray.tmin || t > ray.tmax) return false;
       ray.tmax = t;
       return true;
     }
-    case SHAPE_DISK: {  // geometry.cpp:138-148
+    case SHAPE_DISK: if constexpr (!(F & F_DISK)) __builtin_unreachable(); else {  // geometry.cpp:138-148
       const f3 position = ld3(f), n = ld3(f + 3);
       const float denom = dot(ray.d, n);
       if (denom == 0.0f) return false;
@@ -383,7 +401,7 @@ PINE_HD bool shape_intersect(const DShape* S, DRay& ray) {
       ray.tmax = t;
       return true;
     }
-    case SHAPE_CONE: {  // geometry.cpp:428-454
+    case SHAPE_CONE: if constexpr (!(F & F_CONE)) __builtin_unreachable(); else {  // geometry.cpp:428-454
       float tmax, side;
       if (cone_quadratic(f, ray, tmax, side) && side < 0) {
         ray.tmax = tmax;
@@ -406,6 +424,7 @@ PINE_HD void aabb_surface_info(f3 lo, f3 hi, f3 p, DSurface& it) {
   set(it.p, axis, pos ? get(hi, axis) : get(lo, axis));
 }
 
+template <unsigned F = F_ALL>
 PINE_HD void shape_surface_info(const DShape* S, f3 p, DSurface& it) {
   const float* f = S->f;
   it.uv = f2{0, 0};
@@ -420,15 +439,15 @@ PINE_HD void shape_surface_info(const DShape* S, f3 p, DSurface& it) {
       it.uv = f2{u, v} + f2{0.5f, 0.5f};
       break;
     }
-    case SHAPE_AABB: aabb_surface_info(ld3(f), ld3(f + 3), p, it); break;
-    case SHAPE_OBB: {  // bbox.cpp:173-177
+    case SHAPE_AABB: if constexpr (!(F & F_AABB)) __builtin_unreachable(); else { aabb_surface_info(ld3(f), ld3(f + 3), p, it); } break;
+    case SHAPE_OBB: if constexpr (!(F & F_OBB)) __builtin_unreachable(); else {  // bbox.cpp:173-177
       const m34 mi = ld34(f + 18);
       aabb_surface_info(ld3(f), ld3(f + 3), mul_point(mi, p), it);
       it.p = mul_point(ld34(f + 6), it.p);
       it.n = normalize(mul(transpose(linear(mi)), it.n));
       break;
     }
-    case SHAPE_SPHERE: {  // geometry.cpp:94-98
+    case SHAPE_SPHERE: if constexpr (!(F & F_SPHERE)) __builtin_unreachable(); else {  // geometry.cpp:94-98
       const f3 c = ld3(f);
       it.n = normalize(p - c);
       it.p = c + it.n * f[3];
@@ -438,7 +457,7 @@ PINE_HD void shape_surface_info(const DShape* S, f3 p, DSurface& it) {
       it.uv = f2{phi, acosf(it.n.z)};
       break;
     }
-    case SHAPE_DISK: {  // geometry.cpp:149-155
+    case SHAPE_DISK: if constexpr (!(F & F_DISK)) __builtin_unreachable(); else {  // geometry.cpp:149-155
       const f3 position = ld3(f), u = ld3(f + 6), v = ld3(f + 9);
       it.n = ld3(f + 3);
       const float ex = dot(p - position, u);
@@ -447,7 +466,7 @@ PINE_HD void shape_surface_info(const DShape* S, f3 p, DSurface& it) {
       it.p = position + ex * u + ey * v;
       break;
     }
-    case SHAPE_CONE: {  // geometry.cpp:455-460
+    case SHAPE_CONE: if constexpr (!(F & F_CONE)) __builtin_unreachable(); else {  // geometry.cpp:455-460
       const f3 apex = ld3(f), n = ld3(f + 3);
       const float l = length(p - apex) * f[8];
       const f3 x = apex - n * l;
@@ -521,6 +540,7 @@ PINE_HD bool tri_sample(const float* v, f3 p, f2 u, DShapeSample& ss) {  // Tria
   ss.pdf = sqr(ss.distance) / pmax(absdot(ss.w, ss.n) * area, kEpsilon);
   return true;
 }
+template <unsigned F = F_ALL>
 PINE_HD bool shape_sample(const DShape* S, const float* tri_verts, f3 o, f2 u, float u1, DShapeSample& ss) {
   const float* f = S->f;
   switch (S->kind) {
@@ -531,7 +551,7 @@ PINE_HD bool shape_sample(const DShape* S, const float* tri_verts, f3 o, f2 u, f
       ss.pdf = sqr(ss.distance) / (absdot(ss.w, ss.n) * f[20]);
       break;
     }
-    case SHAPE_SPHERE: {  // geometry.cpp:99-114
+    case SHAPE_SPHERE: if constexpr (!(F & F_SPHERE)) __builtin_unreachable(); else {  // geometry.cpp:99-114
       const f3 c = ld3(f);
       const float r = f[3];
       const float l = length(c - o);
@@ -549,7 +569,7 @@ PINE_HD bool shape_sample(const DShape* S, const float* tri_verts, f3 o, f2 u, f
       ss.n = (ss.p - c) / r;
       break;
     }
-    case SHAPE_DISK: {  // geometry.cpp:156-165
+    case SHAPE_DISK: if constexpr (!(F & F_DISK)) __builtin_unreachable(); else {  // geometry.cpp:156-165
       const f2 uv = sample_disk_concentric(u);
       const float r = f[12];
       ss.p = ld3(f) + r * ld3(f + 6) * uv.x + r * ld3(f + 9) * uv.y;
@@ -558,7 +578,7 @@ PINE_HD bool shape_sample(const DShape* S, const float* tri_verts, f3 o, f2 u, f
       ss.pdf = sqr(ss.distance) / pmax(absdot(ss.w, ss.n) * f[13], kEpsilon);
       break;
     }
-    case SHAPE_MESH: {  // Mesh::sample geometry.h:170-178
+    case SHAPE_MESH: if constexpr (!(F & F_MESH)) __builtin_unreachable(); else {  // Mesh::sample geometry.h:170-178
       const int first = as_int(f[0]), nt = as_int(f[1]);
       if (nt == 0) return false;
       const int ti = int(float(size_t(nt)) * u1);
@@ -571,19 +591,20 @@ PINE_HD bool shape_sample(const DShape* S, const float* tri_verts, f3 o, f2 u, f
   if (ss.pdf <= 0 || isinf(ss.pdf)) return false;
   return true;
 }
+template <unsigned F = F_ALL>
 PINE_HD float shape_pdf(const DShape* S, const DRay& ray, f3 ns) {
   const float* f = S->f;
   switch (S->kind) {
     case SHAPE_RECT: return sqr(ray.tmax) / f[20] * absdot(ns, ray.d);  // geometry.cpp:368-370 (quirk A4)
-    case SHAPE_SPHERE: {                                               // :115-120
+    case SHAPE_SPHERE: if constexpr (!(F & F_SPHERE)) __builtin_unreachable(); else {                                               // :115-120
       const float l = length(ld3(f) - ray.o);
       const float cos_theta = psqrt(1 - sqr(f[3] / l));
       const float Sa = 2 * kPi * (1 - cos_theta);
       return 1.0f / Sa;
     }
-    case SHAPE_DISK: return sqr(ray.tmax) / (f[13] * absdot(ns, ray.d));  // :166-168
-    case SHAPE_CONE: return sqr(ray.tmax) / f[11] * absdot(ns, ray.d);   // :462-464
-    case SHAPE_MESH: return sqr(ray.tmax) / (f[3] * absdot(ns, ray.d));  // geometry.h:180-182
+    case SHAPE_DISK: if constexpr (!(F & F_DISK)) __builtin_unreachable(); else { return sqr(ray.tmax) / (f[13] * absdot(ns, ray.d)); }  // :166-168
+    case SHAPE_CONE: if constexpr (!(F & F_CONE)) __builtin_unreachable(); else { return sqr(ray.tmax) / f[11] * absdot(ns, ray.d); }  // :462-464
+    case SHAPE_MESH: if constexpr (!(F & F_MESH)) __builtin_unreachable(); else { return sqr(ray.tmax) / (f[3] * absdot(ns, ray.d)); }  // geometry.h:180-182
     default: return 0.0f;
   }
 }
@@ -681,7 +702,9 @@ struct DBxdf {
   float roughness, ior;
   f3 wi;  // local frame
 };
+template <unsigned F = F_ALL>
 PINE_HD bool bxdf_is_delta(const DBxdf& b) {
+  if constexpr (!(F & (F_UBER | F_SSS))) return false;
   switch (b.kind) {
     case BX_DIFFUSE:
     case BX_DIFF_DIEL:
@@ -694,6 +717,7 @@ struct DBsdfSample {
   float pdf;
   bool is_delta;
 };
+template <unsigned F = F_ALL>
 PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DBsdfSample& bs) {
   const f3 wi = b.wi;
   bs.is_delta = false;
@@ -706,7 +730,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       bs.f = b.albedo / kPi;
       return true;
     }
-    case BX_CONDUCTOR: {  // bxdf.cpp:39-64
+    case BX_CONDUCTOR: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:39-64
       const float alpha = sqr(b.roughness);
       if (alpha < 1e-4f) {
         bs.wo = Reflect(wi);
@@ -725,7 +749,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       bs.f = fr * (tr_D_G(d, wo, wm, wi) / (4 * CosTheta(wi) * CosTheta(wo)));
       return true;
     }
-    case BX_REFRACTIVE: {  // bxdf.cpp:102-124
+    case BX_REFRACTIVE: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else {  // bxdf.cpp:102-124
       const float alpha = sqr(b.roughness);
       if (alpha < 1e-4f) {
         bs.wo = Reflect(wi);
@@ -743,7 +767,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       bs.f = b.albedo * (tr_D_G(d, wo, wm, wi) / (4 * CosTheta(wi) * CosTheta(wo)));
       return true;
     }
-    case BX_REFR_DIEL: {  // bxdf.cpp:162-208
+    case BX_REFR_DIEL: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:162-208
       const float fr = FrDielectric(CosTheta(wi), b.ior);
       const float alpha = sqr(b.roughness);
       if (alpha < 1e-4f) {
@@ -779,7 +803,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       }
       return true;
     }
-    case BX_DIFF_DIEL: {  // bxdf.cpp:250-287 (diffuse lobe is NOT flipped to wi's side, Appendix A5)
+    case BX_DIFF_DIEL: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:250-287 (diffuse lobe is NOT flipped to wi's side, Appendix A5)
       const float fr = FrDielectric(CosTheta(wi), b.ior);
       const float alpha = sqr(b.roughness);
       if (alpha < 1e-4f) {
@@ -810,7 +834,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       }
       return true;
     }
-    case BX_BSSRDF: {  // bxdf.cpp:356-367
+    case BX_BSSRDF: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else {  // bxdf.cpp:356-367
       f3 wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
       if (CosTheta(wi) > 0) wo = -wo;
       bs.wo = wo;
@@ -821,13 +845,14 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
   }
   return false;
 }
+template <unsigned F = F_ALL>
 PINE_HD f3 bxdf_f(const DBxdf& b, f3 wo) {
   const f3 wi = b.wi;
   switch (b.kind) {
     case BX_DIFFUSE:  // bxdf.cpp:24-28
       if (!SameHemisphere(wi, wo)) return mk3(0.0f);
       return b.albedo / kPi;
-    case BX_CONDUCTOR: {  // bxdf.cpp:65-79
+    case BX_CONDUCTOR: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:65-79
       if (!SameHemisphere(wi, wo)) return mk3(0.0f);
       const float alpha = sqr(b.roughness);
       const TRDist d{alpha, alpha};
@@ -836,7 +861,7 @@ PINE_HD f3 bxdf_f(const DBxdf& b, f3 wo) {
       const f3 fr = FrSchlick(b.albedo, absdot(wi, wm));
       return fr * (tr_D_G(d, wo, wm, wi) / (4 * AbsCosTheta(wo) * AbsCosTheta(wi)));
     }
-    case BX_REFRACTIVE: {  // bxdf.cpp:125-140
+    case BX_REFRACTIVE: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else {  // bxdf.cpp:125-140
       const float alpha = sqr(b.roughness);
       const TRDist d{alpha, alpha};
       const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
@@ -845,7 +870,7 @@ PINE_HD f3 bxdf_f(const DBxdf& b, f3 wo) {
       if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return mk3(0.0f);
       return b.albedo * (tr_D_G(d, wi, wm, wo) / pabs(4 * cosThetaI * cosThetaO));
     }
-    case BX_REFR_DIEL: {  // bxdf.cpp:209-230 (`auto eta = 1` is an int in the reference)
+    case BX_REFR_DIEL: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:209-230 (`auto eta = 1` is an int in the reference)
       const float alpha = sqr(b.roughness);
       const TRDist d{alpha, alpha};
       const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
@@ -859,7 +884,7 @@ PINE_HD f3 bxdf_f(const DBxdf& b, f3 wo) {
       const float denom = sqr(dot(wo, wm) + dot(wi, wm) / float(eta)) * cosThetaI * cosThetaO;
       return b.albedo * ((1 - fr) * tr_D(d, wm) * tr_G(d, wi, wo) * pabs(dot(wo, wm) * dot(wi, wm) / denom));
     }
-    case BX_DIFF_DIEL: {  // bxdf.cpp:288-306
+    case BX_DIFF_DIEL: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:288-306
       if (!SameHemisphere(wi, wo)) return mk3(0.0f);
       const float alpha = sqr(b.roughness);
       const TRDist d{alpha, alpha};
@@ -872,17 +897,18 @@ PINE_HD f3 bxdf_f(const DBxdf& b, f3 wo) {
       const float reflected = fr * tr_D_G(d, wo, wm, wi) / pabs(4 * cosThetaI * cosThetaO);
       return mk3(reflected) + diffused;
     }
-    case BX_BSSRDF: return b.albedo / kPi;  // bxdf.cpp:368-370
+    case BX_BSSRDF: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else { return b.albedo / kPi; }  // bxdf.cpp:368-370
   }
   return mk3(0.0f);
 }
+template <unsigned F = F_ALL>
 PINE_HD float bxdf_pdf(const DBxdf& b, f3 wo) {
   const f3 wi = b.wi;
   switch (b.kind) {
     case BX_DIFFUSE:  // bxdf.cpp:29-33
       if (!SameHemisphere(wi, wo)) return 0.0f;
       return AbsCosTheta(wo) / kPi;
-    case BX_CONDUCTOR: {  // bxdf.cpp:80-95
+    case BX_CONDUCTOR: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:80-95
       if (!SameHemisphere(wi, wo)) return 0.0f;
       const float alpha = sqr(b.roughness);
       const TRDist d{alpha, alpha};
@@ -891,7 +917,7 @@ PINE_HD float bxdf_pdf(const DBxdf& b, f3 wo) {
       wm = FaceNormal(wm);
       return tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
     }
-    case BX_REFRACTIVE: {  // bxdf.cpp:141-157
+    case BX_REFRACTIVE: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else {  // bxdf.cpp:141-157
       const float alpha = sqr(b.roughness);
       const TRDist d{alpha, alpha};
       const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
@@ -900,7 +926,7 @@ PINE_HD float bxdf_pdf(const DBxdf& b, f3 wo) {
       if (dot(wm, wo) * cosThetaO <= 0 || dot(wm, wi) * cosThetaI <= 0) return 0.0f;
       return tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
     }
-    case BX_REFR_DIEL: {  // bxdf.cpp:231-245
+    case BX_REFR_DIEL: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:231-245
       const float alpha = sqr(b.roughness);
       const TRDist d{alpha, alpha};
       const float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
@@ -915,7 +941,7 @@ PINE_HD float bxdf_pdf(const DBxdf& b, f3 wo) {
       const float dwm_dwo = absdot(wo, wm) / denom;
       return (1 - fr) * tr_pdf(d, wi, wm) * dwm_dwo;
     }
-    case BX_DIFF_DIEL: {  // bxdf.cpp:307-324
+    case BX_DIFF_DIEL: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:307-324
       if (!SameHemisphere(wi, wo)) return 0.0f;
       const float alpha = sqr(b.roughness);
       const TRDist d{alpha, alpha};
@@ -928,7 +954,7 @@ PINE_HD float bxdf_pdf(const DBxdf& b, f3 wo) {
       const float pr = fr * tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
       return pr + pt;
     }
-    case BX_BSSRDF: return AbsCosTheta(wo) / kPi;  // bxdf.cpp:371-373
+    case BX_BSSRDF: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else { return AbsCosTheta(wo) / kPi; }  // bxdf.cpp:371-373
   }
   return 0.0f;
 }

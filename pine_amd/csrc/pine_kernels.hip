@@ -38,6 +38,7 @@ SceneHost& scene_host(pine_gpu_scene* s);
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kTile = 8;         // 8x8 pixel tiles = 64 pixels = one wave's worth of items
+constexpr int kPoolItems = 128;  // items a wave claims from the global queue per atomic
 constexpr int kMaxDepth = 32;    // max_path_length supported (2 beta bits per level in one u64)
 
 struct DeviceScene {
@@ -56,6 +57,25 @@ struct DeviceScene {
   int max_path_length;
   int stack_top;        // traversal stack entries needed by the top-level BVH
   int stack_total;      // top + deepest mesh BVH
+  // the small scene records packed in one 16-byte-aligned blob (for LDS staging):
+  const uint4* blob;
+  int blob_bytes;
+  int off_nodes, off_shapes, off_materials, off_bvhs, off_prims, off_lights;  // byte offsets in the blob
+};
+
+// What the traversal and shading code reads.  In the F_LDS_SCENE specialisation every pointer is
+// derived from the workgroup's LDS copy of the blob (so the loads are ds_read, ~64-cycle latency,
+// instead of L1/L2 round trips); otherwise they point into HBM-backed global memory.
+struct SceneView {
+  const DShape* shapes;
+  const DMaterial* materials;
+  const DNode* nodes;
+  const int* prims;
+  const DBvh* bvhs;
+  const int* lights;
+  const float* tri_verts;
+  int stack_top;
+  int num_shapes;
 };
 
 struct WorkParams {
@@ -74,7 +94,7 @@ struct WorkParams {
 // lane-interleaved ([slot][thread]) so pushes/pops are bank-conflict free.
 // ------------------------------------------------------------------------------------------------
 template <bool ANY>
-__device__ __forceinline__ bool mesh_traverse(const DeviceScene& S, const DBvh bvh, DRay& ray,
+__device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh, DRay& ray,
                                               const DRayOct& oct, int* stack, int sp0, int& prim_out) {
   bool hit = false;
   auto leaf = [&](int start, int count) -> bool {
@@ -130,8 +150,8 @@ __device__ __forceinline__ bool mesh_traverse(const DeviceScene& S, const DBvh b
 
 // ANY: BVH::hit (bvh.cpp:497-511).  !ANY: BVH::intersect (bvh.cpp:513-548) minus the final
 // compute_surface_info, which the caller does once for the winning primitive.
-template <bool ANY>
-__device__ __forceinline__ bool scene_traverse(const DeviceScene& S, DRay& ray, int* stack, int& geom_out,
+template <bool ANY, unsigned F>
+__device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, int* stack, int& geom_out,
                                                int& prim_out) {
   if (S.num_shapes == 0) return false;
   const DRayOct oct = make_oct(ray);
@@ -141,20 +161,24 @@ __device__ __forceinline__ bool scene_traverse(const DeviceScene& S, DRay& ray, 
     for (int i = start; i < start + count; i++) {
       const int g = S.prims[i];
       const DShape* sh = &S.shapes[g];
-      if (sh->kind == SHAPE_MESH) {
-        const DBvh mb = S.bvhs[as_int(sh->f[2])];
-        int prim = 0;
-        const bool h = mesh_traverse<ANY>(S, mb, ray, oct, stack, S.stack_top, prim);
-        if (ANY) {
-          if (h) return true;
-        } else if (h) {
-          hit = true;
-          geom_out = g;
-          prim_out = prim;
+      bool is_mesh = false;
+      if constexpr (F & F_MESH) is_mesh = sh->kind == SHAPE_MESH;
+      if (is_mesh) {
+        if constexpr (F & F_MESH) {
+          const DBvh mb = S.bvhs[as_int(sh->f[2])];
+          int prim = 0;
+          const bool h = mesh_traverse<ANY>(S, mb, ray, oct, stack, S.stack_top, prim);
+          if (ANY) {
+            if (h) return true;
+          } else if (h) {
+            hit = true;
+            geom_out = g;
+            prim_out = prim;
+          }
         }
       } else if (ANY) {
-        if (shape_hit(sh, ray)) return true;
-      } else if (shape_intersect(sh, ray)) {
+        if (shape_hit<F>(sh, ray)) return true;
+      } else if (shape_intersect<F>(sh, ray)) {
         hit = true;
         geom_out = g;
       }
@@ -265,11 +289,37 @@ __device__ __forceinline__ f3 material_le(const DMaterial* m, f3 n, f3 wo) {  //
   return ld3(m->color);
 }
 
-__global__ void __launch_bounds__(kBlock)
+template <unsigned F, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(kBlock, WAVES_PER_SIMD)
 path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, Counters* __restrict__ counters) {
-  extern __shared__ int lds_stack[];
-  int* stack = lds_stack + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  int* stack = lds_raw + threadIdx.x;
+  SceneView V;
+  V.tri_verts = S.tri_verts;
+  V.stack_top = S.stack_top;
+  V.num_shapes = S.num_shapes;
+  if constexpr (F & F_LDS_SCENE) {
+    // stage the scene blob behind the traversal stack (stack_total * 1 KiB keeps 16-byte alignment)
+    uint4* dst = reinterpret_cast<uint4*>(lds_raw + S.stack_total * kBlock);
+    const int n16 = S.blob_bytes >> 4;
+    for (int i = threadIdx.x; i < n16; i += kBlock) dst[i] = S.blob[i];
+    __syncthreads();
+    const char* base = reinterpret_cast<const char*>(dst);
+    V.nodes = reinterpret_cast<const DNode*>(base + S.off_nodes);
+    V.shapes = reinterpret_cast<const DShape*>(base + S.off_shapes);
+    V.materials = reinterpret_cast<const DMaterial*>(base + S.off_materials);
+    V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
+    V.prims = reinterpret_cast<const int*>(base + S.off_prims);
+    V.lights = reinterpret_cast<const int*>(base + S.off_lights);
+  } else {
+    V.nodes = S.nodes;
+    V.shapes = S.shapes;
+    V.materials = S.materials;
+    V.bvhs = S.bvhs;
+    V.prims = S.prims;
+    V.lights = S.lights;
+  }
   const unsigned lane_slot = blockIdx.x * kBlock + threadIdx.x;
   const unsigned fold_stride = gridDim.x * kBlock;
   auto fold_at = [&](int level, int field) -> float& {
@@ -294,17 +344,49 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   unsigned long long beta_flags = 0;  // 2 bits per level: 0 = beta (1,1,1); 1..3 = beta 3 on channel-1 (BSSRDF)
   unsigned vcount = 0;      // radiance() invocations of the current sample
   unsigned long long shadow_count = 0, vertex_count = 0;
+  // wave-uniform private item pool [pool_next, pool_end)
+  unsigned long long pool_next = 0, pool_end = 0;
+  bool queue_empty = false;
 
   while (true) {
     // ---------------- regeneration ----------------
-    if (!alive && !lane_done) {
-      if (!(have_item && s_cur < s_end)) {
-        have_item = false;
-        // pull one item; hipcc turns the per-lane atomicAdd into one wave-aggregated atomic
-        const unsigned long long item = atomicAdd(&counters->next_item, 1ull);
-        if (item >= W.total_items) {
-          lane_done = true;
-        } else {
+    // Lanes whose item is exhausted take the next items of the wave's private pool (a range of
+    // kPoolItems consecutive items claimed from the global queue with ONE atomic by one lane);
+    // ranks inside the wave come from a ballot prefix count, so there is no per-lane atomic.
+    // (A per-iteration wave-aggregated atomic on one word saturates at ~90 M dequeues/s chip-wide,
+    // MI355X_MICROARCH.md "dequeue" -- that was the first bottleneck measured.)
+    {
+      bool need_item = !alive && !lane_done && !(have_item && s_cur < s_end);
+      while (true) {
+        const unsigned long long mask = __ballot(need_item);
+        if (mask == 0) break;
+        if (pool_next == pool_end) {
+          if (queue_empty) {
+            if (need_item) {
+              lane_done = true;
+              have_item = false;
+            }
+            break;
+          }
+          unsigned long long base = 0;
+          if ((threadIdx.x & 63) == 0) base = atomicAdd(&counters->next_item, (unsigned long long)kPoolItems);
+          base = __shfl(base, 0);
+          if (base >= W.total_items) {
+            queue_empty = true;
+          } else {
+            pool_next = base;
+            pool_end = base + kPoolItems < W.total_items ? base + kPoolItems : W.total_items;
+          }
+          continue;
+        }
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long avail = pool_end - pool_next;
+        const unsigned want = __popcll(mask);
+        const unsigned take = want < avail ? want : unsigned(avail);
+        if (need_item && rank < take) {
+          const unsigned long long item = pool_next + rank;
+          need_item = false;
           const ItemInfo it = decode_item(W, S.cam.W, S.cam.H, S.spp, item);
           if (it.valid) {
             have_item = true;
@@ -319,10 +401,13 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               const ulonglong2 c = ckpt[item];
               sampler.rng = DRng{c.x, c.y};
             }
+          } else {
+            have_item = false;  // pixel outside the film (partial border tile): ask again next trip
           }
         }
+        pool_next += take;
       }
-      if (have_item && s_cur < s_end) {
+      if (!alive && !lane_done && have_item && s_cur < s_end) {
         // start sample s_cur: BlueSobolSampler index = s, dimension = 0 (sampler.h:174-181)
         sampler.index = s_cur;
         sampler.dimension = 0;
@@ -348,7 +433,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     vcount++;
     const f3 wi = -ray.d;
     int geom = -1, prim = 0;
-    const bool hit = scene_traverse<false>(S, ray, stack, geom, prim);
+    const bool hit = scene_traverse<false, F>(V, ray, stack, geom, prim);
 
     // terminal result of this vertex, if it terminates
     bool terminal = false;
@@ -364,16 +449,18 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if (!hit) {
       terminal = true;  // no environment light (path.cpp:75-81)
     } else {
-      shape = &S.shapes[geom];
-      mat = &S.materials[shape->material];
+      shape = &V.shapes[geom];
+      mat = &V.materials[shape->material];
       const f3 ph = ray_at(ray, ray.tmax);
-      if (shape->kind == SHAPE_MESH) tri_surface_info(S.tri_verts + size_t(prim) * 9, ph, it);
-      else shape_surface_info(shape, ph, it);
+      bool on_mesh = false;
+      if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
+      if (on_mesh) tri_surface_info(V.tri_verts + size_t(prim) * 9, ph, it);
+      else shape_surface_info<F>(shape, ph, it);
       if (mat->kind == MAT_EMISSIVE) {  // path.cpp:83-87
         Lo = mk3(1.0f) * material_le(mat, it.n, wi);
         if (!pv_is_delta) {
           has_light_pdf = true;
-          light_pdf = shape_pdf(shape, ray, it.n) / float(size_t(S.num_lights));  // lightsampler.cpp:27-29
+          light_pdf = shape_pdf<F>(shape, ray, it.n) / float(size_t(S.num_lights));  // lightsampler.cpp:27-29
         }
         terminal = true;
       } else if (pv_length + 1 >= S.max_path_length) {  // path.cpp:89
@@ -392,7 +479,10 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       bx.albedo = ld3(mat->color);
       bx.roughness = 0.0f;
       bx.ior = 1.0f;
-      if (mat->kind == MAT_UBER) {
+      bool is_uber = false, is_sss = false;
+      if constexpr (F & F_UBER) is_uber = mat->kind == MAT_UBER;
+      if constexpr (F & F_SSS) is_sss = mat->kind == MAT_SUBSURFACE;
+      if (is_uber) {
         if (with_probability(mat->metallic, sampler)) {
           bx.kind = BX_CONDUCTOR;
           bx.roughness = mat->roughness;
@@ -405,7 +495,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           bx.roughness = mat->roughness;
           bx.ior = mat->ior;
         }
-      } else if (mat->kind == MAT_SUBSURFACE) {
+      } else if (is_sss) {
         const float fr = FrDielectric(dot(wi, it.n), mat->ior);
         if (sampler_get1d(S.tables, sampler) < fr) {
           bx.kind = BX_REFRACTIVE;
@@ -422,7 +512,9 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
       // ---- BSSRDF random walk inside the same shape (bxdf.cpp:329-353, :375-382) ----
       int beta_channel = 0;
-      if (bx.kind == BX_BSSRDF) {
+      bool do_walk = false;
+      if constexpr (F & F_SSS) do_walk = bx.kind == BX_BSSRDF;
+      if (do_walk) {
         f3 p = it.p;
         f3 w = -wi;
         if (Refract(wi, it.n, bx.ior, w, nullptr)) {
@@ -434,13 +526,15 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             DSurface sit;
             sit.p = sit.n = mk3(0.0f);  // non-mesh shapes leave them zero (Appendix A5)
             bool h;
-            if (shape->kind == SHAPE_MESH) {
+            bool walk_mesh = false;
+            if constexpr (F & F_MESH) walk_mesh = shape->kind == SHAPE_MESH;
+            if (walk_mesh) {
               const DRayOct oct = make_oct(wr);
               int wprim = 0;
-              h = mesh_traverse<false>(S, S.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
-              if (h) tri_surface_info(S.tri_verts + size_t(wprim) * 9, ray_at(wr, wr.tmax), sit);
+              h = mesh_traverse<false>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
+              if (h) tri_surface_info(V.tri_verts + size_t(wprim) * 9, ray_at(wr, wr.tmax), sit);
             } else {
-              h = shape_intersect(shape, wr);
+              h = shape_intersect<F>(shape, wr);
             }
             if (!h) break;  // sample_p returns nullopt: nothing changes
             const float t = -logf(1 - sampler_get1d(S.tables, sampler)) * sigma_t_inv;
@@ -461,28 +555,28 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
       // ---- next-event estimation (path.cpp:98-113) ----
       f3 nee = mk3(0.0f);
-      if (!bxdf_is_delta(bx)) {
+      if (!bxdf_is_delta<F>(bx)) {
         // g++ order for LightSampler::sample's arguments (lightsampler.h:27): get2d, then get1d
         const f2 u2 = sampler_get2d(S.tables, sampler);
         float u1 = sampler_get1d(S.tables, sampler);
         if (S.num_lights > 0) {  // UniformLightSampler::sample lightsampler.cpp:12-26
           u1 *= float(S.num_lights);
           const int index = int(u1);
-          const DShape* lshape = &S.shapes[S.lights[index]];
+          const DShape* lshape = &V.shapes[V.lights[index]];
           DShapeSample gs;
-          if (shape_sample(lshape, S.tri_verts, it.p, u2, u1 - float(index), gs)) {
+          if (shape_sample<F>(lshape, V.tri_verts, it.p, u2, u1 - float(index), gs)) {
             // AreaLight::sample light.cpp:55-69
-            const f3 le = material_le(&S.materials[lshape->material], gs.n, -gs.w);
+            const f3 le = material_le(&V.materials[lshape->material], gs.n, -gs.w);
             if (!is_zero(le)) {
               const float ls_pdf = gs.pdf / float(S.num_lights);
               shadow_count++;
               DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
               int g2, p2;
-              if (!scene_traverse<true>(S, sr, stack, g2, p2)) {
+              if (!scene_traverse<true, F>(V, sr, stack, g2, p2)) {
                 const float cosine = absdot(gs.w, it.n);
                 const f3 wo = mul(w2l, gs.w);
-                const f3 f = bxdf_f(bx, wo);
-                const float mis = balance_heuristic(ls_pdf, bxdf_pdf(bx, wo));
+                const f3 f = bxdf_f<F>(bx, wo);
+                const float mis = balance_heuristic(ls_pdf, bxdf_pdf<F>(bx, wo));
                 nee = mk3(0.0f) + le * mk3(1.0f) * cosine * f / ls_pdf * mis;
               }
             }
@@ -492,7 +586,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
       // ---- BSDF sampling + continuation (path.cpp:114-120) ----
       DBsdfSample bs;
-      if (bxdf_sample(bx, S.tables, sampler, bs)) {
+      if (bxdf_sample<F>(bx, S.tables, sampler, bs)) {
         const f3 wo_world = mul(l2w, bs.wo);
         const float cosine = absdot(wo_world, it.n);
         const int level = pv_length;
@@ -558,6 +652,24 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     atomicAdd(&counters->shadow_rays, shadow_count);
   }
 }
+
+// Compiled specialisations, most specific first.
+using PathKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, Counters*);
+struct KernelVariant {
+  unsigned features;
+  PathKernelFn fn;
+  const char* name;
+};
+constexpr unsigned kFBoxes = F_AABB | F_OBB;
+constexpr unsigned kFAnalytic = F_AABB | F_OBB | F_SPHERE | F_DISK | F_CONE | F_UBER;
+static const KernelVariant kVariants[] = {
+    {kFBoxes | F_LDS_SCENE, path_trace_kernel<kFBoxes | F_LDS_SCENE, 4>, "rect+box/diffuse, scene in LDS"},
+    {kFAnalytic | F_LDS_SCENE, path_trace_kernel<kFAnalytic | F_LDS_SCENE, 2>, "analytic shapes/uber, scene in LDS"},
+    {kFAnalytic, path_trace_kernel<kFAnalytic, 2>, "analytic shapes/uber"},
+    {F_ALL | F_LDS_SCENE, path_trace_kernel<F_ALL | F_LDS_SCENE, 2>, "all features, scene in LDS"},
+    {F_ALL, path_trace_kernel<F_ALL, 2>, "all features"},
+};
+constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 
 // Ordered per-pixel sum: film[p] = (sum_{s=0..spp-1, in order} L_s) / spp  (path.cpp:34-38).
 // One wave per tile, lane = pixel in tile: every sample row is one coalesced 1 KiB read.
@@ -735,14 +847,10 @@ struct pine_gpu_plan {
   WorkParams W{};
   int film_w = 0, film_h = 0;
   // device buffers
-  DShape* d_shapes = nullptr;
-  DMaterial* d_materials = nullptr;
-  DNode* d_nodes = nullptr;
-  int* d_prims = nullptr;
-  DBvh* d_bvhs = nullptr;
+  char* d_blob = nullptr;  // nodes | shapes | materials | bvhs | prims | lights
   float* d_tri = nullptr;
-  int* d_lights = nullptr;
   uint8_t* d_tables = nullptr;
+  int variant = -1;
   ulonglong2* d_ckpt = nullptr;
   float4* d_samples = nullptr;
   float* d_fold = nullptr;
@@ -774,20 +882,15 @@ int pine_gpu_set_table_path(const char* path) {
 void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
-  hipFree(p->d_shapes);
-  hipFree(p->d_materials);
-  hipFree(p->d_nodes);
-  hipFree(p->d_prims);
-  hipFree(p->d_bvhs);
-  hipFree(p->d_tri);
-  hipFree(p->d_lights);
-  hipFree(p->d_tables);
-  hipFree(p->d_ckpt);
-  hipFree(p->d_samples);
-  hipFree(p->d_fold);
-  hipFree(p->d_counters);
+  (void)hipFree(p->d_blob);
+  (void)hipFree(p->d_tri);
+  (void)hipFree(p->d_tables);
+  (void)hipFree(p->d_ckpt);
+  (void)hipFree(p->d_samples);
+  (void)hipFree(p->d_fold);
+  (void)hipFree(p->d_counters);
   for (auto& e : p->ev)
-    if (e) hipEventDestroy(e);
+    if (e) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -828,13 +931,26 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
 
   std::vector<DShape> shapes;
   for (auto& g : H.geometries) shapes.push_back(g.shape);
-  if (upload(p->d_shapes, shapes)) return -1;
-  if (upload(p->d_materials, H.materials)) return -1;
-  if (upload(p->d_nodes, A.nodes)) return -1;
-  if (upload(p->d_prims, A.prims)) return -1;
-  if (upload(p->d_bvhs, A.bvhs)) return -1;
+  // one blob for the small records (16-byte aligned sections), so a workgroup can stage it in LDS
+  std::vector<char> blob;
+  auto put = [&](const void* src, size_t bytes) {
+    size_t off = (blob.size() + 15) & ~size_t(15);
+    blob.resize(off + std::max<size_t>(bytes, 16));
+    if (bytes) memcpy(blob.data() + off, src, bytes);
+    return int(off);
+  };
+  DeviceScene& S = p->S;
+  S.off_nodes = put(A.nodes.data(), A.nodes.size() * sizeof(DNode));
+  S.off_shapes = put(shapes.data(), shapes.size() * sizeof(DShape));
+  S.off_materials = put(H.materials.data(), H.materials.size() * sizeof(DMaterial));
+  S.off_bvhs = put(A.bvhs.data(), A.bvhs.size() * sizeof(DBvh));
+  S.off_prims = put(A.prims.data(), A.prims.size() * sizeof(int));
+  S.off_lights = put(H.lights.data(), H.lights.size() * sizeof(int));
+  blob.resize((blob.size() + 15) & ~size_t(15));
+  S.blob_bytes = int(blob.size());
+  HIP_OK(hipMalloc((void**)&p->d_blob, blob.size()));
+  HIP_OK(hipMemcpy(p->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (upload(p->d_tri, A.tri_verts)) return -1;
-  if (upload(p->d_lights, H.lights)) return -1;
   // tables: sobol + the selected spp variant
   int k = 0;
   while ((1 << k) < spp) k++;
@@ -842,14 +958,14 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   HIP_OK(hipMemcpy(p->d_tables, g_tables.data(), 65536, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(p->d_tables + 65536, g_tables.data() + 65536 + size_t(k) * 262144, 262144, hipMemcpyHostToDevice));
 
-  DeviceScene& S = p->S;
-  S.shapes = p->d_shapes;
-  S.materials = p->d_materials;
-  S.nodes = p->d_nodes;
-  S.prims = p->d_prims;
-  S.bvhs = p->d_bvhs;
+  S.blob = reinterpret_cast<const uint4*>(p->d_blob);
+  S.nodes = reinterpret_cast<const DNode*>(p->d_blob + S.off_nodes);
+  S.shapes = reinterpret_cast<const DShape*>(p->d_blob + S.off_shapes);
+  S.materials = reinterpret_cast<const DMaterial*>(p->d_blob + S.off_materials);
+  S.bvhs = reinterpret_cast<const DBvh*>(p->d_blob + S.off_bvhs);
+  S.prims = reinterpret_cast<const int*>(p->d_blob + S.off_prims);
+  S.lights = reinterpret_cast<const int*>(p->d_blob + S.off_lights);
   S.tri_verts = p->d_tri;
-  S.lights = p->d_lights;
   S.num_lights = int(H.lights.size());
   S.num_shapes = int(shapes.size());
   S.cam = H.camera;
@@ -868,10 +984,41 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.stack_top = d_top;
   S.stack_total = std::max(1, d_top + d_mesh);
   p->lds_bytes = size_t(S.stack_total) * kBlock * sizeof(int);
-  if (p->lds_bytes > 160 * 1024) {
+  if (p->lds_bytes > 64 * 1024) {
     set_error("BVH too deep for the LDS traversal stack");
     return -1;
   }
+  // kernel specialisation: the smallest compiled feature set that covers the scene
+  unsigned need = 0;
+  for (auto& sh : shapes) {
+    switch (sh.kind) {
+      case SHAPE_AABB: need |= F_AABB; break;
+      case SHAPE_OBB: need |= F_OBB; break;
+      case SHAPE_SPHERE: need |= F_SPHERE; break;
+      case SHAPE_DISK: need |= F_DISK; break;
+      case SHAPE_CONE: need |= F_CONE; break;
+      case SHAPE_MESH: need |= F_MESH; break;
+      default: break;
+    }
+  }
+  for (auto& m : H.materials) {
+    if (m.kind == MAT_UBER) need |= F_UBER;
+    if (m.kind == MAT_SUBSURFACE) need |= F_SSS;
+  }
+  const bool lds_ok = size_t(S.blob_bytes) <= 32 * 1024 && getenv("PINE_GPU_NO_LDS_SCENE") == nullptr;
+  p->variant = -1;
+  for (int v = 0; v < kNumVariants; v++) {
+    const unsigned F = kVariants[v].features;
+    if ((F & need) != need) continue;
+    if (((F & F_LDS_SCENE) != 0) != lds_ok) continue;
+    p->variant = v;
+    break;
+  }
+  if (p->variant < 0) {
+    set_error("no kernel variant covers this scene");
+    return -1;
+  }
+  if (kVariants[p->variant].features & F_LDS_SCENE) p->lds_bytes += size_t(S.blob_bytes);
 
   // scenes whose materials draw from the per-pixel RNG inside radiance() (Uber with fractional
   // metallic/transmission: sampler.h:317-324; BSSRDF channel pick: bxdf.cpp:335) make a pixel's
@@ -907,9 +1054,9 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));
   int blocks_per_cu = 0;
-  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, path_trace_kernel, kBlock, p->lds_bytes));
+  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)kVariants[p->variant].fn, kBlock, p->lds_bytes));
   if (blocks_per_cu < 1) blocks_per_cu = 1;
-  if (blocks_per_cu > 4) blocks_per_cu = 4;
+  if (blocks_per_cu > 8) blocks_per_cu = 8;
   const char* env_bpc = getenv("PINE_GPU_BLOCKS_PER_CU");
   if (env_bpc && atoi(env_bpc) > 0) blocks_per_cu = atoi(env_bpc);
   unsigned long long want = (W.total_items + kBlock - 1) / kBlock;
@@ -959,8 +1106,8 @@ int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_) {
                        p->W, p->film_w, p->film_h, p->S.spp, p->d_ckpt);
   }
   if (p->timed) HIP_OK(hipEventRecord(p->ev[1], stream));
-  hipLaunchKernelGGL(path_trace_kernel, dim3(p->grid), dim3(kBlock), p->lds_bytes, stream, p->S, p->W, p->d_ckpt,
-                     p->d_samples, p->d_fold, p->d_counters);
+  hipLaunchKernelGGL(kVariants[p->variant].fn, dim3(p->grid), dim3(kBlock), p->lds_bytes, stream, p->S, p->W,
+                     (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_counters);
   if (p->timed) HIP_OK(hipEventRecord(p->ev[2], stream));
   {
     const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
