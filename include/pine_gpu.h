@@ -157,6 +157,10 @@ typedef struct {
 /* Blocks until the last launch has finished (needed to read the device-side counters). */
 int pine_gpu_plan_stats_get(pine_gpu_plan*, pine_gpu_plan_stats* out);
 
+/* Diagnostic builds only (-DPINE_PROFILE_SECTIONS): per-section wave-cycle sums of the last launch
+ * (all zeros in the product build). */
+int pine_gpu_plan_debug_sections(pine_gpu_plan*, uint64_t out[16]);
+
 /* Per-sample radiance of the last launch: copies spp_eff*W*H float4 (r,g,b,vertices) to host,
  * layout [(y*W+x)*spp + s].  Test/debug aid. */
 int pine_gpu_plan_read_samples(pine_gpu_plan*, float* out_host, int64_t capacity_floats);

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpine_gpu.so")
+LIB_PATH = os.environ.get("PINE_GPU_LIB") or os.path.join(_HERE, "lib", "libpine_gpu.so")
 TABLE_PATH = os.path.join(_HERE, "data", "bluesobol_u8.bin")
 
 if not os.path.exists(LIB_PATH):
@@ -93,6 +93,7 @@ SIGNATURES = {
     "pine_gpu_plan_destroy": (None, [C.c_void_p]),
     "pine_gpu_plan_stats_get": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "pine_gpu_plan_read_samples": (C.c_int, [C.c_void_p, c_f_p, C.c_int64]),
+    "pine_gpu_plan_debug_sections": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "pine_gpu_test_sampler": (C.c_int, [C.c_int, C.c_int, c_f_p, C.c_int64]),
     "pine_gpu_test_rng": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.c_int64]),
     "pine_gpu_test_sincos": (C.c_int, [C.c_int, c_f_p, C.c_int64, c_f_p, c_f_p]),

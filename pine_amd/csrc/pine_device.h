@@ -85,17 +85,43 @@ PINE_HD float rng_nextf(DRng& g) {  // rng.h:132-135
 // ------------------------------------------------------------------------------------------------
 // BlueSobolSampler (src/pine/core/sampler.h:166-201, src/contrib/bluesobol/bluenoise_*spp.cpp:14-34)
 // ------------------------------------------------------------------------------------------------
+constexpr int kLdsSamplerDims = 40;     // sampler dimensions served from the LDS cache
+constexpr int kLdsTileDwords = 12;      // per lane: 10 dwords of rank bytes (dims 0..39) + 2 of scramble bytes
+constexpr int kLdsLaneStride = 256;     // = workgroup size: per-lane LDS slices are [dword][lane]
+
 struct DTables {
-  const uint8_t* sobol;     // [256*256]
+  const uint8_t* sobol;     // [256 dims][256 samples]: TRANSPOSED relative to the published table
   const uint8_t* scramble;  // [128*128*8] of the selected spp variant
-  const uint8_t* rank;      // [128*128*8]
+  const uint8_t* rank;      // [128*128*8] (+64 bytes of wrap-around padding on the device)
+  // Optional workgroup-local cache (LDS): the first kLdsSamplerDims rows of the transposed Sobol
+  // table, and for THIS lane's current pixel the 40 ranking bytes + 8 scrambling bytes the
+  // lookup needs (refreshed whenever the lane takes a new work item).
+  const uint8_t* lds_sobol;
+  const uint32_t* lds_tile;  // lane slice: dword j at lds_tile[j * kLdsLaneStride]
 };
+// value = sobol[dim + (index ^ rank[(dim + pix*8) % N]) * 256] ^ scramble[dim % 8 + pix*8]
+// (bluenoise_*spp.cpp:14-34); LDS = true reads dims < kLdsSamplerDims from the workgroup cache.
+template <bool LDS = false>
 PINE_HD float blue_sample_dimension(const DTables& t, int px, int py, int index, int dim) {
-  const int pix = (px & 127) + (py & 127) * 128;
+#ifdef PINE_ABL_SAMPLER  /* experiment builds only: no table loads (wrong values, timing only) */
+  return (0.5f + float((px * 7 + py * 31 + dim * 13 + index * 3) & 255)) / 256.0f;
+#endif
   const int si = index & 255;
   const int sd = dim & 255;
+  if constexpr (LDS) {
+    if (sd < kLdsSamplerDims) {
+      const unsigned sh = 8u * unsigned(sd & 3);
+      const uint32_t rw = t.lds_tile[(sd >> 2) * kLdsLaneStride];
+      const int ranked = si ^ int((rw >> sh) & 255u);
+      int value = t.lds_sobol[sd * 256 + ranked];
+      const uint32_t sw = t.lds_tile[(10 + ((sd & 7) >> 2)) * kLdsLaneStride];
+      value = value ^ int((sw >> sh) & 255u);
+      return (0.5f + float(value)) / 256.0f;
+    }
+  }
+  const int pix = (px & 127) + (py & 127) * 128;
   const int ranked = si ^ int(t.rank[(sd + pix * 8) % (128 * 128 * 8)]);
-  int value = t.sobol[sd + ranked * 256];
+  int value = t.sobol[sd * 256 + ranked];  // = sobol_256spp_256d[sd + ranked*256]
   value = value ^ int(t.scramble[(sd % 8) + pix * 8]);
   return (0.5f + float(value)) / 256.0f;
 }
@@ -105,16 +131,18 @@ struct DSampler {
   int dimension;  // BlueSobolSampler::dimension
   DRng rng;
 };
+template <bool LDS = false>
 PINE_HD float sampler_get1d(const DTables& t, DSampler& s) {  // sampler.h:183-187
   if (s.dimension >= 256) s.dimension = 2;
-  return blue_sample_dimension(t, s.px, s.py, s.index, s.dimension++);
+  return blue_sample_dimension<LDS>(t, s.px, s.py, s.index, s.dimension++);
 }
+template <bool LDS = false>
 PINE_HD f2 sampler_get2d(const DTables& t, DSampler& s) {  // sampler.h:188-194
   if (s.dimension + 1 >= 256) s.dimension = 2;
   const int dim = s.dimension;
   s.dimension += 2;
-  const float a = blue_sample_dimension(t, s.px, s.py, s.index, dim);
-  const float b = blue_sample_dimension(t, s.px, s.py, s.index, dim + 1);
+  const float a = blue_sample_dimension<LDS>(t, s.px, s.py, s.index, dim);
+  const float b = blue_sample_dimension<LDS>(t, s.px, s.py, s.index, dim + 1);
   return f2{a, b};
 }
 // with_probability (sampler.h:317-324): consumes an RNG float only for prob strictly in (0,1)
@@ -717,13 +745,13 @@ struct DBsdfSample {
   float pdf;
   bool is_delta;
 };
-template <unsigned F = F_ALL>
+template <unsigned F = F_ALL, bool LDS = false>
 PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DBsdfSample& bs) {
   const f3 wi = b.wi;
   bs.is_delta = false;
   switch (b.kind) {
     case BX_DIFFUSE: {  // bxdf.cpp:11-23
-      f3 wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
+      f3 wo = cosine_weighted_hemisphere(sampler_get2d<LDS>(T, sampler));
       if (CosTheta(wi) < 0) wo = -wo;
       bs.wo = wo;
       bs.pdf = AbsCosTheta(wo) / kPi;
@@ -740,7 +768,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
         return true;
       }
       const TRDist d{alpha, alpha};
-      const f3 wm = tr_SampleWm(d, wi, sampler_get2d(T, sampler));
+      const f3 wm = tr_SampleWm(d, wi, sampler_get2d<LDS>(T, sampler));
       const f3 wo = Reflect(wi, wm);
       if (!SameHemisphere(wi, wo)) return false;
       const f3 fr = FrSchlick(b.albedo, absdot(wi, wm));
@@ -759,7 +787,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
         return true;
       }
       const TRDist d{alpha, alpha};
-      const f3 wm = tr_SampleWm(d, wi, sampler_get2d(T, sampler));
+      const f3 wm = tr_SampleWm(d, wi, sampler_get2d<LDS>(T, sampler));
       const f3 wo = Reflect(wi, wm);
       if (!SameHemisphere(wi, wo)) return false;
       bs.wo = wo;
@@ -771,7 +799,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       const float fr = FrDielectric(CosTheta(wi), b.ior);
       const float alpha = sqr(b.roughness);
       if (alpha < 1e-4f) {
-        if (sampler_get1d(T, sampler) < fr) {
+        if (sampler_get1d<LDS>(T, sampler) < fr) {
           bs.wo = Reflect(wi);
           bs.f = b.albedo * (fr / AbsCosTheta(bs.wo));
           bs.pdf = fr;
@@ -785,8 +813,8 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
         return true;
       }
       const TRDist d{alpha, alpha};
-      const f3 wm = tr_SampleWm(d, wi, sampler_get2d(T, sampler));
-      if (sampler_get1d(T, sampler) < fr) {
+      const f3 wm = tr_SampleWm(d, wi, sampler_get2d<LDS>(T, sampler));
+      if (sampler_get1d<LDS>(T, sampler) < fr) {
         const f3 wo = Reflect(wi, wm);
         if (!SameHemisphere(wi, wo)) return false;
         bs.wo = wo;
@@ -807,35 +835,35 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       const float fr = FrDielectric(CosTheta(wi), b.ior);
       const float alpha = sqr(b.roughness);
       if (alpha < 1e-4f) {
-        if (sampler_get1d(T, sampler) < fr) {
+        if (sampler_get1d<LDS>(T, sampler) < fr) {
           bs.wo = Reflect(wi);
           bs.f = mk3(fr);
           bs.pdf = fr * AbsCosTheta(bs.wo);
           bs.is_delta = true;
         } else {
-          bs.wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
+          bs.wo = cosine_weighted_hemisphere(sampler_get2d<LDS>(T, sampler));
           bs.f = b.albedo * ((1 - fr) / kPi);
           bs.pdf = (1 - fr) * AbsCosTheta(bs.wo) / kPi;
         }
         return true;
       }
       const TRDist d{alpha, alpha};
-      const f3 wm = tr_SampleWm(d, wi, sampler_get2d(T, sampler));
-      if (sampler_get1d(T, sampler) < fr) {
+      const f3 wm = tr_SampleWm(d, wi, sampler_get2d<LDS>(T, sampler));
+      if (sampler_get1d<LDS>(T, sampler) < fr) {
         const f3 wo = Reflect(wi, wm);
         if (!SameHemisphere(wi, wo)) return false;
         bs.wo = wo;
         bs.f = mk3(fr * tr_D_G(d, wi, wm, wo) / (4 * CosTheta(wi) * CosTheta(wo)));
         bs.pdf = fr * tr_pdf(d, wi, wm) / (4 * absdot(wi, wm));
       } else {
-        bs.wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
+        bs.wo = cosine_weighted_hemisphere(sampler_get2d<LDS>(T, sampler));
         bs.f = b.albedo * ((1 - fr) / kPi);
         bs.pdf = AbsCosTheta(bs.wo) * (1 - fr) / kPi;
       }
       return true;
     }
     case BX_BSSRDF: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else {  // bxdf.cpp:356-367
-      f3 wo = cosine_weighted_hemisphere(sampler_get2d(T, sampler));
+      f3 wo = cosine_weighted_hemisphere(sampler_get2d<LDS>(T, sampler));
       if (CosTheta(wi) > 0) wo = -wo;
       bs.wo = wo;
       bs.pdf = AbsCosTheta(wo) / kPi;

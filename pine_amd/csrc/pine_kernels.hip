@@ -38,6 +38,10 @@ SceneHost& scene_host(pine_gpu_scene* s);
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kTile = 8;         // 8x8 pixel tiles = 64 pixels = one wave's worth of items
+#ifndef PINE_LDS_FOLD_LEVELS
+#define PINE_LDS_FOLD_LEVELS 1
+#endif
+constexpr int kLdsFoldLevels = PINE_LDS_FOLD_LEVELS;  // fold-stack levels kept in LDS (deeper levels spill to global memory)
 constexpr int kPoolItems = 128;  // items a wave claims from the global queue per atomic
 constexpr int kMaxDepth = 32;    // max_path_length supported (2 beta bits per level in one u64)
 
@@ -281,7 +285,29 @@ struct Counters {
   unsigned long long vertices;
   unsigned long long shadow_rays;
   unsigned long long pad;
+  unsigned long long section_cycles[16];  // diagnostic builds (-DPINE_PROFILE_SECTIONS) only
 };
+
+// Diagnostic section timing: per-wave s_memtime deltas summed per section.  Never compiled into the
+// product build; the stamps only go to Counters::section_cycles, which nothing else reads.
+#ifdef PINE_PROFILE_SECTIONS
+#define SEC_DECL unsigned long long sec_t = __builtin_readcyclecounter(), sec_acc[16] = {0}
+#define SEC_MARK(id)                                              \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_readcyclecounter();   \
+    sec_acc[id] += t_ - sec_t;                                    \
+    sec_t = t_;                                                   \
+  } while (0)
+#define SEC_FLUSH()                                                                     \
+  do {                                                                                  \
+    if ((threadIdx.x & 63) == 0)                                                        \
+      for (int i_ = 0; i_ < 16; i_++) atomicAdd(&counters->section_cycles[i_], sec_acc[i_]); \
+  } while (0)
+#else
+#define SEC_DECL
+#define SEC_MARK(id)
+#define SEC_FLUSH()
+#endif
 
 __device__ __forceinline__ f3 material_le(const DMaterial* m, f3 n, f3 wo) {  // material.h:22-25
   if (m->kind != MAT_EMISSIVE) return mk3(0.0f);
@@ -293,15 +319,30 @@ template <unsigned F, int WAVES_PER_SIMD>
 __global__ void __launch_bounds__(kBlock, WAVES_PER_SIMD)
 path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, Counters* __restrict__ counters) {
+  // dynamic LDS: [fold levels 0..3: 8 fields x 256 lanes each][traversal stack][scene blob]
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-  int* stack = lds_raw + threadIdx.x;
+  //              [sampler lane slices: 12 dwords x 256 lanes][Sobol rows of dims < 40][scene blob]
+  float* lds_fold = reinterpret_cast<float*>(lds_raw) + threadIdx.x;
+  int* lds_stack0 = lds_raw + kLdsFoldLevels * 8 * kBlock;
+  int* stack = lds_stack0 + threadIdx.x;
+  uint32_t* lds_tile = reinterpret_cast<uint32_t*>(lds_stack0 + S.stack_total * kBlock) + threadIdx.x;
+  uint8_t* lds_sobol = reinterpret_cast<uint8_t*>(lds_stack0 + (S.stack_total + kLdsTileDwords) * kBlock);
+  int* lds_rest = lds_stack0 + (S.stack_total + kLdsTileDwords) * kBlock + kLdsSamplerDims * 256 / 4;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(S.tables.sobol);
+    uint4* dst = reinterpret_cast<uint4*>(lds_sobol);
+    for (int i = threadIdx.x; i < kLdsSamplerDims * 256 / 16; i += kBlock) dst[i] = src[i];
+  }
+  DTables T = S.tables;
+  T.lds_sobol = lds_sobol;
+  T.lds_tile = lds_tile;
   SceneView V;
   V.tri_verts = S.tri_verts;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
   if constexpr (F & F_LDS_SCENE) {
     // stage the scene blob behind the traversal stack (stack_total * 1 KiB keeps 16-byte alignment)
-    uint4* dst = reinterpret_cast<uint4*>(lds_raw + S.stack_total * kBlock);
+    uint4* dst = reinterpret_cast<uint4*>(lds_rest);
     const int n16 = S.blob_bytes >> 4;
     for (int i = threadIdx.x; i < n16; i += kBlock) dst[i] = S.blob[i];
     __syncthreads();
@@ -313,6 +354,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.prims = reinterpret_cast<const int*>(base + S.off_prims);
     V.lights = reinterpret_cast<const int*>(base + S.off_lights);
   } else {
+    __syncthreads();  // Sobol rows staged above
     V.nodes = S.nodes;
     V.shapes = S.shapes;
     V.materials = S.materials;
@@ -322,8 +364,32 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   }
   const unsigned lane_slot = blockIdx.x * kBlock + threadIdx.x;
   const unsigned fold_stride = gridDim.x * kBlock;
-  auto fold_at = [&](int level, int field) -> float& {
-    return fold[(size_t(level) * 8 + field) * fold_stride + lane_slot];
+  // FoldEntry storage: levels < kLdsFoldLevels in LDS ([level][field][lane], conflict-free), deeper
+  // levels in a lane-interleaved global array (coalesced across the wave).
+  auto fold_store = [&](int level, const float (&e)[8]) {
+#ifdef PINE_ABL_FOLD
+    return;
+#endif
+    if (level < kLdsFoldLevels) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) lds_fold[(level * 8 + i) * kBlock] = e[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) fold[(size_t(level - kLdsFoldLevels) * 8 + i) * fold_stride + lane_slot] = e[i];
+    }
+  };
+  auto fold_load = [&](int level, float (&e)[8]) {
+#ifdef PINE_ABL_FOLD
+    for (int i = 0; i < 8; i++) e[i] = 0.25f;
+    return;
+#endif
+    if (level < kLdsFoldLevels) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) e[i] = lds_fold[(level * 8 + i) * kBlock];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) e[i] = fold[(size_t(level - kLdsFoldLevels) * 8 + i) * fold_stride + lane_slot];
+    }
   };
 
   // ---- lane state ----
@@ -348,7 +414,9 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   unsigned long long pool_next = 0, pool_end = 0;
   bool queue_empty = false;
 
+  SEC_DECL;
   while (true) {
+    SEC_MARK(0);  // loop overhead
     // ---------------- regeneration ----------------
     // Lanes whose item is exhausted take the next items of the wave's private pool (a range of
     // kPoolItems consecutive items claimed from the global queue with ONE atomic by one lane);
@@ -392,6 +460,20 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             have_item = true;
             sampler.px = it.px;
             sampler.py = it.py;
+            {
+              // refresh this lane's sampler slice: 40 ranking bytes + 8 scrambling bytes of the pixel
+              const int pix = (it.px & 127) + (it.py & 127) * 128;
+              const uint2* rsrc = reinterpret_cast<const uint2*>(S.tables.rank + size_t(pix) * 8);
+              const uint2 sc = *reinterpret_cast<const uint2*>(S.tables.scramble + size_t(pix) * 8);
+#pragma unroll
+              for (int j = 0; j < 5; j++) {
+                const uint2 r = rsrc[j];
+                lds_tile[(2 * j) * kBlock] = r.x;
+                lds_tile[(2 * j + 1) * kBlock] = r.y;
+              }
+              lds_tile[10 * kBlock] = sc.x;
+              lds_tile[11 * kBlock] = sc.y;
+            }
             s_cur = it.chunk * W.samples_per_item;
             s_end = s_cur + W.samples_per_item;
             sample_base = it.sample_base;
@@ -426,6 +508,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         alive = true;
       }
     }
+    SEC_MARK(1);  // regeneration
     if (__all(lane_done && !alive)) break;
     if (!alive) continue;
 
@@ -434,6 +517,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     const f3 wi = -ray.d;
     int geom = -1, prim = 0;
     const bool hit = scene_traverse<false, F>(V, ray, stack, geom, prim);
+    SEC_MARK(2);  // closest-hit traversal
 
     // terminal result of this vertex, if it terminates
     bool terminal = false;
@@ -468,6 +552,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       }
     }
 
+    SEC_MARK(3);  // surface info + emissive/terminal test
     if (!terminal) {
       m3 l2w = coordinate_system(it.n);  // interaction.h:14-17
       m3 w2l = transpose(l2w);
@@ -497,7 +582,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         }
       } else if (is_sss) {
         const float fr = FrDielectric(dot(wi, it.n), mat->ior);
-        if (sampler_get1d(S.tables, sampler) < fr) {
+        if (sampler_get1d<true>(T, sampler) < fr) {
           bx.kind = BX_REFRACTIVE;
           bx.roughness = pmax(mat->roughness, min_roughness);
           bx.ior = mat->ior;
@@ -537,7 +622,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               h = shape_intersect<F>(shape, wr);
             }
             if (!h) break;  // sample_p returns nullopt: nothing changes
-            const float t = -logf(1 - sampler_get1d(S.tables, sampler)) * sigma_t_inv;
+            const float t = -logf(1 - sampler_get1d<true>(T, sampler)) * sigma_t_inv;
             if (wr.tmax < t) {
               beta_channel = channel + 1;
               it.p = sit.p;
@@ -548,17 +633,18 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               break;
             }
             p = ray_at(wr, t);
-            w = uniform_sphere(sampler_get2d(S.tables, sampler));
+            w = uniform_sphere(sampler_get2d<true>(T, sampler));
           }
         }
       }
 
+      SEC_MARK(4);  // sample_bxdf (+ BSSRDF walk)
       // ---- next-event estimation (path.cpp:98-113) ----
       f3 nee = mk3(0.0f);
       if (!bxdf_is_delta<F>(bx)) {
         // g++ order for LightSampler::sample's arguments (lightsampler.h:27): get2d, then get1d
-        const f2 u2 = sampler_get2d(S.tables, sampler);
-        float u1 = sampler_get1d(S.tables, sampler);
+        const f2 u2 = sampler_get2d<true>(T, sampler);
+        float u1 = sampler_get1d<true>(T, sampler);
         if (S.num_lights > 0) {  // UniformLightSampler::sample lightsampler.cpp:12-26
           u1 *= float(S.num_lights);
           const int index = int(u1);
@@ -572,7 +658,14 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               shadow_count++;
               DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
               int g2, p2;
-              if (!scene_traverse<true, F>(V, sr, stack, g2, p2)) {
+              SEC_MARK(5);  // light sampling
+#ifdef PINE_ABL_NOSHADOW
+              const bool occluded = sr.tmax < 0;
+#else
+              const bool occluded = scene_traverse<true, F>(V, sr, stack, g2, p2);
+#endif
+              SEC_MARK(6);  // shadow traversal
+              if (!occluded) {
                 const float cosine = absdot(gs.w, it.n);
                 const f3 wo = mul(w2l, gs.w);
                 const f3 f = bxdf_f<F>(bx, wo);
@@ -584,20 +677,15 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         }
       }
 
+      SEC_MARK(7);  // NEE evaluation (and light sampling of lanes without a shadow ray)
       // ---- BSDF sampling + continuation (path.cpp:114-120) ----
       DBsdfSample bs;
-      if (bxdf_sample<F>(bx, S.tables, sampler, bs)) {
+      if (bxdf_sample<F, true>(bx, T, sampler, bs)) {
         const f3 wo_world = mul(l2w, bs.wo);
         const float cosine = absdot(wo_world, it.n);
         const int level = pv_length;
-        fold_at(level, 0) = nee.x;
-        fold_at(level, 1) = nee.y;
-        fold_at(level, 2) = nee.z;
-        fold_at(level, 3) = bs.f.x;
-        fold_at(level, 4) = bs.f.y;
-        fold_at(level, 5) = bs.f.z;
-        fold_at(level, 6) = cosine / bs.pdf;
-        fold_at(level, 7) = bs.pdf;
+        const float entry[8] = {nee.x, nee.y, nee.z, bs.f.x, bs.f.y, bs.f.z, cosine / bs.pdf, bs.pdf};
+        fold_store(level, entry);
         beta_flags = (beta_flags & ~(3ull << (2 * level))) | ((unsigned long long)beta_channel << (2 * level));
         ray = spawn_ray(it.p, it.n, wo_world, kFloatMax);
         pv_length = level + 1;
@@ -615,15 +703,18 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       }
     }
 
+    SEC_MARK(8);  // BSDF sample + push
     if (terminal) {
       // ---- backward fold through the pending levels (path.cpp:114-121, Appendix A1) ----
       f3 Li = Lo;
       bool lp_valid = has_light_pdf;
       float lp = light_pdf;
       for (int level = pv_length - 1; level >= 0; level--) {
-        const f3 e_nee{fold_at(level, 0), fold_at(level, 1), fold_at(level, 2)};
-        const f3 e_f{fold_at(level, 3), fold_at(level, 4), fold_at(level, 5)};
-        const float e_cp = fold_at(level, 6), e_pdf = fold_at(level, 7);
+        float e[8];
+        fold_load(level, e);
+        const f3 e_nee{e[0], e[1], e[2]};
+        const f3 e_f{e[3], e[4], e[5]};
+        const float e_cp = e[6], e_pdf = e[7];
         const float mis = lp_valid ? balance_heuristic(e_pdf, lp) : 1.0f;
         const f3 lo = e_nee + Li * e_f * (e_cp * mis);
         f3 beta = mk3(1.0f);
@@ -640,8 +731,10 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       s_cur++;
       alive = false;
     }
+    SEC_MARK(9);  // fold + sample store
   }
 
+  SEC_FLUSH();
   // per-wave reduction of the counters, one atomic per wave
   for (int off = 32; off > 0; off >>= 1) {
     vertex_count += __shfl_down(vertex_count, off);
@@ -657,17 +750,25 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 using PathKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, Counters*);
 struct KernelVariant {
   unsigned features;
+  int waves_per_simd;
   PathKernelFn fn;
   const char* name;
 };
 constexpr unsigned kFBoxes = F_AABB | F_OBB;
 constexpr unsigned kFAnalytic = F_AABB | F_OBB | F_SPHERE | F_DISK | F_CONE | F_UBER;
 static const KernelVariant kVariants[] = {
-    {kFBoxes | F_LDS_SCENE, path_trace_kernel<kFBoxes | F_LDS_SCENE, 4>, "rect+box/diffuse, scene in LDS"},
-    {kFAnalytic | F_LDS_SCENE, path_trace_kernel<kFAnalytic | F_LDS_SCENE, 2>, "analytic shapes/uber, scene in LDS"},
-    {kFAnalytic, path_trace_kernel<kFAnalytic, 2>, "analytic shapes/uber"},
-    {F_ALL | F_LDS_SCENE, path_trace_kernel<F_ALL | F_LDS_SCENE, 2>, "all features, scene in LDS"},
-    {F_ALL, path_trace_kernel<F_ALL, 2>, "all features"},
+    {kFBoxes | F_LDS_SCENE, 4, path_trace_kernel<kFBoxes | F_LDS_SCENE, 4>, "rect+box/diffuse, scene in LDS"},
+#ifdef PINE_EXPERIMENT_WPS
+    {kFBoxes | F_LDS_SCENE, 5, path_trace_kernel<kFBoxes | F_LDS_SCENE, 5>, "rect+box/diffuse, scene in LDS, 5 waves"},
+    {kFBoxes | F_LDS_SCENE, 6, path_trace_kernel<kFBoxes | F_LDS_SCENE, 6>, "rect+box/diffuse, scene in LDS, 6 waves"},
+    {kFBoxes | F_LDS_SCENE, 8, path_trace_kernel<kFBoxes | F_LDS_SCENE, 8>, "rect+box/diffuse, scene in LDS, 8 waves"},
+#endif
+#ifndef PINE_ONLY_CBOX_VARIANT  /* experiment builds compile just the first variant */
+    {kFAnalytic | F_LDS_SCENE, 2, path_trace_kernel<kFAnalytic | F_LDS_SCENE, 2>, "analytic shapes/uber, scene in LDS"},
+    {kFAnalytic, 2, path_trace_kernel<kFAnalytic, 2>, "analytic shapes/uber"},
+    {F_ALL | F_LDS_SCENE, 2, path_trace_kernel<F_ALL | F_LDS_SCENE, 2>, "all features, scene in LDS"},
+    {F_ALL, 2, path_trace_kernel<F_ALL, 2>, "all features"},
+#endif
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -809,6 +910,15 @@ static int load_tables() {
   }
   g_tables.swap(buf);
   return 0;
+}
+// The device keeps sobol_256spp_256d transposed ([dimension][sample] instead of [sample][dimension]):
+// lanes of a wave usually ask for the same dimension at 64 different (ranked) sample rows, which is
+// one 256-byte row here instead of 64 cache lines 256 bytes apart.
+static std::vector<uint8_t> transposed_sobol() {
+  std::vector<uint8_t> t(65536);
+  for (int s = 0; s < 256; s++)
+    for (int d = 0; d < 256; d++) t[d * 256 + s] = g_tables[s * 256 + d];
+  return t;
 }
 static int effective_spp(int spp) {  // BlueSobolSampler ctor sampler.cpp:115-121
   if (spp > 256) spp = 256;
@@ -954,9 +1064,16 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // tables: sobol + the selected spp variant
   int k = 0;
   while ((1 << k) < spp) k++;
-  HIP_OK(hipMalloc((void**)&p->d_tables, 65536 + 262144));
-  HIP_OK(hipMemcpy(p->d_tables, g_tables.data(), 65536, hipMemcpyHostToDevice));
+  // device layout: sobolT 64 KiB | scramble 128 KiB | rank 128 KiB | 64 bytes = rank[0..63] again, so
+  // a pixel's 40 consecutive ranking bytes never need the reference's modulo wrap
+  HIP_OK(hipMalloc((void**)&p->d_tables, 65536 + 262144 + 64));
+  {
+    const std::vector<uint8_t> st = transposed_sobol();
+    HIP_OK(hipMemcpy(p->d_tables, st.data(), 65536, hipMemcpyHostToDevice));
+  }
   HIP_OK(hipMemcpy(p->d_tables + 65536, g_tables.data() + 65536 + size_t(k) * 262144, 262144, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(p->d_tables + 65536 + 262144, g_tables.data() + 65536 + size_t(k) * 262144 + 131072, 64,
+                   hipMemcpyHostToDevice));
 
   S.blob = reinterpret_cast<const uint4*>(p->d_blob);
   S.nodes = reinterpret_cast<const DNode*>(p->d_blob + S.off_nodes);
@@ -972,6 +1089,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.tables.sobol = p->d_tables;
   S.tables.scramble = p->d_tables + 65536;
   S.tables.rank = p->d_tables + 65536 + 131072;
+  S.tables.lds_sobol = nullptr;
+  S.tables.lds_tile = nullptr;
   S.spp = spp;
   S.max_path_length = prm->max_path_length;
   int d_top = 0, d_mesh = 0;
@@ -983,7 +1102,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   S.stack_top = d_top;
   S.stack_total = std::max(1, d_top + d_mesh);
-  p->lds_bytes = size_t(S.stack_total) * kBlock * sizeof(int);
+  p->lds_bytes = size_t(kLdsFoldLevels * 8 + S.stack_total + kLdsTileDwords) * kBlock * sizeof(int) +
+                 size_t(kLdsSamplerDims) * 256;
   if (p->lds_bytes > 64 * 1024) {
     set_error("BVH too deep for the LDS traversal stack");
     return -1;
@@ -1011,6 +1131,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     const unsigned F = kVariants[v].features;
     if ((F & need) != need) continue;
     if (((F & F_LDS_SCENE) != 0) != lds_ok) continue;
+    if (getenv("PINE_GPU_WPS") && atoi(getenv("PINE_GPU_WPS")) != kVariants[v].waves_per_simd) continue;
     p->variant = v;
     break;
   }
@@ -1065,7 +1186,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
 
   if (W.items_per_pixel > 1) HIP_OK(hipMalloc((void**)&p->d_ckpt, W.total_items * sizeof(ulonglong2)));
   HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
-  HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * size_t(p->grid) * kBlock * sizeof(float)));
+  HIP_OK(hipMalloc((void**)&p->d_fold, size_t(std::max(1, prm->max_path_length - kLdsFoldLevels)) * 8 * size_t(p->grid) * kBlock * sizeof(float)));
   HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
   p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
   if (p->timed)
@@ -1157,6 +1278,19 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
       HIP_OK(hipEventElapsedTime(&out->resolve_ms, p->ev[2], p->ev[3]));
     }
   }
+  return 0;
+}
+
+int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
+  if (!p || !out) {
+    set_error("null argument");
+    return -1;
+  }
+  HIP_OK(hipSetDevice(p->device));
+  HIP_OK(hipDeviceSynchronize());
+  Counters c;
+  HIP_OK(hipMemcpy(&c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; i++) out[i] = c.section_cycles[i];
   return 0;
 }
 
@@ -1259,10 +1393,13 @@ int pine_gpu_test_sampler(int device, int spp_req, float* out, int64_t capacity)
   uint8_t* dt;
   float* dout;
   HIP_OK(hipMalloc((void**)&dt, 65536 + 262144));
-  HIP_OK(hipMemcpy(dt, g_tables.data(), 65536, hipMemcpyHostToDevice));
+  {
+    const std::vector<uint8_t> st = transposed_sobol();
+    HIP_OK(hipMemcpy(dt, st.data(), 65536, hipMemcpyHostToDevice));
+  }
   HIP_OK(hipMemcpy(dt + 65536, g_tables.data() + 65536 + size_t(k) * 262144, 262144, hipMemcpyHostToDevice));
   HIP_OK(hipMalloc((void**)&dout, need * 4));
-  DTables T{dt, dt + 65536, dt + 65536 + 131072};
+  DTables T{dt, dt + 65536, dt + 65536 + 131072, nullptr, nullptr};
   hipLaunchKernelGGL(test_sampler_kernel, dim3(6), dim3(64), 0, 0, T, spp, dout);
   HIP_OK(hipMemcpy(out, dout, need * 4, hipMemcpyDeviceToHost));
   hipFree(dt);

@@ -24,8 +24,13 @@ PINE_HD float pclamp(float v, float a, float b) { return pmin(pmax(v, a), b); }
 PINE_HD float pabs(float v) { return fabsf(v); }
 PINE_HD float psqrt(float v) { return sqrtf(v); }
 // libm-exact sin/cos (see pine_libm.h); on the host these equal std::sin/std::cos of glibc.
+#ifdef PINE_ABL_SINCOS  /* experiment builds only: hardware approximations (timing only) */
+PINE_HD float psin(float v) { return __sinf(v); }
+PINE_HD float pcos(float v) { return __cosf(v); }
+#else
 PINE_HD float psin(float v) { return pine_libm::sinf_glibc(v); }
 PINE_HD float pcos(float v) { return pine_libm::cosf_glibc(v); }
+#endif
 
 struct f2 {
   float x, y;
