@@ -126,6 +126,10 @@ typedef struct {
 
 #define PINE_GPU_FLAG_TIMING 1 /* record per-kernel HIP-event timings for the roofline report */
 
+/* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are
+ * dealt round-robin to `world` ranks (host-side helper; the kernels use the same mapping). */
+int pine_gpu_shard_of_pixel(int film_w, int x, int y, int world);
+
 /* Path to the packed BlueSobol tables (pine_amd/data/bluesobol_u8.bin); call once per process. */
 int pine_gpu_set_table_path(const char* path);
 

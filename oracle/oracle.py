@@ -58,6 +58,16 @@ def render(pscene: str, size, spp, depth, threads=0, rows=None):
     return film, st
 
 
+def render_shard(pscene: str, size, spp, depth, rank, world, threads=0):
+    w, h = size
+    film = np.zeros((h, w, 4), np.float32)
+    rc = lib().oracle_render_shard(pscene.encode(), _tp(), int(spp), int(depth), int(threads), int(rank), int(world),
+                                   film.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError(f"oracle_render_shard: {lib().oracle_last_error().decode()}")
+    return film
+
+
 def render_samples(pscene: str, size, spp_eff, spp, depth, threads=0):
     w, h = size
     out = np.zeros((h, w, spp_eff, 4), np.float32)

@@ -2085,8 +2085,11 @@ bool parse_pscene(const char* text, Scene& scene) {
 }
 
 // PathIntegrator::render (path.cpp:26-41) with parallel_for's scheduling shape (parallel.h:19-57)
+// shard_world > 1: only pixels of 8x8 tiles t = ty*tiles_x + tx with t % world == rank are rendered
+// (the product's multi-GPU partition, pine_amd/csrc/pine_kernels.hip decode_item); others untouched.
 void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int depth, int threads,
-                 int y0, int y1, float* film, float* samples_out, oracle_stats* stats) {
+                 int y0, int y1, float* film, float* samples_out, oracle_stats* stats,
+                 int shard_rank = 0, int shard_world = 1) {
   int W = scene.camera.W, H = scene.camera.H;
   int spp = bluesobol_effective_spp(spp_req);
   BlueTables bt = select_tables(tables, spp);
@@ -2112,6 +2115,11 @@ void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int dep
       int end_index = std::min(index + batch_size, n_items);
       for (int i = index; i < end_index; i++) {
         int px = (first + i) % W, py = (first + i) / W;
+        if (shard_world > 1) {
+          int tiles_x = (W + 7) / 8;
+          int tile = (py / 8) * tiles_x + px / 8;
+          if (tile % shard_world != shard_rank) continue;
+        }
         sampler.start_pixel(px, py, 0);
         vec3 L(0.0f);
         for (int si = 0; si < spp; si++, sampler.start_next_sample()) {
@@ -2179,6 +2187,15 @@ int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth,
   render_impl(scene, tables, spp, depth, threads, y0, y1, film_out, nullptr, stats);
   auto t1 = std::chrono::steady_clock::now();
   if (stats) stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+  return 0;
+}
+
+int oracle_render_shard(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,
+                        int shard_rank, int shard_world, float* film_out) {
+  Scene scene;
+  if (!parse_pscene(pscene, scene)) return 2;
+  scene.build_accel();
+  render_impl(scene, tables, spp, depth, threads, 0, 0, film_out, nullptr, nullptr, shard_rank, shard_world);
   return 0;
 }
 

@@ -30,6 +30,11 @@ typedef struct {
 int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,
                   int y0, int y1, float* film_out, oracle_stats* stats);
 
+/* Render only the pixels of this shard (8x8 tiles dealt round-robin, the product's multi-GPU
+ * partition); film_out must be zero-initialised by the caller, other pixels are left untouched. */
+int oracle_render_shard(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,
+                        int shard_rank, int shard_world, float* film_out);
+
 /* Per-sample radiance (before the per-pixel sum): out[(y*W+x)*spp + s] = (r,g,b,vertices). */
 int oracle_render_samples(const char* pscene, const uint8_t* tables, int spp, int depth,
                           int threads, float* samples_out);

@@ -86,6 +86,7 @@ SIGNATURES = {
     "pine_gpu_scene_describe": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "pine_gpu_scene_build_accel": (C.c_int, [C.c_void_p]),
     "pine_gpu_scene_accel_dump": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int64]),
+    "pine_gpu_shard_of_pixel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pine_gpu_set_table_path": (C.c_int, [C.c_char_p]),
     "pine_gpu_path_render": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), c_f_p]),
     "pine_gpu_plan_create": (C.c_void_p, [C.c_void_p, C.POINTER(RenderParams)]),

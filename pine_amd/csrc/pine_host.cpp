@@ -673,6 +673,15 @@ int pine_gpu_scene_set_camera_thinlens(pine_gpu_scene* s, int w, int h, int tone
   return 0;
 }
 
+int pine_gpu_shard_of_pixel(int film_w, int x, int y, int world) {
+  if (film_w <= 0 || x < 0 || y < 0 || world < 1) {
+    set_error("bad argument");
+    return -1;
+  }
+  const int tiles_x = (film_w + 7) / 8;
+  return ((y / 8) * tiles_x + x / 8) % world;
+}
+
 int64_t pine_gpu_scene_describe(pine_gpu_scene* s, char* buf, int64_t capacity) {
   if (!check(s)) return -1;
   std::string d = s->host.describe();

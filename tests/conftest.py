@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    bad = bits(a) != bits(b)
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} values differ; first at {np.argwhere(bad)[0].tolist()}: {a[tuple(np.argwhere(bad)[0])]} vs {b[tuple(np.argwhere(bad)[0])]}"
+
+
+def load_film(name):
+    z = np.load(os.path.join(GOLDEN, f"film_{name}.npz"))
+    return z["film"], str(z["pscene"]), int(z["spp"]), int(z["depth"])
+
+
+FILM_NAMES = [
+    "cbox_committed_64_s16_d4", "cbox_readme_64_s16_d4", "cbox_readme_64_s256_d8",
+    "cbox_rect_readme_64_s64_d5", "cbox_committed_ragged_45x37_s8_d3", "cbox_readme_64_s1_d1",
+    "zoo_48_s16_d5", "classic_cones12_90x45_s32_d6", "sss_48_s32_d8",
+]
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    return o

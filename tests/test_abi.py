@@ -1,0 +1,149 @@
+"""CPU: the C-ABI library loads, exports every symbol include/pine_gpu.h declares, and its host-side
+logic (scene building, host math, BVH build, error behaviour) works without a GPU.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, assert_bit_equal, load_film
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "pine_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pine_gpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pine_amd import _lib
+    names = _declared()
+    assert len(names) > 35
+    for n in names:
+        assert hasattr(_lib.lib, n), f"libpine_gpu.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib.pine_gpu_abi_version() == 1
+
+
+def test_host_math_matches_reference():
+    import pine_amd as pa
+    ref = np.load(os.path.join(GOLDEN, "host_math.npy"))
+    m0 = pa.translate([0.0, 0.0, 0.6]) * pa.rotate_y(0.4) * pa.scale([0.6, 0.6, 0.6])
+    m1 = pa.translate([-0.6, 0.0, 1.0]) * pa.rotate_y(-0.4) * pa.scale([0.6, 1.3, 0.6])
+    got = []
+    for m in (m0, pa.inverse(m0), m1, pa.inverse(m1), pa.look_at([0, 0, 0], [0, 0, 1]), pa.look_at([0, 1, -4], [0, 1, 0]),
+              pa.look_at([0, 4, -8], [0, 1, 0]), pa.rotate_x(0.3) * pa.rotate_z(-1.1)):
+        got += list(m.s)
+    assert_bit_equal(np.float32(got), ref[:128], "mat4 helpers")
+
+
+def test_scene_describe_equals_golden_pscene():
+    """The API mirror + C ABI rebuild exactly the scene text the golden films were rendered from."""
+    from pine_amd import scenes
+    _, ps, _, _ = load_film("cbox_committed_64_s16_d4")
+    assert scenes.cbox((64, 64), "committed").describe() == ps
+    _, ps, _, _ = load_film("sss_48_s32_d8")
+    assert scenes.sss((48, 48), 1).describe() == ps
+    _, ps, _, _ = load_film("classic_cones12_90x45_s32_d6")
+    assert scenes.classic_cones((90, 45), 12).describe() == ps
+
+
+def test_error_behaviour_mirrors_reference():
+    import pine_amd as pa
+    s = pa.Scene()
+    with pytest.raises(pa.PineError, match="Can't find material"):   # scene.cpp:53
+        s.add(pa.Rect([0, 0, 0], [1, 0, 0], [0, 0, 1]), "nope")
+    with pytest.raises(pa.PineError, match="degenerated"):           # geometry.cpp:266
+        s.add("m", pa.Diffuse([1, 1, 1]))
+        s.add(pa.Rect([0, 0, 0], [1, 0, 0], [2, 0, 0]), "m")
+    with pytest.raises(pa.PineError, match="max_path_length"):       # path.cpp:12-13
+        pa.PathIntegrator(pa.BlueSampler(4), 0)
+    with pytest.raises(pa.PineError):
+        pa.BlueSampler(0)
+    assert pa.BlueSampler(1000).spp() == 256 and pa.BlueSampler(5).spp() == 8
+
+
+def test_material_name_shadowing_and_light_list():
+    import pine_amd as pa
+    s = pa.Scene()
+    s.add("a", pa.Diffuse([1, 0, 0]))
+    s.add("a", pa.Diffuse([0, 1, 0]))  # map assignment: the later one wins
+    s.add(pa.Rect([0, 0, 0], [1, 0, 0], [0, 0, 1]), "a")
+    s.add(pa.Rect([0, 1, 0], [1, 0, 0], [0, 0, 1]), pa.Emissive([1, 1, 1]))
+    d = s.describe()
+    assert d.count("material a diffuse") == 2 and "shape rect a" in d and "emissive" in d
+
+
+def test_bvh_build_invariants():
+    """Host BVH build (no GPU): every primitive in exactly one leaf, child boxes inside the parent's."""
+    from pine_amd import scenes, _lib
+    sc = scenes.classic_cones((64, 32), 16)
+    n_nodes = _lib.check(_lib.lib.pine_gpu_scene_build_accel(sc._h))
+    assert n_nodes > 50
+    nodes = np.zeros((n_nodes, 16), np.float32)
+    prims = np.zeros(4096, np.int32)
+    n_prims = _lib.lib.pine_gpu_scene_accel_dump(sc._h, nodes.ctypes.data_as(C.c_void_p), nodes.nbytes,
+                                                 prims.ctypes.data_as(C.POINTER(C.c_int32)), prims.size)
+    n_geoms = 16 * 16 + 5
+    assert n_prims == n_geoms
+    assert sorted(prims[:n_prims].tolist()) == list(range(n_geoms))
+    ints = nodes.view(np.int32)
+    seen = np.zeros(n_prims, bool)
+    for nd in range(n_nodes):
+        for c in range(2):
+            child, count = ints[nd, 12 + c], ints[nd, 14 + c]
+            if count > 0:
+                assert not seen[child:child + count].any()
+                seen[child:child + count] = True
+            else:
+                lo, hi = nodes[nd, 6 * c:6 * c + 3], nodes[nd, 6 * c + 3:6 * c + 6]
+                clo = np.minimum(nodes[child, 0:3], nodes[child, 6:9])
+                chi = np.maximum(nodes[child, 3:6], nodes[child, 9:12])
+                assert (clo >= lo).all() and (chi <= hi).all()
+    assert seen.all()
+
+
+def test_shard_mapping_is_a_partition():
+    from pine_amd import _lib
+    w, h, world = 45, 37, 3
+    owner = np.array([[_lib.lib.pine_gpu_shard_of_pixel(w, x, y, world) for x in range(w)] for y in range(h)])
+    tiles_x = (w + 7) // 8
+    ys, xs = np.mgrid[0:h, 0:w]
+    assert np.array_equal(owner, ((ys // 8) * tiles_x + xs // 8) % world)
+    assert set(np.unique(owner)) == {0, 1, 2}
+
+
+def test_film_finalize_u8():
+    import pine_amd as pa
+    f = pa.Film([4, 2], pa.Uncharted2())
+    f.pixels[...] = 0.0
+    f.pixels[0, 0, :3] = 11.2 / 2  # maps to the white point: uncharted2(11.2)/uncharted2(11.2) = 1
+    out = f.finalize_u8()
+    assert out.shape == (2, 4, 4) and (out[..., 3] == 255).all()
+    assert tuple(out[1, 0, :3]) == (255, 255, 255)  # row 0 of the film is the bottom image row (y flip)
+    assert tuple(out[0, 1, :3]) == (0, 0, 0)
+
+
+def test_no_gpu_means_loud_failure():
+    """The product never falls back to a CPU path: without a device, rendering raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pine_amd as pa
+    from pine_amd import scenes
+    sc = scenes.cbox((16, 16))
+    with pytest.raises(pa.PineError, match="no HIP device|hip"):
+        pa.PathIntegrator(pa.BlueSampler(4), 4).render(sc)
+    with pytest.raises(pa.PineError):
+        pa.Plan(sc, 4, 4)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pine_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f

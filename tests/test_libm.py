@@ -1,0 +1,15 @@
+"""CPU: pine_amd/csrc/pine_libm.h (the device's sinf/cosf) against the host libm, the one the reference
+links.  The exhaustive run (2.2e9 floats, stride 1) is `tools/check_libm.cpp`; here a 1/61 subsample."""
+import os
+import subprocess
+
+from conftest import ROOT
+
+
+def test_sincos_match_host_libm(tmp_path):
+    exe = tmp_path / "check_libm"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-pthread",
+                           os.path.join(ROOT, "tools", "check_libm.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "61"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert '"sin_mismatch": 0' in out.stdout and '"cos_mismatch": 0' in out.stdout

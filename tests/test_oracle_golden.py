@@ -1,0 +1,106 @@
+"""CPU: the oracle (oracle/pine_oracle.cpp) against the golden vectors produced by the REAL reference
+(tests/golden, tools/make_golden.py).  Everything is bit-exact: integer streams, host math, per-shape
+records and whole films."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, FILM_NAMES, assert_bit_equal, load_film
+
+
+@pytest.mark.parametrize("spp", [1, 16, 256])
+def test_sampler_stream_matches_reference(oracle, spp):
+    k = np.load(os.path.join(GOLDEN, f"sampler_spp{spp}.npz"))["k"]
+    ref = (k.astype(np.float32) + np.float32(0.5)) / np.float32(256)
+    assert_bit_equal(oracle.sampler_stream(spp), ref, f"BlueSobolSampler({spp}) stream")
+
+
+def test_sampler_known_answers(oracle):
+    # BlueSampler(16), pixel (3,5), sample 0, dims 0..5 and sample 1, dims 0..2
+    s = oracle.sampler_stream(16).reshape(6, -1)[2]  # pixel (3,5) is the third test pixel
+    np.testing.assert_array_equal(s[:6], np.float32([0.564453125, 0.935546875, 0.431640625, 0.025390625, 0.880859375, 0.021484375]))
+    np.testing.assert_array_equal(s[260:263], np.float32([0.060546875, 0.162109375, 0.845703125]))
+    s = oracle.sampler_stream(256).reshape(6, -1)[5]  # pixel (639,639)
+    np.testing.assert_array_equal(s[:3], np.float32([0.568359375, 0.693359375, 0.728515625]))
+
+
+def test_sampler_spp_rounding():
+    from oracle import oracle as o
+    # BlueSobolSampler ctor: round up to a power of two, clamp to 256 (sampler.cpp:115-121)
+    assert [o.effective_spp(n) for n in (1, 2, 3, 5, 16, 17, 100, 256, 512, 1024)] == [1, 2, 4, 8, 16, 32, 128, 256, 256, 256]
+
+
+def test_rng_stream_matches_reference(oracle):
+    ref = np.load(os.path.join(GOLDEN, "rng.npy"))
+    got = oracle.rng_stream()
+    assert np.array_equal(got, ref)
+    # SURVEY.md Appendix D known answers
+    r = got.reshape(6, 19)
+    assert int(r[0, 0]) == 0x6C9A7A0560404F9B            # hash((0,0), 0)
+    assert int(r[2, 0]) == 0x56B273D97D8B5B00            # hash((3,5), 0)
+    assert int(r[2, 1]) == 0x387FD842DB87B11A and int(r[2, 2]) == 0xDC2BCC5E60C5924B
+    f = r[2, 3:7].astype(np.uint32).view(np.float32)
+    np.testing.assert_array_equal(f, np.float32([0.159773335, 0.0878059268, 0.203855723, 0.123972036]))
+
+
+def test_host_math_matches_reference(oracle):
+    assert_bit_equal(oracle.host_math(), np.load(os.path.join(GOLDEN, "host_math.npy")), "host math")
+
+
+def test_shape_records_match_reference(oracle):
+    z = np.load(os.path.join(GOLDEN, "shapes_zoo.npz"))
+    rec = z["records"]
+    got = oracle.shapes(str(z["pscene"]), z["rays"], rec.shape[0])
+    # compute_surface_info output is only defined on a hit (the reference leaves `it` untouched otherwise)
+    assert_bit_equal(got[..., :3], rec[..., :3], "hit / intersect / tmax")
+    hit = rec[..., 1] == 1
+    assert hit.sum() > 500
+    assert_bit_equal(got[hit][:, 3:], rec[hit][:, 3:], "surface info on hits")
+
+
+@pytest.mark.parametrize("name", FILM_NAMES)
+def test_film_bit_identical_to_reference(oracle, name):
+    ref, ps, spp, depth = load_film(name)
+    h, w, _ = ref.shape
+    film, st = oracle.render(ps, (w, h), spp, depth)
+    assert_bit_equal(film, ref, name)
+    assert st.camera_samples == w * h * oracle.effective_spp(spp)
+
+
+def test_row_range_and_shards_compose(oracle):
+    ref, ps, spp, depth = load_film("cbox_committed_ragged_45x37_s8_d3")
+    h, w, _ = ref.shape
+    a, _ = oracle.render(ps, (w, h), spp, depth, rows=(0, 20))
+    b, _ = oracle.render(ps, (w, h), spp, depth, rows=(20, h))
+    assert_bit_equal(a + b, ref, "row ranges")
+    tot = sum(oracle.render_shard(ps, (w, h), spp, depth, r, 3) for r in range(3))
+    assert_bit_equal(tot, ref, "3 tile shards")
+
+
+def test_depth_must_be_positive(oracle):
+    _, ps, spp, _ = load_film("cbox_readme_64_s1_d1")
+    with pytest.raises(RuntimeError, match="max_path_length"):
+        oracle.render(ps, (64, 64), spp, 0)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/pine"), reason="reference sources absent")
+def test_oracle_against_live_reference(oracle):
+    """In the build container the real reference binary is available: one fresh config, bit-exact."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/pine_ref not built")
+    from pine_amd import scenes
+    sc = scenes.cbox((40, 24), "readme")
+    ps = sc.describe()
+    ref, _ = oracle.ref_render(ps, (40, 24), 32, 6)
+    got, _ = oracle.render(ps, (40, 24), 32, 6)
+    assert_bit_equal(got, ref, "live reference")
+
+
+def test_stats_file_present():
+    st = json.load(open(os.path.join(GOLDEN, "stats_640.json")))
+    c1 = st["C1_cbox_640_s16_d4_committed"]
+    # SURVEY.md Appendix C sanity values of the g++ oracle
+    np.testing.assert_allclose(c1["mean_rgb"], [0.093782, 0.058198, 0.017012], atol=1e-6)
+    np.testing.assert_allclose(c1["center_pixel"], [0.087721169, 0.0352332816, 0.00938287377], rtol=1e-7)

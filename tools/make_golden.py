@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REAL reference (oracle/_ref/pine_ref, built from
+/root/reference by oracle/Makefile).  Runs only in the build container; the outputs (data: inputs
+and the reference's outputs, no reference source) are committed and travel to the GPU box.
+
+    python tools/make_golden.py            # everything except the two 640x640 statistics
+    python tools/make_golden.py --full     # also C1/C2 whole-image statistics (~1 min of CPU)
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pine_amd import scenes  # noqa: E402  (scene construction only: host code, no GPU)
+
+REF = os.path.join(ROOT, "oracle", "_ref", "pine_ref")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def run_ref(*args):
+    return subprocess.run([REF, *map(str, args)], capture_output=True, text=True, check=True).stdout
+
+
+def ref_film(scene, spp, depth, tmp):
+    w, h = scene.camera.film().size
+    sp, fp = os.path.join(tmp, "s.pscene"), os.path.join(tmp, "s.film")
+    ps = scene.describe()
+    open(sp, "w").write(ps)
+    info = json.loads(run_ref("render", sp, spp, depth, fp).strip().splitlines()[-1])
+    return ps, np.fromfile(fp, dtype=np.float32).reshape(h, w, 4), info
+
+
+FILMS = {
+    # name: (builder, spp, depth)
+    "cbox_committed_64_s16_d4": (lambda: scenes.cbox((64, 64), "committed"), 16, 4),
+    "cbox_readme_64_s16_d4": (lambda: scenes.cbox((64, 64), "readme"), 16, 4),
+    "cbox_readme_64_s256_d8": (lambda: scenes.cbox((64, 64), "readme"), 256, 8),
+    "cbox_rect_readme_64_s64_d5": (lambda: scenes.cbox((64, 64), "readme", False), 64, 5),
+    "cbox_committed_ragged_45x37_s8_d3": (lambda: scenes.cbox((45, 37), "committed"), 8, 3),
+    "cbox_readme_64_s1_d1": (lambda: scenes.cbox((64, 64), "readme"), 1, 1),
+    "zoo_48_s16_d5": (lambda: scenes.shapes_zoo((48, 48)), 16, 5),
+    "classic_cones12_90x45_s32_d6": (lambda: scenes.classic_cones((90, 45), 12), 32, 6),
+    "sss_48_s32_d8": (lambda: scenes.sss((48, 48), 1), 32, 8),
+}
+
+
+def main():
+    full = "--full" in sys.argv
+    os.makedirs(OUT, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        # 1. sampler / rng / host-math known answers
+        for spp in (1, 16, 256):
+            fp = os.path.join(tmp, "samp.bin")
+            run_ref("sampler", spp, fp)
+            v = np.fromfile(fp, dtype=np.float32)
+            q = np.floor(v * 256).astype(np.uint8)  # values are (k + 0.5) / 256, k < 256: lossless
+            assert np.array_equal(((q.astype(np.float32) + np.float32(0.5)) / np.float32(256)).view(np.uint32), v.view(np.uint32))
+            np.savez_compressed(os.path.join(OUT, f"sampler_spp{spp}.npz"), k=q)
+        fp = os.path.join(tmp, "rng.bin")
+        run_ref("rng", fp)
+        np.save(os.path.join(OUT, "rng.npy"), np.fromfile(fp, dtype=np.uint64))
+        fp = os.path.join(tmp, "host.bin")
+        run_ref("host", fp)
+        np.save(os.path.join(OUT, "host_math.npy"), np.fromfile(fp, dtype=np.float32))
+
+        # 2. per-shape records on a fixed ray set (grazing / inside / behind / tmax-clipped included)
+        zoo = scenes.shapes_zoo((48, 48))
+        rng = np.random.default_rng(12345)
+        n = 1500
+        o = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32) + np.array([0, 1, 1], np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        d[:50] = np.array([0, -1, 0], np.float32)           # axis-parallel
+        d[50:100] = np.array([1, 0, 0], np.float32)
+        o[100:150] = np.array([0.3, 0.3, 0.9], np.float32)  # origins inside the OBB / near the sphere
+        tmin = np.zeros((n, 1), np.float32)
+        tmax = np.full((n, 1), np.finfo(np.float32).max, np.float32)
+        tmax[200:400, 0] = rng.uniform(0.1, 2.5, 200).astype(np.float32)  # clipped rays
+        rays = np.concatenate([o, d, tmin, tmax], axis=1).astype(np.float32)
+        sp, rp, op = (os.path.join(tmp, x) for x in ("z.pscene", "rays.bin", "shapes.bin"))
+        zps = zoo.describe()
+        open(sp, "w").write(zps)
+        rays.tofile(rp)
+        run_ref("shapes", sp, rp, op)
+        rec = np.fromfile(op, dtype=np.float32).reshape(-1, n, 11)
+        np.savez_compressed(os.path.join(OUT, "shapes_zoo.npz"), rays=rays, records=rec, pscene=np.array(zps))
+
+        # 3. films
+        meta = {}
+        for name, (build, spp, depth) in FILMS.items():
+            ps, film, info = ref_film(build(), spp, depth, tmp)
+            np.savez_compressed(os.path.join(OUT, f"film_{name}.npz"), film=film, pscene=np.array(ps),
+                                spp=spp, depth=depth)
+            meta[name] = {"spp": spp, "depth": depth, "size": [info["w"], info["h"]],
+                          "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
+                          "md5": hashlib.md5(film.tobytes()).hexdigest()}
+            print(name, meta[name]["mean_rgb"])
+
+        # 4. whole-image statistics of the BASELINE configs (too big to commit as films)
+        stats_path = os.path.join(OUT, "stats_640.json")
+        stats = json.load(open(stats_path)) if os.path.exists(stats_path) else {}
+        if full:
+            for name, spp, depth, cam in (("C1_cbox_640_s16_d4_committed", 16, 4, "committed"),
+                                           ("C2_cbox_640_s256_d8_committed", 256, 8, "committed"),
+                                           ("cbox_640_s16_d4_readme", 16, 4, "readme")):
+                ps, film, info = ref_film(scenes.cbox((640, 640), cam), spp, depth, tmp)
+                stats[name] = {"spp": spp, "depth": depth, "camera": cam,
+                               "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
+                               "md5": hashlib.md5(film.tobytes()).hexdigest(),
+                               "center_pixel": [float(x) for x in film[320, 320, :3]],
+                               "black_pixels": int((film[..., :3] == 0).all(axis=2).sum()),
+                               "ref_seconds": info["seconds"], "ref_threads": info["threads"],
+                               "ref_msamples_per_s": info["msamples_per_s"]}
+                print(name, stats[name])
+            json.dump(stats, open(stats_path, "w"), indent=1)
+        json.dump(meta, open(os.path.join(OUT, "films.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
