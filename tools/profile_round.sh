@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage (on the GPU box): tools/profile_round.sh rNN
+# Produces profiles/<tag>_* : rocprofv3 kernel-trace stats of `python bench.py`, PMC passes of the
+# path kernel (separate passes, no trace domains besides kernel-trace), and the bench JSON line.
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/profiles
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 10 --warmup 2 > gpurun_out/profiles/${tag}_bench_under_rocprof.log 2>&1
+cp gpurun_out/prof_$tag/*/*_kernel_stats.csv gpurun_out/profiles/${tag}_kernel_stats.csv
+tools/pmc.sh $tag > /dev/null 2>&1
+cp gpurun_out/pmc_${tag}_summary.txt gpurun_out/profiles/${tag}_pmc_summary.txt
+python bench.py --steps 10 --warmup 2 > gpurun_out/profiles/${tag}_bench.json 2> gpurun_out/profiles/${tag}_bench.err
+tail -1 gpurun_out/profiles/${tag}_bench.json | cut -c1-400
+cat gpurun_out/profiles/${tag}_kernel_stats.csv | cut -c1-160
