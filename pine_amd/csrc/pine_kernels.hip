@@ -45,6 +45,38 @@ constexpr int kLdsFoldLevels = PINE_LDS_FOLD_LEVELS;  // fold-stack levels kept 
 constexpr int kPoolItems = 128;  // items a wave claims from the global queue per atomic
 constexpr int kMaxDepth = 32;    // max_path_length supported (2 beta bits per level in one u64)
 
+// Diagnostic section timing: per-wave s_memtime deltas summed per section.  Never compiled into the
+// product build; the stamps only go to Counters::section_cycles, which nothing else reads.
+#ifdef PINE_PROFILE_SECTIONS
+__device__ unsigned long long g_region_lanes[16], g_region_hits[16];
+// REGION(id): average number of active lanes at a code region's entry (divergence probe)
+#define REGION(id)                                                                  \
+  do {                                                                              \
+    const unsigned long long m_ = __ballot(1);                                      \
+    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m_) - 1) {               \
+      atomicAdd(&g_region_lanes[id], (unsigned long long)__popcll(m_));             \
+      atomicAdd(&g_region_hits[id], 1ull);                                          \
+    }                                                                               \
+  } while (0)
+#define SEC_DECL unsigned long long sec_t = __builtin_readcyclecounter(), sec_acc[16] = {0}
+#define SEC_MARK(id)                                              \
+  do {                                                            \
+    const unsigned long long t_ = __builtin_readcyclecounter();   \
+    sec_acc[id] += t_ - sec_t;                                    \
+    sec_t = t_;                                                   \
+  } while (0)
+#define SEC_FLUSH()                                                                     \
+  do {                                                                                  \
+    if ((threadIdx.x & 63) == 0)                                                        \
+      for (int i_ = 0; i_ < 16; i_++) atomicAdd(&counters->section_cycles[i_], sec_acc[i_]); \
+  } while (0)
+#else
+#define REGION(id)
+#define SEC_DECL
+#define SEC_MARK(id)
+#define SEC_FLUSH()
+#endif
+
 struct DeviceScene {
   const DShape* shapes;
   const DMaterial* materials;
@@ -163,6 +195,7 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
   bool hit = false;
   auto leaf = [&](int start, int count) -> bool {
     for (int i = start; i < start + count; i++) {
+      REGION(ANY ? 5 : 2);  // leaf primitive test
       const int g = S.prims[i];
       const DShape* sh = &S.shapes[g];
       bool is_mesh = false;
@@ -196,6 +229,7 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
   int sp = 0;
   int next = top.root;
   while (true) {
+    REGION(ANY ? 4 : 1);  // top-level node visit
     const DNode* node = &S.nodes[next];
     int l = -1, r = -1;
     float t0 = ray.tmax, t1 = ray.tmax;
@@ -288,26 +322,7 @@ struct Counters {
   unsigned long long section_cycles[16];  // diagnostic builds (-DPINE_PROFILE_SECTIONS) only
 };
 
-// Diagnostic section timing: per-wave s_memtime deltas summed per section.  Never compiled into the
-// product build; the stamps only go to Counters::section_cycles, which nothing else reads.
-#ifdef PINE_PROFILE_SECTIONS
-#define SEC_DECL unsigned long long sec_t = __builtin_readcyclecounter(), sec_acc[16] = {0}
-#define SEC_MARK(id)                                              \
-  do {                                                            \
-    const unsigned long long t_ = __builtin_readcyclecounter();   \
-    sec_acc[id] += t_ - sec_t;                                    \
-    sec_t = t_;                                                   \
-  } while (0)
-#define SEC_FLUSH()                                                                     \
-  do {                                                                                  \
-    if ((threadIdx.x & 63) == 0)                                                        \
-      for (int i_ = 0; i_ < 16; i_++) atomicAdd(&counters->section_cycles[i_], sec_acc[i_]); \
-  } while (0)
-#else
-#define SEC_DECL
-#define SEC_MARK(id)
-#define SEC_FLUSH()
-#endif
+
 
 __device__ __forceinline__ f3 material_le(const DMaterial* m, f3 n, f3 wo) {  // material.h:22-25
   if (m->kind != MAT_EMISSIVE) return mk3(0.0f);
@@ -363,7 +378,11 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.lights = S.lights;
   }
   const unsigned lane_slot = blockIdx.x * kBlock + threadIdx.x;
-  const unsigned fold_stride = gridDim.x * kBlock;
+  // global part of the fold stack: lane-major, one 32-byte entry (two float4) per level, so the
+  // bytes a lane touches are only the levels its paths really reach -- the hot set (~2.6 levels x
+  // 32 B x resident lanes ~ 22 MB chip-wide, 2.7 MB per XCD) stays in the XCD's 4 MB L2, whereas a
+  // [level][field][lane] layout touches all levels of all lanes (58 MB) and thrashes it.
+  float4* const fold_lane = reinterpret_cast<float4*>(fold) + size_t(lane_slot) * 2 * size_t(S.max_path_length);
   // FoldEntry storage: levels < kLdsFoldLevels in LDS ([level][field][lane], conflict-free), deeper
   // levels in a lane-interleaved global array (coalesced across the wave).
   auto fold_store = [&](int level, const float (&e)[8]) {
@@ -374,8 +393,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 #pragma unroll
       for (int i = 0; i < 8; i++) lds_fold[(level * 8 + i) * kBlock] = e[i];
     } else {
-#pragma unroll
-      for (int i = 0; i < 8; i++) fold[(size_t(level - kLdsFoldLevels) * 8 + i) * fold_stride + lane_slot] = e[i];
+      fold_lane[2 * level] = make_float4(e[0], e[1], e[2], e[3]);
+      fold_lane[2 * level + 1] = make_float4(e[4], e[5], e[6], e[7]);
     }
   };
   auto fold_load = [&](int level, float (&e)[8]) {
@@ -387,8 +406,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 #pragma unroll
       for (int i = 0; i < 8; i++) e[i] = lds_fold[(level * 8 + i) * kBlock];
     } else {
-#pragma unroll
-      for (int i = 0; i < 8; i++) e[i] = fold[(size_t(level - kLdsFoldLevels) * 8 + i) * fold_stride + lane_slot];
+      const float4 a = fold_lane[2 * level], b = fold_lane[2 * level + 1];
+      e[0] = a.x, e[1] = a.y, e[2] = a.z, e[3] = a.w, e[4] = b.x, e[5] = b.y, e[6] = b.z, e[7] = b.w;
     }
   };
 
@@ -490,6 +509,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         pool_next += take;
       }
       if (!alive && !lane_done && have_item && s_cur < s_end) {
+        REGION(0);  // camera ray generation
         // start sample s_cur: BlueSobolSampler index = s, dimension = 0 (sampler.h:174-181)
         sampler.index = s_cur;
         sampler.dimension = 0;
@@ -533,6 +553,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if (!hit) {
       terminal = true;  // no environment light (path.cpp:75-81)
     } else {
+      REGION(3);  // surface info
       shape = &V.shapes[geom];
       mat = &V.materials[shape->material];
       const f3 ph = ray_at(ray, ray.tmax);
@@ -554,6 +575,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
     SEC_MARK(3);  // surface info + emissive/terminal test
     if (!terminal) {
+      REGION(6);  // non-terminal shading
       m3 l2w = coordinate_system(it.n);  // interaction.h:14-17
       m3 w2l = transpose(l2w);
       // ---- material.sample_bxdf (material.h:30-131, material.cpp:9-28) ----
@@ -655,6 +677,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             const f3 le = material_le(&V.materials[lshape->material], gs.n, -gs.w);
             if (!is_zero(le)) {
               const float ls_pdf = gs.pdf / float(S.num_lights);
+              REGION(7);  // shadow ray cast
               shadow_count++;
               DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
               int g2, p2;
@@ -709,7 +732,9 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       f3 Li = Lo;
       bool lp_valid = has_light_pdf;
       float lp = light_pdf;
+      REGION(8);  // terminal fold entry
       for (int level = pv_length - 1; level >= 0; level--) {
+        REGION(9);  // fold level
         float e[8];
         fold_load(level, e);
         const f3 e_nee{e[0], e[1], e[2]};
@@ -718,10 +743,12 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const float mis = lp_valid ? balance_heuristic(e_pdf, lp) : 1.0f;
         const f3 lo = e_nee + Li * e_f * (e_cp * mis);
         f3 beta = mk3(1.0f);
-        const unsigned bc = unsigned(beta_flags >> (2 * level)) & 3u;
-        if (bc) {
-          beta = mk3(0.0f);
-          set(beta, int(bc) - 1, 3.0f);
+        if constexpr (F & F_SSS) {
+          const unsigned bc = unsigned(beta_flags >> (2 * level)) & 3u;
+          if (bc) {
+            beta = mk3(0.0f);
+            set(beta, int(bc) - 1, 3.0f);
+          }
         }
         Li = mk3(0.0f) + vmin(mk3(1.0f) * beta * lo, mk3(8.0f));
         lp_valid = false;
@@ -1186,7 +1213,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
 
   if (W.items_per_pixel > 1) HIP_OK(hipMalloc((void**)&p->d_ckpt, W.total_items * sizeof(ulonglong2)));
   HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
-  HIP_OK(hipMalloc((void**)&p->d_fold, size_t(std::max(1, prm->max_path_length - kLdsFoldLevels)) * 8 * size_t(p->grid) * kBlock * sizeof(float)));
+  HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * size_t(p->grid) * kBlock * sizeof(float)));
   HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
   p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
   if (p->timed)
@@ -1291,6 +1318,13 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
   Counters c;
   HIP_OK(hipMemcpy(&c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; i++) out[i] = c.section_cycles[i];
+#ifdef PINE_PROFILE_SECTIONS
+  unsigned long long rl[16], rh[16];
+  HIP_OK(hipMemcpyFromSymbol(rl, HIP_SYMBOL(g_region_lanes), sizeof rl));
+  HIP_OK(hipMemcpyFromSymbol(rh, HIP_SYMBOL(g_region_hits), sizeof rh));
+  for (int i = 0; i < 16; i++)
+    if (rh[i]) fprintf(stderr, "region %2d: entries %llu avg active lanes %.2f\n", i, rh[i], double(rl[i]) / double(rh[i]));
+#endif
   return 0;
 }
 
