@@ -129,7 +129,6 @@ struct DSampler {
   int px, py;
   int index;      // sample index within the pixel
   int dimension;  // BlueSobolSampler::dimension
-  DRng rng;
 };
 template <bool LDS = false>
 PINE_HD float sampler_get1d(const DTables& t, DSampler& s) {  // sampler.h:183-187
@@ -146,10 +145,10 @@ PINE_HD f2 sampler_get2d(const DTables& t, DSampler& s) {  // sampler.h:188-194
   return f2{a, b};
 }
 // with_probability (sampler.h:317-324): consumes an RNG float only for prob strictly in (0,1)
-PINE_HD bool with_probability(float prob, DSampler& s) {
+PINE_HD bool with_probability(float prob, DRng& g) {
   if (prob == 0) return false;
   if (prob == 1) return true;
-  return rng_nextf(s.rng) < prob;
+  return rng_nextf(g) < prob;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -158,7 +157,9 @@ PINE_HD bool with_probability(float prob, DSampler& s) {
 PINE_HD f2 sample_disk_polar(f2 u) {
   const float r = psqrt(u.x);
   const float theta = 2 * kPi * u.y;
-  return f2{r * pcos(theta), r * psin(theta)};
+  float sn, cs;
+  psincos(theta, sn, cs);
+  return f2{r * cs, r * sn};
 }
 PINE_HD f2 sample_disk_concentric(f2 u) {
   u = f2{u.x * 2 - 1.0f, u.y * 2 - 1.0f};
@@ -170,7 +171,9 @@ PINE_HD f2 sample_disk_concentric(f2 u) {
     r = u.y;
     theta = kPi / 2.0f - kPi / 4.0f * (u.x / u.y);
   }
-  return r * f2{pcos(theta), psin(theta)};
+  float sn, cs;
+  psincos(theta, sn, cs);
+  return r * f2{cs, sn};
 }
 PINE_HD f3 cosine_weighted_hemisphere(f2 u) {
   const f2 d = sample_disk_concentric(u);
@@ -181,7 +184,9 @@ PINE_HD f3 uniform_sphere(f2 u) {
   const float phi = u.x * kPi * 2;
   const float cos_theta = 1 - 2 * u.y;
   const float sin_theta = psqrt(1.0f - sqr(cos_theta));
-  return f3{sin_theta * pcos(phi), sin_theta * psin(phi), cos_theta};
+  float sn, cs;
+  psincos(phi, sn, cs);
+  return f3{sin_theta * cs, sin_theta * sn, cos_theta};
 }
 PINE_HD float balance_heuristic(float pF, float pG) { return pF / (pF + pG); }
 
@@ -310,7 +315,16 @@ PINE_HD bool rect_test(const float* f, const DRay& ray, float& t_out) {
   const f3 position = ld3(f), n = ld3(f + 9);
   const float denom = dot(ray.d, n);
   if (denom == 0.0f) return false;
-  const float t = (dot(position - ray.o, n)) / denom;
+  const float num = dot(position - ray.o, n);
+  // Exact shortcuts that spare the 11-instruction IEEE division for planes that cannot be hit:
+  //  * every ray on this path has tmin == 0, so a quotient that is negative or zero fails
+  //    `t <= tmin`: decided by the operands' signs alone (NaNs fall through to the division);
+  //  * |num| > |denom| * tmax * (1 + 2^-20) implies the rounded quotient is >= tmax.
+  if (ray.tmin == 0.0f) {
+    if (num == 0.0f || (num < 0.0f && denom > 0.0f) || (num > 0.0f && denom < 0.0f)) return false;
+    if (pabs(num) > pabs(denom) * ray.tmax * 1.00000095367431640625f) return false;
+  }
+  const float t = num / denom;
   if (t <= ray.tmin || t >= ray.tmax) return false;
   const f3 p = ray_at(ray, t) - position;
   const float u = dot(p, ld3(f + 14));
@@ -727,6 +741,7 @@ enum BxdfKind : int { BX_DIFFUSE, BX_CONDUCTOR, BX_REFRACTIVE, BX_REFR_DIEL, BX_
 struct DBxdf {
   int kind;
   f3 albedo;
+  f3 albedo_over_pi;  // albedo / Pi precomputed on the host (identical IEEE division)
   float roughness, ior;
   f3 wi;  // local frame
 };
@@ -755,7 +770,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       if (CosTheta(wi) < 0) wo = -wo;
       bs.wo = wo;
       bs.pdf = AbsCosTheta(wo) / kPi;
-      bs.f = b.albedo / kPi;
+      bs.f = b.albedo_over_pi;
       return true;
     }
     case BX_CONDUCTOR: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:39-64
@@ -867,7 +882,7 @@ PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DB
       if (CosTheta(wi) > 0) wo = -wo;
       bs.wo = wo;
       bs.pdf = AbsCosTheta(wo) / kPi;
-      bs.f = b.albedo / kPi;
+      bs.f = b.albedo_over_pi;
       return true;
     }
   }
@@ -879,7 +894,7 @@ PINE_HD f3 bxdf_f(const DBxdf& b, f3 wo) {
   switch (b.kind) {
     case BX_DIFFUSE:  // bxdf.cpp:24-28
       if (!SameHemisphere(wi, wo)) return mk3(0.0f);
-      return b.albedo / kPi;
+      return b.albedo_over_pi;
     case BX_CONDUCTOR: if constexpr (!(F & F_UBER)) __builtin_unreachable(); else {  // bxdf.cpp:65-79
       if (!SameHemisphere(wi, wo)) return mk3(0.0f);
       const float alpha = sqr(b.roughness);
@@ -925,7 +940,7 @@ PINE_HD f3 bxdf_f(const DBxdf& b, f3 wo) {
       const float reflected = fr * tr_D_G(d, wo, wm, wi) / pabs(4 * cosThetaI * cosThetaO);
       return mk3(reflected) + diffused;
     }
-    case BX_BSSRDF: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else { return b.albedo / kPi; }  // bxdf.cpp:368-370
+    case BX_BSSRDF: if constexpr (!(F & F_SSS)) __builtin_unreachable(); else { return b.albedo_over_pi; }  // bxdf.cpp:368-370
   }
   return mk3(0.0f);
 }

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 
 #include "../../include/pine_gpu.h"
 
@@ -139,7 +140,9 @@ int SceneHost::find_material(const char* name) const {
     if (material_names[i] == name) return i;
   return -1;
 }
-int SceneHost::add_material(const char* name, const DMaterial& m, const std::string& desc) {
+int SceneHost::add_material(const char* name, const DMaterial& m_, const std::string& desc) {
+  DMaterial m = m_;
+  for (int i = 0; i < 3; i++) m.color_over_pi[i] = m.color[i] / kPi;
   materials.push_back(m);
   material_names.push_back(name ? name : "");
   material_describe.push_back(desc);

@@ -330,36 +330,64 @@ __device__ __forceinline__ f3 material_le(const DMaterial* m, f3 n, f3 wo) {  //
   return ld3(m->color);
 }
 
+// LDS layout of the path kernel (dword offsets; everything per-lane is [slot][thread], so a wave's
+// accesses are bank-conflict free and one VGPR (thread id) + an immediate offset addresses all of it):
+//   fold level(s)   kLdsFoldLevels * 8 x 256      FoldEntry fields of the shallowest level(s)
+//   sampler slices  12 x 256                      40 ranking + 8 scrambling bytes of the lane's pixel
+//   RNG state       4 x 256                       per-pixel xoroshiro state (only touched at sample start)
+//   Sobol rows      40 x 256 bytes                transposed table, dimensions < 40
+//   traversal stack stack_total x 256             (runtime depth)
+//   scene blob      blob_bytes                    nodes | shapes | materials | bvhs | prims | lights
+constexpr int kOffFold = 0;
+constexpr int kOffTile = kLdsFoldLevels * 8 * kBlock;
+constexpr int kOffRng = kOffTile + kLdsTileDwords * kBlock;
+constexpr int kOffSobol = kOffRng + 4 * kBlock;
+constexpr int kOffStack = kOffSobol + kLdsSamplerDims * 256 / 4;
+constexpr size_t kLdsFixedBytes = size_t(kOffStack) * 4;
+
+// Packed per-lane path bookkeeping (one VGPR):
+//   bits 0-8 sample index within the pixel (= BlueSobolSampler::index), 9-17 sampler dimension,
+//   18-23 Vertex::length, 24-29 Vertex::diffuse_length, 30 Vertex::is_delta
+struct PackedState {
+  unsigned v;
+  __device__ __forceinline__ int s_cur() const { return int(v & 0x1ffu); }
+  __device__ __forceinline__ int dim() const { return int((v >> 9) & 0x1ffu); }
+  __device__ __forceinline__ int length() const { return int((v >> 18) & 0x3fu); }
+  __device__ __forceinline__ int diffuse_length() const { return int((v >> 24) & 0x3fu); }
+  __device__ __forceinline__ bool is_delta() const { return (v >> 30) & 1u; }
+  __device__ __forceinline__ void set_dim(int d) { v = (v & ~(0x1ffu << 9)) | (unsigned(d) << 9); }
+  __device__ __forceinline__ void start_sample(int s) { v = unsigned(s) | (1u << 30); }  // dim 0, first_vertex()
+  __device__ __forceinline__ void next_vertex(bool delta) {  // Vertex(pv, pdf, is_delta) path.cpp:18-19
+    v = (v & 0x3ffffu) + ((unsigned(length()) + 1u) << 18) + ((unsigned(diffuse_length()) + (delta ? 0u : 1u)) << 24) +
+        (delta ? (1u << 30) : 0u);
+  }
+};
+
 template <unsigned F, int WAVES_PER_SIMD>
 __global__ void __launch_bounds__(kBlock, WAVES_PER_SIMD)
 path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, Counters* __restrict__ counters) {
-  // dynamic LDS: [fold levels 0..3: 8 fields x 256 lanes each][traversal stack][scene blob]
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-  //              [sampler lane slices: 12 dwords x 256 lanes][Sobol rows of dims < 40][scene blob]
-  float* lds_fold = reinterpret_cast<float*>(lds_raw) + threadIdx.x;
-  int* lds_stack0 = lds_raw + kLdsFoldLevels * 8 * kBlock;
-  int* stack = lds_stack0 + threadIdx.x;
-  uint32_t* lds_tile = reinterpret_cast<uint32_t*>(lds_stack0 + S.stack_total * kBlock) + threadIdx.x;
-  uint8_t* lds_sobol = reinterpret_cast<uint8_t*>(lds_stack0 + (S.stack_total + kLdsTileDwords) * kBlock);
-  int* lds_rest = lds_stack0 + (S.stack_total + kLdsTileDwords) * kBlock + kLdsSamplerDims * 256 / 4;
+  const unsigned tid = threadIdx.x;
+  float* const lds_f = reinterpret_cast<float*>(lds_raw);
+  uint32_t* const lds_u = reinterpret_cast<uint32_t*>(lds_raw);
+  int* const stack = lds_raw + kOffStack + tid;
   {
     const uint4* src = reinterpret_cast<const uint4*>(S.tables.sobol);
-    uint4* dst = reinterpret_cast<uint4*>(lds_sobol);
-    for (int i = threadIdx.x; i < kLdsSamplerDims * 256 / 16; i += kBlock) dst[i] = src[i];
+    uint4* dst = reinterpret_cast<uint4*>(lds_raw + kOffSobol);
+    for (int i = tid; i < kLdsSamplerDims * 256 / 16; i += kBlock) dst[i] = src[i];
   }
   DTables T = S.tables;
-  T.lds_sobol = lds_sobol;
-  T.lds_tile = lds_tile;
+  T.lds_sobol = reinterpret_cast<const uint8_t*>(lds_raw + kOffSobol);
+  T.lds_tile = lds_u + kOffTile + tid;
   SceneView V;
   V.tri_verts = S.tri_verts;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
   if constexpr (F & F_LDS_SCENE) {
-    // stage the scene blob behind the traversal stack (stack_total * 1 KiB keeps 16-byte alignment)
-    uint4* dst = reinterpret_cast<uint4*>(lds_rest);
+    uint4* dst = reinterpret_cast<uint4*>(lds_raw + kOffStack + S.stack_total * kBlock);
     const int n16 = S.blob_bytes >> 4;
-    for (int i = threadIdx.x; i < n16; i += kBlock) dst[i] = S.blob[i];
+    for (int i = tid; i < n16; i += kBlock) dst[i] = S.blob[i];
     __syncthreads();
     const char* base = reinterpret_cast<const char*>(dst);
     V.nodes = reinterpret_cast<const DNode*>(base + S.off_nodes);
@@ -377,24 +405,24 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.prims = S.prims;
     V.lights = S.lights;
   }
-  const unsigned lane_slot = blockIdx.x * kBlock + threadIdx.x;
-  // global part of the fold stack: lane-major, one 32-byte entry (two float4) per level, so the
+  // Global part of the fold stack: lane-major, one 32-byte entry (two float4) per level, so the
   // bytes a lane touches are only the levels its paths really reach -- the hot set (~2.6 levels x
   // 32 B x resident lanes ~ 22 MB chip-wide, 2.7 MB per XCD) stays in the XCD's 4 MB L2, whereas a
   // [level][field][lane] layout touches all levels of all lanes (58 MB) and thrashes it.
-  float4* const fold_lane = reinterpret_cast<float4*>(fold) + size_t(lane_slot) * 2 * size_t(S.max_path_length);
-  // FoldEntry storage: levels < kLdsFoldLevels in LDS ([level][field][lane], conflict-free), deeper
-  // levels in a lane-interleaved global array (coalesced across the wave).
+  auto fold_entry = [&](int level) -> float4* {
+    return reinterpret_cast<float4*>(fold) + (size_t(blockIdx.x * kBlock + tid) * size_t(S.max_path_length) + size_t(level)) * 2;
+  };
   auto fold_store = [&](int level, const float (&e)[8]) {
 #ifdef PINE_ABL_FOLD
     return;
 #endif
     if (level < kLdsFoldLevels) {
 #pragma unroll
-      for (int i = 0; i < 8; i++) lds_fold[(level * 8 + i) * kBlock] = e[i];
+      for (int i = 0; i < 8; i++) lds_f[kOffFold + (level * 8 + i) * kBlock + tid] = e[i];
     } else {
-      fold_lane[2 * level] = make_float4(e[0], e[1], e[2], e[3]);
-      fold_lane[2 * level + 1] = make_float4(e[4], e[5], e[6], e[7]);
+      float4* q = fold_entry(level);
+      q[0] = make_float4(e[0], e[1], e[2], e[3]);
+      q[1] = make_float4(e[4], e[5], e[6], e[7]);
     }
   };
   auto fold_load = [&](int level, float (&e)[8]) {
@@ -404,34 +432,42 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 #endif
     if (level < kLdsFoldLevels) {
 #pragma unroll
-      for (int i = 0; i < 8; i++) e[i] = lds_fold[(level * 8 + i) * kBlock];
+      for (int i = 0; i < 8; i++) e[i] = lds_f[kOffFold + (level * 8 + i) * kBlock + tid];
     } else {
-      const float4 a = fold_lane[2 * level], b = fold_lane[2 * level + 1];
+      const float4* q = fold_entry(level);
+      const float4 a = q[0], b = q[1];
       e[0] = a.x, e[1] = a.y, e[2] = a.z, e[3] = a.w, e[4] = b.x, e[5] = b.y, e[6] = b.z, e[7] = b.w;
     }
   };
+  // the per-pixel RNG lives in LDS: it is only touched when a sample starts (4 draws, path.cpp:35)
+  // and by the few material branches that draw from it inside radiance()
+  auto rng_load = [&]() -> DRng {
+    const uint32_t a = lds_u[kOffRng + tid], b = lds_u[kOffRng + kBlock + tid], c = lds_u[kOffRng + 2 * kBlock + tid],
+                   d = lds_u[kOffRng + 3 * kBlock + tid];
+    return DRng{uint64_t(a) | (uint64_t(b) << 32), uint64_t(c) | (uint64_t(d) << 32)};
+  };
+  auto rng_store = [&](const DRng& g) {
+    lds_u[kOffRng + tid] = uint32_t(g.s0);
+    lds_u[kOffRng + kBlock + tid] = uint32_t(g.s0 >> 32);
+    lds_u[kOffRng + 2 * kBlock + tid] = uint32_t(g.s1);
+    lds_u[kOffRng + 3 * kBlock + tid] = uint32_t(g.s1 >> 32);
+  };
 
-  // ---- lane state ----
-  bool lane_done = false;   // queue exhausted for this lane
+  // ---- lane state (kept small on purpose: the kernel sits at the 128-VGPR / 4-waves-per-SIMD edge) ----
+  bool lane_done = false;  // queue exhausted for this lane
   bool have_item = false;
-  bool alive = false;       // a path is in flight
-  int s_cur = 0, s_end = 0;
-  unsigned long long sample_base = 0;
-  DSampler sampler;
-  sampler.px = sampler.py = sampler.index = sampler.dimension = 0;
-  sampler.rng = DRng{0, 0};
-  DRay ray;
-  ray.o = ray.d = mk3(0.0f);
-  ray.tmin = 0;
-  ray.tmax = 0;
-  int pv_length = 0, pv_diffuse_length = 0;
-  bool pv_is_delta = true;
-  unsigned long long beta_flags = 0;  // 2 bits per level: 0 = beta (1,1,1); 1..3 = beta 3 on channel-1 (BSSRDF)
-  unsigned vcount = 0;      // radiance() invocations of the current sample
-  unsigned long long shadow_count = 0, vertex_count = 0;
+  bool alive = false;      // a path is in flight
+  f3 ray_o = mk3(0.0f), ray_d = mk3(0.0f);
+  float ray_tmax = 0.0f;   // every ray on this path has tmin == 0
+  unsigned pxy = 0;        // px | py << 16
+  unsigned sample_base = 0;
+  PackedState st{0};
+  unsigned shadow_count = 0;
+  unsigned long long beta_flags = 0;  // 2 bits per level (BSSRDF beta channel); dead code without F_SSS
   // wave-uniform private item pool [pool_next, pool_end)
   unsigned long long pool_next = 0, pool_end = 0;
   bool queue_empty = false;
+  const int kspi = W.samples_per_item;
 
   SEC_DECL;
   while (true) {
@@ -443,20 +479,17 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     // (A per-iteration wave-aggregated atomic on one word saturates at ~90 M dequeues/s chip-wide,
     // MI355X_MICROARCH.md "dequeue" -- that was the first bottleneck measured.)
     {
-      bool need_item = !alive && !lane_done && !(have_item && s_cur < s_end);
+      bool need_item = !alive && !lane_done && !have_item;
       while (true) {
         const unsigned long long mask = __ballot(need_item);
         if (mask == 0) break;
         if (pool_next == pool_end) {
           if (queue_empty) {
-            if (need_item) {
-              lane_done = true;
-              have_item = false;
-            }
+            if (need_item) lane_done = true;
             break;
           }
           unsigned long long base = 0;
-          if ((threadIdx.x & 63) == 0) base = atomicAdd(&counters->next_item, (unsigned long long)kPoolItems);
+          if ((tid & 63) == 0) base = atomicAdd(&counters->next_item, (unsigned long long)kPoolItems);
           base = __shfl(base, 0);
           if (base >= W.total_items) {
             queue_empty = true;
@@ -466,7 +499,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           }
           continue;
         }
-        const unsigned lane = threadIdx.x & 63;
+        const unsigned lane = tid & 63;
         const unsigned rank = __popcll(mask & ((1ull << lane) - 1ull));
         const unsigned long long avail = pool_end - pool_next;
         const unsigned want = __popcll(mask);
@@ -477,8 +510,9 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           const ItemInfo it = decode_item(W, S.cam.W, S.cam.H, S.spp, item);
           if (it.valid) {
             have_item = true;
-            sampler.px = it.px;
-            sampler.py = it.py;
+            pxy = unsigned(it.px) | (unsigned(it.py) << 16);
+            st.start_sample(it.chunk * kspi);
+            sample_base = unsigned(it.sample_base);
             {
               // refresh this lane's sampler slice: 40 ranking bytes + 8 scrambling bytes of the pixel
               const int pix = (it.px & 127) + (it.py & 127) * 128;
@@ -487,44 +521,40 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 #pragma unroll
               for (int j = 0; j < 5; j++) {
                 const uint2 r = rsrc[j];
-                lds_tile[(2 * j) * kBlock] = r.x;
-                lds_tile[(2 * j + 1) * kBlock] = r.y;
+                lds_u[kOffTile + (2 * j) * kBlock + tid] = r.x;
+                lds_u[kOffTile + (2 * j + 1) * kBlock + tid] = r.y;
               }
-              lds_tile[10 * kBlock] = sc.x;
-              lds_tile[11 * kBlock] = sc.y;
+              lds_u[kOffTile + 10 * kBlock + tid] = sc.x;
+              lds_u[kOffTile + 11 * kBlock + tid] = sc.y;
             }
-            s_cur = it.chunk * W.samples_per_item;
-            s_end = s_cur + W.samples_per_item;
-            sample_base = it.sample_base;
             if (W.items_per_pixel == 1) {
-              sampler.rng = rng_seed(hash_pixel(it.px, it.py, 0));  // Sampler::start_pixel
+              rng_store(rng_seed(hash_pixel(it.px, it.py, 0)));  // Sampler::start_pixel
             } else {
               const ulonglong2 c = ckpt[item];
-              sampler.rng = DRng{c.x, c.y};
+              rng_store(DRng{c.x, c.y});
             }
-          } else {
-            have_item = false;  // pixel outside the film (partial border tile): ask again next trip
-          }
+          }  // else: pixel outside the film (partial border tile): ask again next trip
         }
         pool_next += take;
       }
-      if (!alive && !lane_done && have_item && s_cur < s_end) {
+      if (!alive && !lane_done && have_item) {
         REGION(0);  // camera ray generation
         // start sample s_cur: BlueSobolSampler index = s, dimension = 0 (sampler.h:174-181)
-        sampler.index = s_cur;
-        sampler.dimension = 0;
+        st.start_sample(st.s_cur());
+        const int px = int(pxy & 0xffffu), py = int(pxy >> 16);
         // g++ evaluates gen_ray's arguments right to left (path.cpp:35): lens first, then jitter
-        const float lx = rng_nextf(sampler.rng);
-        const float ly = rng_nextf(sampler.rng);
-        const float jx = rng_nextf(sampler.rng);
-        const float jy = rng_nextf(sampler.rng);
-        const f2 pf{(float(sampler.px) + jx) / float(S.cam.W), (float(sampler.py) + jy) / float(S.cam.H)};
-        ray = camera_gen_ray(S.cam, pf, f2{lx, ly});
-        pv_length = 0;
-        pv_diffuse_length = 0;
-        pv_is_delta = true;
-        beta_flags = 0;
-        vcount = 0;
+        DRng g = rng_load();
+        const float lx = rng_nextf(g);
+        const float ly = rng_nextf(g);
+        const float jx = rng_nextf(g);
+        const float jy = rng_nextf(g);
+        rng_store(g);
+        const f2 pf{(float(px) + jx) / float(S.cam.W), (float(py) + jy) / float(S.cam.H)};
+        const DRay r = camera_gen_ray(S.cam, pf, f2{lx, ly});
+        ray_o = r.o;
+        ray_d = r.d;
+        ray_tmax = r.tmax;
+        if constexpr (F & F_SSS) beta_flags = 0;
         alive = true;
       }
     }
@@ -533,10 +563,19 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if (!alive) continue;
 
     // ---------------- one radiance() invocation (path.cpp:42-124) ----------------
-    vcount++;
-    const f3 wi = -ray.d;
+    DSampler sampler;
+    sampler.px = int(pxy & 0xffffu);
+    sampler.py = int(pxy >> 16);
+    sampler.index = st.s_cur();
+    sampler.dimension = st.dim();
+    const int pv_length = st.length();
     int geom = -1, prim = 0;
-    const bool hit = scene_traverse<false, F>(V, ray, stack, geom, prim);
+    bool hit;
+    {
+      DRay ray{ray_o, ray_d, 0.0f, ray_tmax};
+      hit = scene_traverse<false, F>(V, ray, stack, geom, prim);
+      ray_tmax = ray.tmax;
+    }
     SEC_MARK(2);  // closest-hit traversal
 
     // terminal result of this vertex, if it terminates
@@ -556,16 +595,18 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       REGION(3);  // surface info
       shape = &V.shapes[geom];
       mat = &V.materials[shape->material];
-      const f3 ph = ray_at(ray, ray.tmax);
+      const f3 ph = ray_o + ray_tmax * ray_d;
       bool on_mesh = false;
       if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
       if (on_mesh) tri_surface_info(V.tri_verts + size_t(prim) * 9, ph, it);
       else shape_surface_info<F>(shape, ph, it);
       if (mat->kind == MAT_EMISSIVE) {  // path.cpp:83-87
-        Lo = mk3(1.0f) * material_le(mat, it.n, wi);
-        if (!pv_is_delta) {
+        Lo = mk3(1.0f) * material_le(mat, it.n, -ray_d);
+        if (!st.is_delta()) {
           has_light_pdf = true;
-          light_pdf = shape_pdf<F>(shape, ray, it.n) / float(size_t(S.num_lights));  // lightsampler.cpp:27-29
+          const DRay ray{ray_o, ray_d, 0.0f, ray_tmax};
+          light_pdf = shape_pdf<F>(shape, ray, it.n);  // lightsampler.cpp:27-29: / lights.size()
+          if (S.num_lights != 1) light_pdf = light_pdf / float(size_t(S.num_lights));  // x / 1.0f == x exactly
         }
         terminal = true;
       } else if (pv_length + 1 >= S.max_path_length) {  // path.cpp:89
@@ -576,24 +617,25 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     SEC_MARK(3);  // surface info + emissive/terminal test
     if (!terminal) {
       REGION(6);  // non-terminal shading
+      const f3 wi = -ray_d;
       m3 l2w = coordinate_system(it.n);  // interaction.h:14-17
       m3 w2l = transpose(l2w);
       // ---- material.sample_bxdf (material.h:30-131, material.cpp:9-28) ----
-      const bool diffused = pv_diffuse_length > 0;
+      const bool diffused = st.diffuse_length() > 0;
       const float min_roughness = diffused ? 0.6f : 0.0f;  // bxdf.h:15
       DBxdf bx;
       bx.kind = BX_DIFFUSE;
-      bx.albedo = ld3(mat->color);
       bx.roughness = 0.0f;
       bx.ior = 1.0f;
       bool is_uber = false, is_sss = false;
       if constexpr (F & F_UBER) is_uber = mat->kind == MAT_UBER;
       if constexpr (F & F_SSS) is_sss = mat->kind == MAT_SUBSURFACE;
       if (is_uber) {
-        if (with_probability(mat->metallic, sampler)) {
+        DRng g = rng_load();
+        if (with_probability(mat->metallic, g)) {
           bx.kind = BX_CONDUCTOR;
           bx.roughness = mat->roughness;
-        } else if (with_probability(mat->transmission, sampler)) {
+        } else if (with_probability(mat->transmission, g)) {
           bx.kind = BX_REFR_DIEL;
           bx.roughness = mat->roughness;
           bx.ior = mat->ior;
@@ -602,6 +644,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           bx.roughness = mat->roughness;
           bx.ior = mat->ior;
         }
+        rng_store(g);
       } else if (is_sss) {
         const float fr = FrDielectric(dot(wi, it.n), mat->ior);
         if (sampler_get1d<true>(T, sampler) < fr) {
@@ -625,7 +668,9 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         f3 p = it.p;
         f3 w = -wi;
         if (Refract(wi, it.n, bx.ior, w, nullptr)) {
-          const int channel = int(rng_nextf(sampler.rng) * 3);
+          DRng g = rng_load();
+          const int channel = int(rng_nextf(g) * 3);
+          rng_store(g);
           const float sigma_t_inv = 1 / mat->sigma_s[channel];
           const f3 n0 = it.n;
           for (int i = 0;; i++) {
@@ -668,15 +713,15 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const f2 u2 = sampler_get2d<true>(T, sampler);
         float u1 = sampler_get1d<true>(T, sampler);
         if (S.num_lights > 0) {  // UniformLightSampler::sample lightsampler.cpp:12-26
-          u1 *= float(S.num_lights);
+          if (S.num_lights != 1) u1 *= float(S.num_lights);  // x * 1.0f == x exactly
           const int index = int(u1);
           const DShape* lshape = &V.shapes[V.lights[index]];
           DShapeSample gs;
           if (shape_sample<F>(lshape, V.tri_verts, it.p, u2, u1 - float(index), gs)) {
             // AreaLight::sample light.cpp:55-69
-            const f3 le = material_le(&V.materials[lshape->material], gs.n, -gs.w);
-            if (!is_zero(le)) {
-              const float ls_pdf = gs.pdf / float(S.num_lights);
+            const DMaterial* lmat = &V.materials[lshape->material];
+            if (!is_zero(material_le(lmat, gs.n, -gs.w))) {
+              const float ls_pdf = S.num_lights != 1 ? gs.pdf / float(S.num_lights) : gs.pdf;
               REGION(7);  // shadow ray cast
               shadow_count++;
               DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
@@ -689,6 +734,11 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 #endif
               SEC_MARK(6);  // shadow traversal
               if (!occluded) {
+                // the material records are re-read here instead of being kept in registers across
+                // the traversal (le is the emitter's colour: the one-sided test passed above)
+                const f3 le = ld3(lmat->color);
+                bx.albedo = ld3(mat->color);
+                bx.albedo_over_pi = ld3(mat->color_over_pi);
                 const float cosine = absdot(gs.w, it.n);
                 const f3 wo = mul(w2l, gs.w);
                 const f3 f = bxdf_f<F>(bx, wo);
@@ -702,6 +752,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
       SEC_MARK(7);  // NEE evaluation (and light sampling of lanes without a shadow ray)
       // ---- BSDF sampling + continuation (path.cpp:114-120) ----
+      bx.albedo = ld3(mat->color);
+      bx.albedo_over_pi = ld3(mat->color_over_pi);
       DBsdfSample bs;
       if (bxdf_sample<F, true>(bx, T, sampler, bs)) {
         const f3 wo_world = mul(l2w, bs.wo);
@@ -709,11 +761,14 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const int level = pv_length;
         const float entry[8] = {nee.x, nee.y, nee.z, bs.f.x, bs.f.y, bs.f.z, cosine / bs.pdf, bs.pdf};
         fold_store(level, entry);
-        beta_flags = (beta_flags & ~(3ull << (2 * level))) | ((unsigned long long)beta_channel << (2 * level));
-        ray = spawn_ray(it.p, it.n, wo_world, kFloatMax);
-        pv_length = level + 1;
-        pv_diffuse_length += bs.is_delta ? 0 : 1;
-        pv_is_delta = bs.is_delta;
+        if constexpr (F & F_SSS)
+          beta_flags = (beta_flags & ~(3ull << (2 * level))) | ((unsigned long long)beta_channel << (2 * level));
+        const DRay nr = spawn_ray(it.p, it.n, wo_world, kFloatMax);
+        ray_o = nr.o;
+        ray_d = nr.d;
+        ray_tmax = nr.tmax;
+        st.set_dim(sampler.dimension);
+        st.next_vertex(bs.is_delta);
       } else {
         // no continuation: this vertex resolves now with lo = nee (path.cpp:121)
         f3 beta = mk3(1.0f);
@@ -733,7 +788,11 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       bool lp_valid = has_light_pdf;
       float lp = light_pdf;
       REGION(8);  // terminal fold entry
+#ifdef PINE_ABL_FOLDLOOP
+      for (int level = -1; level >= 0; level--) {
+#else
       for (int level = pv_length - 1; level >= 0; level--) {
+#endif
         REGION(9);  // fold level
         float e[8];
         fold_load(level, e);
@@ -753,24 +812,21 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         Li = mk3(0.0f) + vmin(mk3(1.0f) * beta * lo, mk3(8.0f));
         lp_valid = false;
       }
-      samples[sample_base + (unsigned long long)s_cur * 64ull] = make_float4(Li.x, Li.y, Li.z, float(vcount));
-      vertex_count += vcount;
-      s_cur++;
+      // .w = radiance() invocations of this sample (= depth reached + 1); resolve_kernel sums them
+      const int s_now = st.s_cur();
+      samples[size_t(sample_base) + size_t(s_now) * 64u] = make_float4(Li.x, Li.y, Li.z, float(pv_length + 1));
+      st.v = unsigned(s_now + 1);
+      if (((s_now + 1) & (kspi - 1)) == 0) have_item = false;  // item = kspi consecutive samples, kspi a power of two
       alive = false;
     }
     SEC_MARK(9);  // fold + sample store
   }
 
   SEC_FLUSH();
-  // per-wave reduction of the counters, one atomic per wave
-  for (int off = 32; off > 0; off >>= 1) {
-    vertex_count += __shfl_down(vertex_count, off);
-    shadow_count += __shfl_down(shadow_count, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&counters->vertices, vertex_count);
-    atomicAdd(&counters->shadow_rays, shadow_count);
-  }
+  // per-wave reduction of the shadow-ray counter, one atomic per wave
+  unsigned long long sc = shadow_count;
+  for (int off = 32; off > 0; off >>= 1) sc += __shfl_down(sc, off);
+  if ((tid & 63) == 0) atomicAdd(&counters->shadow_rays, sc);
 }
 
 // Compiled specialisations, most specific first.
@@ -802,7 +858,8 @@ constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 // Ordered per-pixel sum: film[p] = (sum_{s=0..spp-1, in order} L_s) / spp  (path.cpp:34-38).
 // One wave per tile, lane = pixel in tile: every sample row is one coalesced 1 KiB read.
 __global__ void __launch_bounds__(kBlock) resolve_kernel(WorkParams W, int film_w, int film_h, int spp,
-                                                        const float4* __restrict__ samples, float4* __restrict__ film) {
+                                                        const float4* __restrict__ samples, float4* __restrict__ film,
+                                                        Counters* __restrict__ counters) {
   const unsigned long long t = blockIdx.x * (unsigned long long)kBlock + threadIdx.x;
   const int ltile = int(t >> 6);
   if (ltile >= W.num_local_tiles) return;
@@ -812,12 +869,17 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(WorkParams W, int film_
   if (px >= film_w || py >= film_h) return;
   const float4* row = samples + (unsigned long long)ltile * (unsigned)spp * 64ull + p;
   f3 L = mk3(0.0f);
+  unsigned long long verts = 0;
   for (int s = 0; s < spp; s++) {
     const float4 v = row[(unsigned long long)s * 64ull];
     L = L + f3{v.x, v.y, v.z};
+    verts += (unsigned long long)v.w;
   }
   const f3 m = L / float(spp);
   film[size_t(py) * film_w + px] = make_float4(m.x, m.y, m.z, 1.0f);
+  // radiance() invocation count of the launch (the unit of the roofline's algorithmic bytes)
+  for (int off = 32; off > 0; off >>= 1) verts += __shfl_down(verts, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&counters->vertices, verts);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -841,7 +903,6 @@ __global__ void test_sampler_kernel(DTables T, int spp, float* out) {
   s.py = kTestPixels[pix][1];
   s.dimension = 0;
   s.index = 0;
-  s.rng = DRng{0, 0};
   size_t k = 0;
   for (int i = 0; i < spp; i++) {
     for (int d = 0; d < 130; d++) {
@@ -1129,8 +1190,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   S.stack_top = d_top;
   S.stack_total = std::max(1, d_top + d_mesh);
-  p->lds_bytes = size_t(kLdsFoldLevels * 8 + S.stack_total + kLdsTileDwords) * kBlock * sizeof(int) +
-                 size_t(kLdsSamplerDims) * 256;
+  p->lds_bytes = kLdsFixedBytes + size_t(S.stack_total) * kBlock * sizeof(int);
   if (p->lds_bytes > 64 * 1024) {
     set_error("BVH too deep for the LDS traversal stack");
     return -1;
@@ -1184,7 +1244,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (in_path_rng) kspi = spp;
   else if (kspi <= 0) kspi = std::min(spp, 4);
   if (kspi > spp) kspi = spp;
-  while (spp % kspi) kspi--;  // spp is a power of two; keep k a divisor
+  {  // spp is a power of two; k must be a power of two dividing it
+    int k2 = 1;
+    while (k2 * 2 <= kspi) k2 *= 2;
+    kspi = k2;
+  }
 
   WorkParams& W = p->W;
   p->film_w = H.camera.W;
@@ -1260,7 +1324,7 @@ int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_) {
   {
     const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
     hipLaunchKernelGGL(resolve_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, p->W,
-                       p->film_w, p->film_h, p->S.spp, p->d_samples, (float4*)film_dev);
+                       p->film_w, p->film_h, p->S.spp, p->d_samples, (float4*)film_dev, p->d_counters);
   }
   if (p->timed) HIP_OK(hipEventRecord(p->ev[3], stream));
   HIP_OK(hipGetLastError());

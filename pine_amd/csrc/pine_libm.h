@@ -121,4 +121,35 @@ PINE_HD float cosf_glibc(float y) {
   return sin_poly(x * sign, x * x, n ^ 1, csign);
 }
 
+// sin and cos of the same argument with one shared range reduction (the two results are exactly
+// sinf_glibc(y) and cosf_glibc(y): same reduction, same polynomials).
+PINE_HD void sincosf_glibc(float y, float& sn, float& cs) {
+  double x = y;
+  int n;
+  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+    const double x2 = x * x;
+    if (abstop12(y) < abstop12(0x1p-12f)) {
+      sn = y;
+      cs = 1.0f;
+      return;
+    }
+    sn = sin_poly(x, x2, 0, 1.0);
+    cs = sin_poly(x, x2, 1, 1.0);
+    return;
+  }
+  if (abstop12(y) < abstop12(120.0f))
+    x = reduce_fast(x, &n);
+  else if (abstop12(y) < abstop12(__builtin_inff()))
+    x = reduce_slow(x, &n);
+  else {
+    sn = cs = y - y;
+    return;
+  }
+  const double sign = (n & 3) == 1 || (n & 3) == 2 ? -1.0 : 1.0;
+  const double csign = (n & 2) ? -1.0 : 1.0;
+  const double xs = x * sign, x2 = x * x;
+  sn = sin_poly(xs, x2, n, csign);
+  cs = sin_poly(xs, x2, n ^ 1, csign);
+}
+
 }  // namespace pine_libm

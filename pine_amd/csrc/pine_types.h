@@ -44,15 +44,17 @@ enum MaterialKind : int {
   MAT_SUBSURFACE = 3,
 };
 
-// 48-byte material record (constant shading nodes folded to literals).
+// 64-byte material record (constant shading nodes folded to literals).
 struct alignas(16) DMaterial {
   float color[3];  // albedo or emission
   int kind;
   float roughness, metallic, transmission, ior;
   float sigma_s[3];
   int pad;
+  float color_over_pi[3];  // albedo / Pi, the Lambertian f (bxdf.cpp:21,27): same IEEE division, done once on the host
+  int pad2;
 };
-static_assert(sizeof(DMaterial) == 48, "DMaterial must be 48 bytes");
+static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
 
 // 64-byte BVH node: the two child boxes live in the parent (as in pine's BVH) so one fetch decides
 // both children.  child[i] >= 0 with count[i] == 0: inner node index.  count[i] > 0: child i is a
