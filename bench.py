@@ -84,7 +84,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the PathIntegrator hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PINE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL calls at N=1
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -96,11 +97,11 @@ def main():
 
     def step():
         plan.launch(film.data_ptr(), stream)
-        if world > 1:
+        if use_dist:
             dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -116,7 +117,7 @@ def main():
         trace_ms.append(plan.stats().trace_ms)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -125,7 +126,7 @@ def main():
     spp_eff = st.spp_effective
     local_samples = st.camera_samples
     verts = st.vertices
-    if world > 1:
+    if use_dist:
         t = torch.tensor([local_samples, verts], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
         total_samples, total_verts = float(t[0]), float(t[1])
@@ -161,7 +162,7 @@ def main():
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -97,7 +97,8 @@ struct DTables {
   // table, and for THIS lane's current pixel the 40 ranking bytes + 8 scrambling bytes the
   // lookup needs (refreshed whenever the lane takes a new work item).
   const uint8_t* lds_sobol;
-  const uint32_t* lds_tile;  // lane slice: dword j at lds_tile[j * kLdsLaneStride]
+  const uint32_t* lds_tile;  // lane / context slice: dword j at lds_tile[j * tile_stride]
+  int tile_stride;           // 256 for the per-lane LDS slices, 1 for a context's 64-byte global record
 };
 // value = sobol[dim + (index ^ rank[(dim + pix*8) % N]) * 256] ^ scramble[dim % 8 + pix*8]
 // (bluenoise_*spp.cpp:14-34); LDS = true reads dims < kLdsSamplerDims from the workgroup cache.
@@ -111,10 +112,10 @@ PINE_HD float blue_sample_dimension(const DTables& t, int px, int py, int index,
   if constexpr (LDS) {
     if (sd < kLdsSamplerDims) {
       const unsigned sh = 8u * unsigned(sd & 3);
-      const uint32_t rw = t.lds_tile[(sd >> 2) * kLdsLaneStride];
+      const uint32_t rw = t.lds_tile[(sd >> 2) * t.tile_stride];
       const int ranked = si ^ int((rw >> sh) & 255u);
       int value = t.lds_sobol[sd * 256 + ranked];
-      const uint32_t sw = t.lds_tile[(10 + ((sd & 7) >> 2)) * kLdsLaneStride];
+      const uint32_t sw = t.lds_tile[(10 + ((sd & 7) >> 2)) * t.tile_stride];
       value = value ^ int((sw >> sh) & 255u);
       return (0.5f + float(value)) / 256.0f;
     }

@@ -77,6 +77,10 @@ __device__ unsigned long long g_region_lanes[16], g_region_hits[16];
 #define SEC_FLUSH()
 #endif
 
+#ifdef PINE_DEBUG_WATCHDOG
+__device__ unsigned g_watchdog[8];  // [0] traversal loop overran, [1] node, [2] sp
+#endif
+
 struct DeviceScene {
   const DShape* shapes;
   const DMaterial* materials;
@@ -129,7 +133,7 @@ struct WorkParams {
 // tested inline in stored primitive order, nearer-exit child first.  The stack lives in LDS,
 // lane-interleaved ([slot][thread]) so pushes/pops are bank-conflict free.
 // ------------------------------------------------------------------------------------------------
-template <bool ANY>
+template <bool ANY, int STRIDE = kBlock>
 __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh, DRay& ray,
                                               const DRayOct& oct, int* stack, int sp0, int& prim_out) {
   bool hit = false;
@@ -167,10 +171,10 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
     if (l != -1) {
       if (r != -1) {
         if (t0 > t1) {
-          stack[sp * kBlock] = l;
+          stack[sp * STRIDE] = l;
           next = r;
         } else {
-          stack[sp * kBlock] = r;
+          stack[sp * STRIDE] = r;
           next = l;
         }
         sp++;
@@ -178,7 +182,7 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
     } else if (r != -1) next = r;
     else {
       if (sp == sp0) break;
-      next = stack[(--sp) * kBlock];
+      next = stack[(--sp) * STRIDE];
     }
   }
   return hit;
@@ -186,7 +190,7 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
 
 // ANY: BVH::hit (bvh.cpp:497-511).  !ANY: BVH::intersect (bvh.cpp:513-548) minus the final
 // compute_surface_info, which the caller does once for the winning primitive.
-template <bool ANY, unsigned F>
+template <bool ANY, unsigned F, int STRIDE = kBlock>
 __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, int* stack, int& geom_out,
                                                int& prim_out) {
   if (S.num_shapes == 0) return false;
@@ -204,7 +208,7 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
         if constexpr (F & F_MESH) {
           const DBvh mb = S.bvhs[as_int(sh->f[2])];
           int prim = 0;
-          const bool h = mesh_traverse<ANY>(S, mb, ray, oct, stack, S.stack_top, prim);
+          const bool h = mesh_traverse<ANY, STRIDE>(S, mb, ray, oct, stack, S.stack_top, prim);
           if (ANY) {
             if (h) return true;
           } else if (h) {
@@ -228,7 +232,18 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
   }
   int sp = 0;
   int next = top.root;
+#ifdef PINE_DEBUG_WATCHDOG
+  int wd_iters = 0;
+#endif
   while (true) {
+#ifdef PINE_DEBUG_WATCHDOG
+    if (++wd_iters > 100000) {
+      g_watchdog[0] = 1;
+      g_watchdog[1] = unsigned(next);
+      g_watchdog[2] = unsigned(sp);
+      return hit;
+    }
+#endif
     REGION(ANY ? 4 : 1);  // top-level node visit
     const DNode* node = &S.nodes[next];
     int l = -1, r = -1;
@@ -244,10 +259,10 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
     if (l != -1) {
       if (r != -1) {
         if (t0 > t1) {
-          stack[sp * kBlock] = l;
+          stack[sp * STRIDE] = l;
           next = r;
         } else {
-          stack[sp * kBlock] = r;
+          stack[sp * STRIDE] = r;
           next = l;
         }
         sp++;
@@ -255,7 +270,7 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
     } else if (r != -1) next = r;
     else {
       if (sp == 0) break;
-      next = stack[(--sp) * kBlock];
+      next = stack[(--sp) * STRIDE];
     }
   }
   return hit;
@@ -380,6 +395,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   DTables T = S.tables;
   T.lds_sobol = reinterpret_cast<const uint8_t*>(lds_raw + kOffSobol);
   T.lds_tile = lds_u + kOffTile + tid;
+  T.tile_stride = kLdsLaneStride;
   SceneView V;
   V.tri_verts = S.tri_verts;
   V.stack_top = S.stack_top;
@@ -829,6 +845,10 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   if ((tid & 63) == 0) atomicAdd(&counters->shadow_rays, sc);
 }
 
+}  // namespace pine_gpu
+#include "pine_queue_kernel.h"
+namespace pine_gpu {
+
 // Compiled specialisations, most specific first.
 using PathKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, Counters*);
 struct KernelVariant {
@@ -854,6 +874,22 @@ static const KernelVariant kVariants[] = {
 #endif
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
+
+// stage-queued kernel (pine_queue_kernel.h): same feature lattice, without the SSS variants
+using QueueKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, uint32_t*, Counters*);
+struct QueueVariant {
+  unsigned features;
+  QueueKernelFn fn;
+  const char* name;
+};
+static const QueueVariant kQueueVariants[] = {
+    {kFBoxes | F_LDS_SCENE, path_queue_kernel<kFBoxes | F_LDS_SCENE>, "queue: rect+box/diffuse, scene in LDS"},
+#ifndef PINE_ONLY_CBOX_VARIANT
+    {kFAnalytic | F_LDS_SCENE, path_queue_kernel<kFAnalytic | F_LDS_SCENE>, "queue: analytic shapes/uber, scene in LDS"},
+    {kFAnalytic, path_queue_kernel<kFAnalytic>, "queue: analytic shapes/uber"},
+#endif
+};
+constexpr int kNumQueueVariants = int(sizeof(kQueueVariants) / sizeof(kQueueVariants[0]));
 
 // Ordered per-pixel sum: film[p] = (sum_{s=0..spp-1, in order} L_s) / spp  (path.cpp:34-38).
 // One wave per tile, lane = pixel in tile: every sample row is one coalesced 1 KiB read.
@@ -1049,6 +1085,8 @@ struct pine_gpu_plan {
   float* d_tri = nullptr;
   uint8_t* d_tables = nullptr;
   int variant = -1;
+  int queue_variant = -1;   // >= 0: the stage-queued kernel is used instead of path_trace_kernel
+  uint32_t* d_ctxg = nullptr;
   ulonglong2* d_ckpt = nullptr;
   float4* d_samples = nullptr;
   float* d_fold = nullptr;
@@ -1083,6 +1121,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_blob);
   (void)hipFree(p->d_tri);
   (void)hipFree(p->d_tables);
+  (void)hipFree(p->d_ctxg);
   (void)hipFree(p->d_ckpt);
   (void)hipFree(p->d_samples);
   (void)hipFree(p->d_fold);
@@ -1179,6 +1218,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.tables.rank = p->d_tables + 65536 + 131072;
   S.tables.lds_sobol = nullptr;
   S.tables.lds_tile = nullptr;
+  S.tables.tile_stride = 0;
   S.spp = spp;
   S.max_path_length = prm->max_path_length;
   int d_top = 0, d_mesh = 0;
@@ -1227,6 +1267,24 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     return -1;
   }
   if (kVariants[p->variant].features & F_LDS_SCENE) p->lds_bytes += size_t(S.blob_bytes);
+  // optional: the stage-queued kernel (PINE_GPU_KERNEL=queue), when a variant covers the scene and its LDS fits
+  p->queue_variant = -1;
+  {
+    const char* ksel = getenv("PINE_GPU_KERNEL");
+    if (ksel && std::string(ksel) == "queue" && !(need & (F_SSS | F_MESH))) {
+      for (int v = 0; v < kNumQueueVariants; v++) {
+        const unsigned F = kQueueVariants[v].features;
+        if ((F & need) != need) continue;
+        if (((F & F_LDS_SCENE) != 0) != lds_ok) continue;
+        const size_t lds = kQLdsFixedBytes + size_t(S.stack_total) * kQBlock * sizeof(int) +
+                           ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0);
+        if (lds > 160 * 1024) continue;
+        p->queue_variant = v;
+        p->lds_bytes = lds;
+        break;
+      }
+    }
+  }
 
   // scenes whose materials draw from the per-pixel RNG inside radiance() (Uber with fractional
   // metallic/transmission: sampler.h:317-324; BSSRDF channel pick: bxdf.cpp:335) make a pixel's
@@ -1266,18 +1324,28 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));
   int blocks_per_cu = 0;
-  HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)kVariants[p->variant].fn, kBlock, p->lds_bytes));
+  if (p->queue_variant >= 0) {
+    blocks_per_cu = 1;  // one 1024-thread workgroup per CU owns the CU's LDS
+    HIP_OK(hipFuncSetAttribute((const void*)kQueueVariants[p->queue_variant].fn,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(p->lds_bytes)));
+  } else {
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)kVariants[p->variant].fn, kBlock, p->lds_bytes));
+  }
   if (blocks_per_cu < 1) blocks_per_cu = 1;
   if (blocks_per_cu > 8) blocks_per_cu = 8;
   const char* env_bpc = getenv("PINE_GPU_BLOCKS_PER_CU");
   if (env_bpc && atoi(env_bpc) > 0) blocks_per_cu = atoi(env_bpc);
   unsigned long long want = (W.total_items + kBlock - 1) / kBlock;
+  if (p->queue_variant >= 0) want = (W.total_items + kQCtx - 1) / kQCtx;
   p->grid = int(std::min<unsigned long long>(want, (unsigned long long)prop.multiProcessorCount * blocks_per_cu));
   if (p->grid < 1) p->grid = 1;
 
   if (W.items_per_pixel > 1) HIP_OK(hipMalloc((void**)&p->d_ckpt, W.total_items * sizeof(ulonglong2)));
   HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
-  HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * size_t(p->grid) * kBlock * sizeof(float)));
+  const size_t fold_slots = p->queue_variant >= 0 ? size_t(p->grid) * kQCtx : size_t(p->grid) * kBlock;
+  HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * fold_slots * sizeof(float)));
+  if (p->queue_variant >= 0)
+    HIP_OK(hipMalloc((void**)&p->d_ctxg, size_t(p->grid) * kQCtx * kQCtxGlobalDwords * sizeof(uint32_t)));
   HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
   p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
   if (p->timed)
@@ -1318,8 +1386,12 @@ int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_) {
                        p->W, p->film_w, p->film_h, p->S.spp, p->d_ckpt);
   }
   if (p->timed) HIP_OK(hipEventRecord(p->ev[1], stream));
-  hipLaunchKernelGGL(kVariants[p->variant].fn, dim3(p->grid), dim3(kBlock), p->lds_bytes, stream, p->S, p->W,
-                     (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_counters);
+  if (p->queue_variant >= 0)
+    hipLaunchKernelGGL(kQueueVariants[p->queue_variant].fn, dim3(p->grid), dim3(kQBlock), p->lds_bytes, stream, p->S,
+                       p->W, (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_ctxg, p->d_counters);
+  else
+    hipLaunchKernelGGL(kVariants[p->variant].fn, dim3(p->grid), dim3(kBlock), p->lds_bytes, stream, p->S, p->W,
+                       (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_counters);
   if (p->timed) HIP_OK(hipEventRecord(p->ev[2], stream));
   {
     const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
@@ -1355,7 +1427,7 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   out->spp_effective = p->S.spp;
   out->samples_per_item = p->W.samples_per_item;
   out->grid_blocks = p->grid;
-  out->block_threads = kBlock;
+  out->block_threads = p->queue_variant >= 0 ? kQBlock : kBlock;
   out->lds_bytes = int(p->lds_bytes);
   if (p->launched) {
     HIP_OK(hipStreamSynchronize(p->last_stream));
@@ -1382,6 +1454,13 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
   Counters c;
   HIP_OK(hipMemcpy(&c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; i++) out[i] = c.section_cycles[i];
+#ifdef PINE_DEBUG_WATCHDOG
+  {
+    unsigned wd[8];
+    HIP_OK(hipMemcpyFromSymbol(wd, HIP_SYMBOL(g_watchdog), sizeof wd));
+    fprintf(stderr, "watchdog: traversal_overrun=%u node=%u sp=%u main_overrun=%u stage=%u\n", wd[0], wd[1], wd[2], wd[3], wd[4]);
+  }
+#endif
 #ifdef PINE_PROFILE_SECTIONS
   unsigned long long rl[16], rh[16];
   HIP_OK(hipMemcpyFromSymbol(rl, HIP_SYMBOL(g_region_lanes), sizeof rl));
@@ -1497,7 +1576,7 @@ int pine_gpu_test_sampler(int device, int spp_req, float* out, int64_t capacity)
   }
   HIP_OK(hipMemcpy(dt + 65536, g_tables.data() + 65536 + size_t(k) * 262144, 262144, hipMemcpyHostToDevice));
   HIP_OK(hipMalloc((void**)&dout, need * 4));
-  DTables T{dt, dt + 65536, dt + 65536 + 131072, nullptr, nullptr};
+  DTables T{dt, dt + 65536, dt + 65536 + 131072, nullptr, nullptr, 0};
   hipLaunchKernelGGL(test_sampler_kernel, dim3(6), dim3(64), 0, 0, T, spp, dout);
   HIP_OK(hipMemcpy(out, dout, need * 4, hipMemcpyDeviceToHost));
   hipFree(dt);

@@ -1,0 +1,619 @@
+// pine_amd/csrc/pine_queue_kernel.h -- stage-queued persistent path kernel (included by
+// pine_kernels.hip; uses its DeviceScene / SceneView / traversal templates).
+//
+// Why: in the lane-owns-a-path kernel (path_trace_kernel) a wave's 64 lanes are in different phases
+// of radiance(): measured VALU lane utilisation is 53 %, and a lockstep workload costs 45 ps per
+// path vertex against 78 ps for the real one.  Here a path is a *context* (12 dwords of state in
+// LDS, 1.5 contexts per thread); three LDS ring queues hold the ids of contexts waiting for
+//     E  extend   : closest-hit traversal, then classification
+//     S  shade    : surface, light sampling, shadow ray, BSDF sampling, fold push, next ray
+//     T  terminal : emission / miss, backward fold, sample store, next camera sample or work item
+// and every wave repeatedly pops up to 64 ids from the fullest queue and runs that one stage for
+// them -- wave-uniform control flow, all lanes doing the same thing: the ballot compaction /
+// regrouping "between bounces" happens every time a stage pushes its survivors.
+//
+// One workgroup of 1024 threads per CU (all 160 KB of LDS, 16 waves sharing the queues).
+// Per-context cold data (sampler tile slice, RNG, fold stack) lives in L2-resident global memory.
+// Every result is bit-identical to path_trace_kernel and to the oracle: the stages run the same
+// device functions in the same order per path; only the scheduling differs.
+#pragma once
+
+namespace pine_gpu {
+
+constexpr int kQBlock = 1024;  // threads per workgroup
+constexpr int kQCtx = 1536;    // path contexts per workgroup
+constexpr int kQRing = 2048;   // ring capacity (power of two >= kQCtx)
+constexpr int kQFields = 12;   // dwords of context state
+constexpr int kQPoolItems = 512;
+enum : int { QS_E = 0, QS_S = 1, QS_T = 2 };
+// context state fields (SoA in LDS: cst[field * kQCtx + id])
+enum : int { CF_OX, CF_OY, CF_OZ, CF_DX, CF_DY, CF_DZ, CF_TMAX, CF_ST, CF_PXY, CF_SBASE, CF_GEOM, CF_PRIM };
+constexpr unsigned kStFresh = 0xffffffffu;  // context has no path yet
+// control words
+enum : int { QC_HEAD = 0, QC_TAIL = 3, QC_BUSY = 6, QC_LOCK = 7, QC_PNEXT = 8, QC_PEND = 10, QC_EXHAUSTED = 12, QC_ABORT = 13, QC_WORDS = 16 };
+constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a protocol bug must end the kernel, not hang the GPU
+
+// LDS layout (dword offsets)
+constexpr int kQOffCtl = 0;
+constexpr int kQOffRing = kQOffCtl + QC_WORDS;                 // 3 rings of kQRing u16
+constexpr int kQOffState = kQOffRing + 3 * kQRing / 2;
+constexpr int kQOffSobol = kQOffState + kQFields * kQCtx;
+constexpr int kQOffStack = kQOffSobol + kLdsSamplerDims * 256 / 4;
+constexpr size_t kQLdsFixedBytes = size_t(kQOffStack) * 4;
+
+// per-context global record: 16 dwords = one 64-byte line
+//   [0..9] ranking bytes of the pixel for dims 0..39, [10..11] scrambling bytes, [12..15] RNG state
+constexpr int kQCtxGlobalDwords = 16;
+
+// Not instantiated with F_SSS: the BSSRDF beta channel per pending level is not carried by the
+// contexts (scenes with Subsurface materials run path_trace_kernel).
+template <unsigned F>
+__global__ void __launch_bounds__(kQBlock, 4)
+path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
+                  float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  unsigned* const qctl = reinterpret_cast<unsigned*>(lds_raw + kQOffCtl);
+  unsigned short* const ring = reinterpret_cast<unsigned short*>(lds_raw + kQOffRing);
+  float* const cstf = reinterpret_cast<float*>(lds_raw + kQOffState);
+  unsigned* const cstu = reinterpret_cast<unsigned*>(lds_raw + kQOffState);
+  int* const stack = lds_raw + kQOffStack + tid;
+
+  // ---- one-time staging ----
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(S.tables.sobol);
+    uint4* dst = reinterpret_cast<uint4*>(lds_raw + kQOffSobol);
+    for (int i = tid; i < kLdsSamplerDims * 256 / 16; i += kQBlock) dst[i] = src[i];
+  }
+  SceneView V;
+  V.tri_verts = S.tri_verts;
+  V.stack_top = S.stack_top;
+  V.num_shapes = S.num_shapes;
+  if constexpr (F & F_LDS_SCENE) {
+    uint4* dst = reinterpret_cast<uint4*>(lds_raw + kQOffStack + S.stack_total * kQBlock);
+    const int n16 = S.blob_bytes >> 4;
+    for (int i = tid; i < n16; i += kQBlock) dst[i] = S.blob[i];
+    const char* base = reinterpret_cast<const char*>(dst);
+    V.nodes = reinterpret_cast<const DNode*>(base + S.off_nodes);
+    V.shapes = reinterpret_cast<const DShape*>(base + S.off_shapes);
+    V.materials = reinterpret_cast<const DMaterial*>(base + S.off_materials);
+    V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
+    V.prims = reinterpret_cast<const int*>(base + S.off_prims);
+    V.lights = reinterpret_cast<const int*>(base + S.off_lights);
+  } else {
+    V.nodes = S.nodes;
+    V.shapes = S.shapes;
+    V.materials = S.materials;
+    V.bvhs = S.bvhs;
+    V.prims = S.prims;
+    V.lights = S.lights;
+  }
+  // queues: every context starts "fresh" in the terminal queue (stage T hands out work items)
+  if (tid < QC_WORDS) qctl[tid] = 0;
+  for (int i = tid; i < 3 * kQRing; i += kQBlock) ring[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < kQCtx; i += kQBlock) {
+    ring[QS_T * kQRing + i] = (unsigned short)(i + 1);
+    cstu[CF_ST * kQCtx + i] = kStFresh;
+  }
+  if (tid == 0) qctl[QC_TAIL + QS_T] = kQCtx;
+  __syncthreads();
+
+  const size_t ctx_base = size_t(blockIdx.x) * kQCtx;
+  auto fold_entry = [&](int id, int level) -> float4* {
+    return reinterpret_cast<float4*>(fold) + ((ctx_base + size_t(id)) * size_t(S.max_path_length) + size_t(level)) * 2;
+  };
+  auto ctx_global = [&](int id) -> uint32_t* { return ctxg + (ctx_base + size_t(id)) * kQCtxGlobalDwords; };
+  auto lds_load = [](const unsigned* p) -> unsigned { return __atomic_load_n(p, __ATOMIC_RELAXED); };
+
+  // push the contexts of lanes with `pred` to queue q (ballot compaction: one LDS atomic per wave)
+  auto push = [&](int q, bool pred, int id) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return;
+    const unsigned cnt = __popcll(m);
+    unsigned base = 0;
+    if (lane == unsigned(__ffsll((long long)m) - 1)) base = atomicAdd(&qctl[QC_TAIL + q], cnt);
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (pred) {
+      const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+      ring[q * kQRing + ((base + rank) & (kQRing - 1))] = (unsigned short)(id + 1);
+    }
+  };
+
+  unsigned shadow_count = 0;
+  unsigned spins = 0;
+  unsigned idle_polls = 0;
+  // bounded-spin bail-out: record where, raise the workgroup's abort flag, leave
+  auto bail = [&](unsigned code, unsigned a, unsigned b) {
+    __atomic_store_n(&qctl[QC_ABORT], 1u, __ATOMIC_RELAXED);
+    atomicAdd(&counters->section_cycles[15], 1ull);
+    counters->section_cycles[12] = code;
+    counters->section_cycles[13] = a;
+    counters->section_cycles[14] = b;
+  };
+
+  unsigned main_trips = 0;
+  while (true) {
+    if (++main_trips > (1u << 26)) {  // safety net: a wave never loops unboundedly
+      if (lane == 0) bail(5, main_trips, 0);
+      break;
+    }
+    // ---------------- pick a stage: the fullest queue (lane 0 decides, result broadcast) ----------------
+    int stage = -1;
+    unsigned n = 0, h = 0;
+    bool finished = false;
+    if (lane == 0) {
+      unsigned cnt[3];
+      int best = 0;
+      for (int q = 0; q < 3; q++) {
+        const unsigned hq = lds_load(&qctl[QC_HEAD + q]);  // head first: both only grow, so the
+        const unsigned tq = lds_load(&qctl[QC_TAIL + q]);  // difference can only be over-estimated
+        cnt[q] = tq - hq;
+        if (cnt[q] > cnt[best]) best = q;
+      }
+      const unsigned busy = lds_load(&qctl[QC_BUSY]);
+      if (cnt[best] >= 64u || (cnt[best] > 0u && (busy == 0u || spins >= 8u))) {
+        // count ourselves busy BEFORE taking items out of the queue, so that "all queues empty and
+        // nobody busy" really means no work can appear any more (idle pollers never touch the
+        // counter: two of them must not keep each other alive)
+        atomicAdd(&qctl[QC_BUSY], 1u);
+        const unsigned h0 = lds_load(&qctl[QC_HEAD + best]);
+        const unsigned avail = lds_load(&qctl[QC_TAIL + best]) - h0;
+        const unsigned want = avail < 64u ? avail : 64u;
+        if (want > 0u && want <= 64u && atomicCAS(&qctl[QC_HEAD + best], h0, h0 + want) == h0) {
+          stage = best;
+          n = want;
+          h = h0;
+        } else {
+          atomicSub(&qctl[QC_BUSY], 1u);
+        }
+      } else {
+        finished = cnt[0] == 0u && cnt[1] == 0u && cnt[2] == 0u && busy == 0u;
+      }
+    }
+    stage = __shfl(stage, 0);
+    n = __shfl(n, 0);
+    h = __shfl(h, 0);
+    finished = __shfl(int(finished), 0) != 0;
+    if (lds_load(&qctl[QC_ABORT]) != 0u) break;
+    if (stage < 0) {
+      if (finished) break;
+      spins++;
+      if (++idle_polls > kQSpinLimit) {
+        if (lane == 0)
+          bail(1, lds_load(&qctl[QC_BUSY]),
+               (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 11) |
+                   ((lds_load(&qctl[QC_TAIL + 2]) - lds_load(&qctl[QC_HEAD + 2])) << 22));
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+      continue;
+    }
+    spins = 0;
+    idle_polls = 0;
+    bool valid = lane < n;
+    int id = -1;
+    if (valid) {
+      unsigned short* slot = &ring[stage * kQRing + ((h + lane) & (kQRing - 1))];
+      unsigned v, tries = 0;
+      while ((v = __atomic_load_n(slot, __ATOMIC_RELAXED)) == 0) {
+        if (++tries > kQSpinLimit) {
+          bail(2, unsigned(stage), h + lane);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      *slot = 0;
+      id = int(v) - 1;
+    }
+    if (id < 0) valid = false;  // (only after a bounded-spin bail-out)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+#ifdef PINE_DEBUG_WATCHDOG
+    if (lane == 0) g_watchdog[4] = unsigned(stage) | (n << 8);
+#endif
+    if (stage == QS_E) {
+      // ================= extend: closest hit + classification =================
+      bool to_shade = false, to_term = false;
+      if (valid) {
+        DRay ray{f3{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]},
+                 f3{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]}, 0.0f,
+                 cstf[CF_TMAX * kQCtx + id]};
+        int geom = -1, prim = 0;
+        const bool hit = scene_traverse<false, F, kQBlock>(V, ray, stack, geom, prim);
+        cstf[CF_TMAX * kQCtx + id] = ray.tmax;
+        cstu[CF_GEOM * kQCtx + id] = unsigned(hit ? geom : -1);
+        cstu[CF_PRIM * kQCtx + id] = unsigned(prim);
+        const PackedState st{cstu[CF_ST * kQCtx + id]};
+        bool terminal = !hit;
+        if (hit) {
+          const DShape* shape = &V.shapes[geom];
+          terminal = V.materials[shape->material].kind == MAT_EMISSIVE || st.length() + 1 >= S.max_path_length;
+        }
+        to_shade = !terminal;
+        to_term = terminal;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      push(QS_S, to_shade, id);
+      push(QS_T, to_term, id);
+    } else if (stage == QS_S) {
+      // ================= shade a non-terminal vertex (path.cpp:91-120) =================
+      bool to_extend = false, to_term = false;
+      if (valid) {
+        const f3 ray_o{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
+        const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
+        const float ray_tmax = cstf[CF_TMAX * kQCtx + id];
+        PackedState st{cstu[CF_ST * kQCtx + id]};
+        const unsigned pxy = cstu[CF_PXY * kQCtx + id];
+        const int geom = int(cstu[CF_GEOM * kQCtx + id]);
+        const int prim = int(cstu[CF_PRIM * kQCtx + id]);
+        uint32_t* const cg = ctx_global(id);
+        DTables T = S.tables;
+        T.lds_sobol = reinterpret_cast<const uint8_t*>(lds_raw + kQOffSobol);
+        T.lds_tile = cg;
+        T.tile_stride = 1;
+        DSampler sampler;
+        sampler.px = int(pxy & 0xffffu);
+        sampler.py = int(pxy >> 16);
+        sampler.index = st.s_cur();
+        sampler.dimension = st.dim();
+        const int pv_length = st.length();
+
+        const DShape* shape = &V.shapes[geom];
+        const DMaterial* mat = &V.materials[shape->material];
+        DSurface it;
+        it.p = it.n = mk3(0.0f);
+        it.uv = f2{0, 0};
+        {
+          const f3 ph = ray_o + ray_tmax * ray_d;
+          bool on_mesh = false;
+          if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
+          if (on_mesh) tri_surface_info(V.tri_verts + size_t(prim) * 9, ph, it);
+          else shape_surface_info<F>(shape, ph, it);
+        }
+        const f3 wi = -ray_d;
+        m3 l2w = coordinate_system(it.n);
+        m3 w2l = transpose(l2w);
+        const bool diffused = st.diffuse_length() > 0;
+        const float min_roughness = diffused ? 0.6f : 0.0f;
+        DBxdf bx;
+        bx.kind = BX_DIFFUSE;
+        bx.roughness = 0.0f;
+        bx.ior = 1.0f;
+        bool is_uber = false, is_sss = false;
+        if constexpr (F & F_UBER) is_uber = mat->kind == MAT_UBER;
+        if constexpr (F & F_SSS) is_sss = mat->kind == MAT_SUBSURFACE;
+        auto rng_load = [&]() -> DRng {
+          return DRng{uint64_t(cg[12]) | (uint64_t(cg[13]) << 32), uint64_t(cg[14]) | (uint64_t(cg[15]) << 32)};
+        };
+        auto rng_store = [&](const DRng& g) {
+          cg[12] = uint32_t(g.s0);
+          cg[13] = uint32_t(g.s0 >> 32);
+          cg[14] = uint32_t(g.s1);
+          cg[15] = uint32_t(g.s1 >> 32);
+        };
+        if (is_uber) {
+          DRng g = rng_load();
+          if (with_probability(mat->metallic, g)) {
+            bx.kind = BX_CONDUCTOR;
+            bx.roughness = mat->roughness;
+          } else if (with_probability(mat->transmission, g)) {
+            bx.kind = BX_REFR_DIEL;
+            bx.roughness = mat->roughness;
+            bx.ior = mat->ior;
+          } else {
+            bx.kind = BX_DIFF_DIEL;
+            bx.roughness = mat->roughness;
+            bx.ior = mat->ior;
+          }
+          rng_store(g);
+        } else if (is_sss) {
+          const float fr = FrDielectric(dot(wi, it.n), mat->ior);
+          if (sampler_get1d<true>(T, sampler) < fr) {
+            bx.kind = BX_REFRACTIVE;
+            bx.roughness = pmax(mat->roughness, min_roughness);
+            bx.ior = mat->ior;
+          } else if (diffused) {
+            bx.kind = BX_DIFFUSE;
+          } else {
+            bx.kind = BX_BSSRDF;
+            bx.ior = mat->ior;
+          }
+        }
+        bx.wi = mul(w2l, wi);
+        int beta_channel = 0;
+        bool do_walk = false;
+        if constexpr (F & F_SSS) do_walk = bx.kind == BX_BSSRDF;
+        if (do_walk) {
+          f3 p = it.p;
+          f3 w = -wi;
+          if (Refract(wi, it.n, bx.ior, w, nullptr)) {
+            DRng g = rng_load();
+            const int channel = int(rng_nextf(g) * 3);
+            rng_store(g);
+            const float sigma_t_inv = 1 / mat->sigma_s[channel];
+            const f3 n0 = it.n;
+            for (int i = 0;; i++) {
+              DRay wr = i == 0 ? spawn_ray_raw(p, n0, w) : DRay{p, w, 0.0f, kFloatMax};
+              DSurface sit;
+              sit.p = sit.n = mk3(0.0f);
+              bool hh;
+              bool walk_mesh = false;
+              if constexpr (F & F_MESH) walk_mesh = shape->kind == SHAPE_MESH;
+              if (walk_mesh) {
+                const DRayOct oct = make_oct(wr);
+                int wprim = 0;
+                hh = mesh_traverse<false, kQBlock>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
+                if (hh) tri_surface_info(V.tri_verts + size_t(wprim) * 9, ray_at(wr, wr.tmax), sit);
+              } else {
+                hh = shape_intersect<F>(shape, wr);
+              }
+              if (!hh) break;
+              const float t = -logf(1 - sampler_get1d<true>(T, sampler)) * sigma_t_inv;
+              if (wr.tmax < t) {
+                beta_channel = channel + 1;
+                it.p = sit.p;
+                it.n = sit.n;
+                l2w = coordinate_system(it.n);
+                w2l = transpose(l2w);
+                bx.wi = mul(w2l, -w);
+                break;
+              }
+              p = ray_at(wr, t);
+              w = uniform_sphere(sampler_get2d<true>(T, sampler));
+            }
+          }
+        }
+        // ---- next-event estimation (path.cpp:98-113) ----
+        f3 nee = mk3(0.0f);
+        if (!bxdf_is_delta<F>(bx)) {
+          const f2 u2 = sampler_get2d<true>(T, sampler);  // g++ order: get2d first (lightsampler.h:27)
+          float u1 = sampler_get1d<true>(T, sampler);
+          if (S.num_lights > 0) {
+            if (S.num_lights != 1) u1 *= float(S.num_lights);
+            const int index = int(u1);
+            const DShape* lshape = &V.shapes[V.lights[index]];
+            DShapeSample gs;
+            if (shape_sample<F>(lshape, V.tri_verts, it.p, u2, u1 - float(index), gs)) {
+              const DMaterial* lmat = &V.materials[lshape->material];
+              if (!is_zero(material_le(lmat, gs.n, -gs.w))) {
+                const float ls_pdf = S.num_lights != 1 ? gs.pdf / float(S.num_lights) : gs.pdf;
+                shadow_count++;
+                DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
+                int g2, p2;
+                if (!scene_traverse<true, F, kQBlock>(V, sr, stack, g2, p2)) {
+                  const f3 le = ld3(lmat->color);
+                  bx.albedo = ld3(mat->color);
+                  bx.albedo_over_pi = ld3(mat->color_over_pi);
+                  const float cosine = absdot(gs.w, it.n);
+                  const f3 wo = mul(w2l, gs.w);
+                  const f3 f = bxdf_f<F>(bx, wo);
+                  const float mis = balance_heuristic(ls_pdf, bxdf_pdf<F>(bx, wo));
+                  nee = mk3(0.0f) + le * mk3(1.0f) * cosine * f / ls_pdf * mis;
+                }
+              }
+            }
+          }
+        }
+        // ---- BSDF sampling + continuation (path.cpp:114-120) ----
+        bx.albedo = ld3(mat->color);
+        bx.albedo_over_pi = ld3(mat->color_over_pi);
+        DBsdfSample bs;
+        if (bxdf_sample<F, true>(bx, T, sampler, bs)) {
+          const f3 wo_world = mul(l2w, bs.wo);
+          const float cosine = absdot(wo_world, it.n);
+          float4* q = fold_entry(id, pv_length);
+          q[0] = make_float4(nee.x, nee.y, nee.z, bs.f.x);
+          q[1] = make_float4(bs.f.y, bs.f.z, cosine / bs.pdf, bs.pdf);
+          const DRay nr = spawn_ray(it.p, it.n, wo_world, kFloatMax);
+          cstf[CF_OX * kQCtx + id] = nr.o.x;
+          cstf[CF_OY * kQCtx + id] = nr.o.y;
+          cstf[CF_OZ * kQCtx + id] = nr.o.z;
+          cstf[CF_DX * kQCtx + id] = nr.d.x;
+          cstf[CF_DY * kQCtx + id] = nr.d.y;
+          cstf[CF_DZ * kQCtx + id] = nr.d.z;
+          cstf[CF_TMAX * kQCtx + id] = nr.tmax;
+          st.set_dim(sampler.dimension);
+          st.next_vertex(bs.is_delta);
+          cstu[CF_ST * kQCtx + id] = st.v;
+          to_extend = true;
+        } else {
+          // no continuation: the vertex resolves with lo = nee (path.cpp:121); stage T folds it
+          f3 beta = mk3(1.0f);
+          if (beta_channel) {
+            beta = mk3(0.0f);
+            set(beta, beta_channel - 1, 3.0f);
+          }
+          const f3 Lo = mk3(0.0f) + vmin(mk3(1.0f) * beta * nee, mk3(8.0f));
+          cstf[CF_DX * kQCtx + id] = Lo.x;
+          cstf[CF_DY * kQCtx + id] = Lo.y;
+          cstf[CF_DZ * kQCtx + id] = Lo.z;
+          cstu[CF_GEOM * kQCtx + id] = unsigned(-2);
+          to_term = true;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      push(QS_E, to_extend, id);
+      push(QS_T, to_term, id);
+    } else {
+      // ================= terminal: result, backward fold, store, next sample / item =================
+      bool need_item = false, have_path = false;
+      unsigned pxy = 0, sample_base = 0;
+      int s_next = 0;
+      if (valid) {
+        const PackedState st{cstu[CF_ST * kQCtx + id]};
+        if (st.v == kStFresh) {
+          need_item = true;
+        } else {
+          const int pv_length = st.length();
+          const int geom = int(cstu[CF_GEOM * kQCtx + id]);
+          f3 Lo = mk3(0.0f);
+          bool lp_valid = false;
+          float lp = 0.0f;
+          if (geom == -2) {
+            Lo = f3{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
+          } else if (geom >= 0) {
+            const DShape* shape = &V.shapes[geom];
+            const DMaterial* mat = &V.materials[shape->material];
+            if (mat->kind == MAT_EMISSIVE) {  // path.cpp:83-87
+              const f3 ray_o{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
+              const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
+              const float ray_tmax = cstf[CF_TMAX * kQCtx + id];
+              DSurface it;
+              it.p = it.n = mk3(0.0f);
+              it.uv = f2{0, 0};
+              const f3 ph = ray_o + ray_tmax * ray_d;
+              bool on_mesh = false;
+              if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
+              if (on_mesh) tri_surface_info(V.tri_verts + size_t(cstu[CF_PRIM * kQCtx + id]) * 9, ph, it);
+              else shape_surface_info<F>(shape, ph, it);
+              Lo = mk3(1.0f) * material_le(mat, it.n, -ray_d);
+              if (!st.is_delta()) {
+                lp_valid = true;
+                const DRay ray{ray_o, ray_d, 0.0f, ray_tmax};
+                lp = shape_pdf<F>(shape, ray, it.n);
+                if (S.num_lights != 1) lp = lp / float(size_t(S.num_lights));
+              }
+            }
+          }
+          // backward fold (path.cpp:114-121)
+          f3 Li = Lo;
+          for (int level = pv_length - 1; level >= 0; level--) {
+            const float4* q = fold_entry(id, level);
+            const float4 a = q[0], b = q[1];
+            const f3 e_nee{a.x, a.y, a.z};
+            const f3 e_f{a.w, b.x, b.y};
+            const float e_cp = b.z, e_pdf = b.w;
+            const float mis = lp_valid ? balance_heuristic(e_pdf, lp) : 1.0f;
+            const f3 lo = e_nee + Li * e_f * (e_cp * mis);
+            Li = mk3(0.0f) + vmin(mk3(1.0f) * mk3(1.0f) * lo, mk3(8.0f));
+            lp_valid = false;
+          }
+          const int s_now = st.s_cur();
+          sample_base = cstu[CF_SBASE * kQCtx + id];
+          pxy = cstu[CF_PXY * kQCtx + id];
+          samples[size_t(sample_base) + size_t(s_now) * 64u] = make_float4(Li.x, Li.y, Li.z, float(pv_length + 1));
+          s_next = s_now + 1;
+          if ((s_next & (W.samples_per_item - 1)) == 0) need_item = true;
+          else have_path = true;
+        }
+      }
+      // ---- hand out work items to the contexts that need one (block pool, refilled from the global queue) ----
+      for (unsigned rounds = 0;; rounds++) {
+        const unsigned long long m = __ballot(need_item);
+        if (m == 0) break;
+        if (rounds > 4096u) {
+          if (lane == 0) bail(4, unsigned(m), unsigned(m >> 32));
+          need_item = false;
+          break;
+        }
+        const unsigned want = __popcll(m);
+        unsigned long long base = 0;
+        unsigned got = 0;
+        if (lane == 0) {
+          unsigned tries = 0;
+          while (atomicCAS(&qctl[QC_LOCK], 0u, 1u) != 0u) {
+            if (++tries > kQSpinLimit) {
+              bail(3, 0, 0);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          unsigned long long nx = (unsigned long long)lds_load(&qctl[QC_PNEXT]) | ((unsigned long long)lds_load(&qctl[QC_PNEXT + 1]) << 32);
+          unsigned long long en = (unsigned long long)lds_load(&qctl[QC_PEND]) | ((unsigned long long)lds_load(&qctl[QC_PEND + 1]) << 32);
+          if (nx == en && lds_load(&qctl[QC_EXHAUSTED]) == 0u) {
+            const unsigned long long b = atomicAdd(&counters->next_item, (unsigned long long)kQPoolItems);
+            if (b >= W.total_items) {
+              __atomic_store_n(&qctl[QC_EXHAUSTED], 1u, __ATOMIC_RELAXED);
+            } else {
+              nx = b;
+              en = b + kQPoolItems < W.total_items ? b + kQPoolItems : W.total_items;
+            }
+          }
+          const unsigned long long avail = en - nx;
+          got = want < avail ? want : unsigned(avail);
+          base = nx;
+          nx += got;
+          __atomic_store_n(&qctl[QC_PNEXT], unsigned(nx), __ATOMIC_RELAXED);
+          __atomic_store_n(&qctl[QC_PNEXT + 1], unsigned(nx >> 32), __ATOMIC_RELAXED);
+          __atomic_store_n(&qctl[QC_PEND], unsigned(en), __ATOMIC_RELAXED);
+          __atomic_store_n(&qctl[QC_PEND + 1], unsigned(en >> 32), __ATOMIC_RELAXED);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __atomic_store_n(&qctl[QC_LOCK], 0u, __ATOMIC_RELAXED);
+        }
+        base = __shfl(base, 0);
+        got = __shfl(got, 0);
+        if (got == 0) {
+          // global queue exhausted: these contexts retire (they are simply not pushed anywhere)
+          need_item = false;
+          break;
+        }
+        const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (need_item && rank < got) {
+          const unsigned long long item = base + rank;
+          const ItemInfo itf = decode_item(W, S.cam.W, S.cam.H, S.spp, item);
+          if (itf.valid) {  // else: pixel outside the film (border tile): take another item next round
+            need_item = false;
+            have_path = true;
+            pxy = unsigned(itf.px) | (unsigned(itf.py) << 16);
+            sample_base = unsigned(itf.sample_base);
+            s_next = itf.chunk * W.samples_per_item;
+            uint32_t* const cg = ctx_global(id);
+            const int pix = (itf.px & 127) + (itf.py & 127) * 128;
+            const uint2* rsrc = reinterpret_cast<const uint2*>(S.tables.rank + size_t(pix) * 8);
+            const uint2 sc = *reinterpret_cast<const uint2*>(S.tables.scramble + size_t(pix) * 8);
+            uint4* cg4 = reinterpret_cast<uint4*>(cg);
+            const uint2 r0 = rsrc[0], r1 = rsrc[1], r2 = rsrc[2], r3 = rsrc[3], r4 = rsrc[4];
+            cg4[0] = make_uint4(r0.x, r0.y, r1.x, r1.y);
+            cg4[1] = make_uint4(r2.x, r2.y, r3.x, r3.y);
+            cg4[2] = make_uint4(r4.x, r4.y, sc.x, sc.y);
+            DRng g;
+            if (W.items_per_pixel == 1) {
+              g = rng_seed(hash_pixel(itf.px, itf.py, 0));
+            } else {
+              const ulonglong2 c = ckpt[item];
+              g = DRng{c.x, c.y};
+            }
+            cg4[3] = make_uint4(uint32_t(g.s0), uint32_t(g.s0 >> 32), uint32_t(g.s1), uint32_t(g.s1 >> 32));
+          }
+        }
+      }
+      // ---- start the next camera sample (path.cpp:34-36) ----
+      if (valid && have_path) {
+        uint4* cg4 = reinterpret_cast<uint4*>(ctx_global(id));
+        const uint4 rs = cg4[3];
+        DRng g{uint64_t(rs.x) | (uint64_t(rs.y) << 32), uint64_t(rs.z) | (uint64_t(rs.w) << 32)};
+        const float lx = rng_nextf(g);  // g++ argument order: lens sample first, then pixel jitter
+        const float ly = rng_nextf(g);
+        const float jx = rng_nextf(g);
+        const float jy = rng_nextf(g);
+        cg4[3] = make_uint4(uint32_t(g.s0), uint32_t(g.s0 >> 32), uint32_t(g.s1), uint32_t(g.s1 >> 32));
+        const int px = int(pxy & 0xffffu), py = int(pxy >> 16);
+        const f2 pf{(float(px) + jx) / float(S.cam.W), (float(py) + jy) / float(S.cam.H)};
+        const DRay r = camera_gen_ray(S.cam, pf, f2{lx, ly});
+        cstf[CF_OX * kQCtx + id] = r.o.x;
+        cstf[CF_OY * kQCtx + id] = r.o.y;
+        cstf[CF_OZ * kQCtx + id] = r.o.z;
+        cstf[CF_DX * kQCtx + id] = r.d.x;
+        cstf[CF_DY * kQCtx + id] = r.d.y;
+        cstf[CF_DZ * kQCtx + id] = r.d.z;
+        cstf[CF_TMAX * kQCtx + id] = r.tmax;
+        PackedState st{0};
+        st.start_sample(s_next);
+        cstu[CF_ST * kQCtx + id] = st.v;
+        cstu[CF_PXY * kQCtx + id] = pxy;
+        cstu[CF_SBASE * kQCtx + id] = sample_base;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      push(QS_E, valid && have_path, id);
+    }
+    if (lane == 0) atomicSub(&qctl[QC_BUSY], 1u);
+  }
+
+  unsigned long long sc = shadow_count;
+  for (int off = 32; off > 0; off >>= 1) sc += __shfl_down(sc, off);
+  if (lane == 0) atomicAdd(&counters->shadow_rays, sc);
+}
+
+}  // namespace pine_gpu
