@@ -77,9 +77,6 @@ __device__ unsigned long long g_region_lanes[16], g_region_hits[16];
 #define SEC_FLUSH()
 #endif
 
-#ifdef PINE_DEBUG_WATCHDOG
-__device__ unsigned g_watchdog[8];  // [0] traversal loop overran, [1] node, [2] sp
-#endif
 
 struct DeviceScene {
   const DShape* shapes;
@@ -232,18 +229,7 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
   }
   int sp = 0;
   int next = top.root;
-#ifdef PINE_DEBUG_WATCHDOG
-  int wd_iters = 0;
-#endif
   while (true) {
-#ifdef PINE_DEBUG_WATCHDOG
-    if (++wd_iters > 100000) {
-      g_watchdog[0] = 1;
-      g_watchdog[1] = unsigned(next);
-      g_watchdog[2] = unsigned(sp);
-      return hit;
-    }
-#endif
     REGION(ANY ? 4 : 1);  // top-level node visit
     const DNode* node = &S.nodes[next];
     int l = -1, r = -1;
@@ -1454,13 +1440,6 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
   Counters c;
   HIP_OK(hipMemcpy(&c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; i++) out[i] = c.section_cycles[i];
-#ifdef PINE_DEBUG_WATCHDOG
-  {
-    unsigned wd[8];
-    HIP_OK(hipMemcpyFromSymbol(wd, HIP_SYMBOL(g_watchdog), sizeof wd));
-    fprintf(stderr, "watchdog: traversal_overrun=%u node=%u sp=%u main_overrun=%u stage=%u\n", wd[0], wd[1], wd[2], wd[3], wd[4]);
-  }
-#endif
 #ifdef PINE_PROFILE_SECTIONS
   unsigned long long rl[16], rh[16];
   HIP_OK(hipMemcpyFromSymbol(rl, HIP_SYMBOL(g_region_lanes), sizeof rl));

@@ -35,8 +35,8 @@ constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a pro
 
 // LDS layout (dword offsets)
 constexpr int kQOffCtl = 0;
-constexpr int kQOffRing = kQOffCtl + QC_WORDS;                 // 3 rings of kQRing u16
-constexpr int kQOffState = kQOffRing + 3 * kQRing / 2;
+constexpr int kQOffRing = kQOffCtl + QC_WORDS;                 // 3 rings of kQRing dwords (id + 1, 0 = empty)
+constexpr int kQOffState = kQOffRing + 3 * kQRing;
 constexpr int kQOffSobol = kQOffState + kQFields * kQCtx;
 constexpr int kQOffStack = kQOffSobol + kLdsSamplerDims * 256 / 4;
 constexpr size_t kQLdsFixedBytes = size_t(kQOffStack) * 4;
@@ -55,7 +55,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63;
   unsigned* const qctl = reinterpret_cast<unsigned*>(lds_raw + kQOffCtl);
-  unsigned short* const ring = reinterpret_cast<unsigned short*>(lds_raw + kQOffRing);
+  unsigned* const ring = reinterpret_cast<unsigned*>(lds_raw + kQOffRing);
   float* const cstf = reinterpret_cast<float*>(lds_raw + kQOffState);
   unsigned* const cstu = reinterpret_cast<unsigned*>(lds_raw + kQOffState);
   int* const stack = lds_raw + kQOffStack + tid;
@@ -94,7 +94,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   for (int i = tid; i < 3 * kQRing; i += kQBlock) ring[i] = 0;
   __syncthreads();
   for (int i = tid; i < kQCtx; i += kQBlock) {
-    ring[QS_T * kQRing + i] = (unsigned short)(i + 1);
+    ring[QS_T * kQRing + i] = unsigned(i + 1);
     cstu[CF_ST * kQCtx + i] = kStFresh;
   }
   if (tid == 0) qctl[QC_TAIL + QS_T] = kQCtx;
@@ -117,7 +117,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     base = __shfl(base, __ffsll((long long)m) - 1);
     if (pred) {
       const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
-      ring[q * kQRing + ((base + rank) & (kQRing - 1))] = (unsigned short)(id + 1);
+      __atomic_store_n(&ring[q * kQRing + ((base + rank) & (kQRing - 1))], unsigned(id + 1), __ATOMIC_RELAXED);
     }
   };
 
@@ -195,24 +195,24 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     bool valid = lane < n;
     int id = -1;
     if (valid) {
-      unsigned short* slot = &ring[stage * kQRing + ((h + lane) & (kQRing - 1))];
+      // take the slot with an atomic exchange: reading and clearing are ONE operation.  (A separate
+      // plain "slot = 0" store may be sunk by the compiler to the end of the stage; by then the ring
+      // can have wrapped and the late store wipes a NEW entry -- its consumer then spins forever.
+      // That was an intermittent hang of the first version.)
+      unsigned* slot = &ring[stage * kQRing + ((h + lane) & (kQRing - 1))];
       unsigned v, tries = 0;
-      while ((v = __atomic_load_n(slot, __ATOMIC_RELAXED)) == 0) {
+      while ((v = atomicExch(slot, 0u)) == 0u) {
         if (++tries > kQSpinLimit) {
           bail(2, unsigned(stage), h + lane);
           break;
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      *slot = 0;
       id = int(v) - 1;
     }
     if (id < 0) valid = false;  // (only after a bounded-spin bail-out)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-#ifdef PINE_DEBUG_WATCHDOG
-    if (lane == 0) g_watchdog[4] = unsigned(stage) | (n << 8);
-#endif
     if (stage == QS_E) {
       // ================= extend: closest hit + classification =================
       bool to_shade = false, to_term = false;
@@ -520,6 +520,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             }
             __builtin_amdgcn_s_sleep(1);
           }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           unsigned long long nx = (unsigned long long)lds_load(&qctl[QC_PNEXT]) | ((unsigned long long)lds_load(&qctl[QC_PNEXT + 1]) << 32);
           unsigned long long en = (unsigned long long)lds_load(&qctl[QC_PEND]) | ((unsigned long long)lds_load(&qctl[QC_PEND + 1]) << 32);
           if (nx == en && lds_load(&qctl[QC_EXHAUSTED]) == 0u) {

@@ -4,10 +4,10 @@ agg = collections.defaultdict(list)
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "path_trace" in r["Kernel_Name"]:
+            if "path_trace" in r["Kernel_Name"] or "path_queue" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 vg = r.get("VGPR_Count"); lds = r.get("LDS_Block_Size"); grid = r.get("Grid_Size")
-print(f"kernel path_trace_kernel VGPR={vg} LDS={lds} grid={grid}")
+print(f"kernel path kernel VGPR={vg} LDS={lds} grid={grid}")
 m = {k: sum(v) / len(v) for k, v in agg.items()}
 for k in sorted(m):
     print(f"{k:28s} {m[k]:.5e}  (n={len(agg[k])})")
