@@ -4,13 +4,14 @@
 // Why: in the lane-owns-a-path kernel (path_trace_kernel) a wave's 64 lanes are in different phases
 // of radiance(): measured VALU lane utilisation is 53 %, and a lockstep workload costs 45 ps per
 // path vertex against 78 ps for the real one.  Here a path is a *context* (12 dwords of state in
-// LDS, 1.5 contexts per thread); three LDS ring queues hold the ids of contexts waiting for
-//     E  extend   : closest-hit traversal, then classification
+// LDS, 1.5 contexts per thread); two LDS ring queues hold the ids of contexts whose last ray has
+// been traced and classified:
 //     S  shade    : surface, light sampling, shadow ray, BSDF sampling, fold push, next ray
 //     T  terminal : emission / miss, backward fold, sample store, next camera sample or work item
-// and every wave repeatedly pops up to 64 ids from the fullest queue and runs that one stage for
-// them -- wave-uniform control flow, all lanes doing the same thing: the ballot compaction /
-// regrouping "between bounces" happens every time a stage pushes its survivors.
+// Both stages end by tracing the context's NEW ray (closest hit) and classifying the hit, then push
+// the context to S or T.  Every wave repeatedly pops up to 64 ids from the fuller queue and runs
+// that one stage for them -- wave-uniform control flow, all lanes doing the same thing: the ballot
+// compaction / regrouping "between bounces" happens every time a stage pushes its survivors.
 //
 // One workgroup of 1024 threads per CU (all 160 KB of LDS, 16 waves sharing the queues).
 // Per-context cold data (sampler tile slice, RNG, fold stack) lives in L2-resident global memory.
@@ -18,25 +19,32 @@
 // device functions in the same order per path; only the scheduling differs.
 #pragma once
 
+#ifndef PINE_QFOLD_BATCH
+#define PINE_QFOLD_BATCH 1
+#endif
+
 namespace pine_gpu {
 
 constexpr int kQBlock = 1024;  // threads per workgroup
-constexpr int kQCtx = 1536;    // path contexts per workgroup
+#ifndef PINE_QCTX
+#define PINE_QCTX 1536
+#endif
+constexpr int kQCtx = PINE_QCTX;  // path contexts per workgroup (1.5x the threads by default)
 constexpr int kQRing = 2048;   // ring capacity (power of two >= kQCtx)
 constexpr int kQFields = 12;   // dwords of context state
 constexpr int kQPoolItems = 512;
-enum : int { QS_E = 0, QS_S = 1, QS_T = 2 };
+enum : int { QS_S = 0, QS_T = 1, QS_COUNT = 2 };
 // context state fields (SoA in LDS: cst[field * kQCtx + id])
 enum : int { CF_OX, CF_OY, CF_OZ, CF_DX, CF_DY, CF_DZ, CF_TMAX, CF_ST, CF_PXY, CF_SBASE, CF_GEOM, CF_PRIM };
 constexpr unsigned kStFresh = 0xffffffffu;  // context has no path yet
 // control words
-enum : int { QC_HEAD = 0, QC_TAIL = 3, QC_BUSY = 6, QC_LOCK = 7, QC_PNEXT = 8, QC_PEND = 10, QC_EXHAUSTED = 12, QC_ABORT = 13, QC_WORDS = 16 };
+enum : int { QC_HEAD = 0, QC_TAIL = 3, QC_BUSY = 6, /* heads at 0..1, tails at 3..4 */ QC_LOCK = 7, QC_PNEXT = 8, QC_PEND = 10, QC_EXHAUSTED = 12, QC_ABORT = 13, QC_WORDS = 16 };
 constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a protocol bug must end the kernel, not hang the GPU
 
 // LDS layout (dword offsets)
 constexpr int kQOffCtl = 0;
 constexpr int kQOffRing = kQOffCtl + QC_WORDS;                 // 3 rings of kQRing dwords (id + 1, 0 = empty)
-constexpr int kQOffState = kQOffRing + 3 * kQRing;
+constexpr int kQOffState = kQOffRing + QS_COUNT * kQRing;
 constexpr int kQOffSobol = kQOffState + kQFields * kQCtx;
 constexpr int kQOffStack = kQOffSobol + kLdsSamplerDims * 256 / 4;
 constexpr size_t kQLdsFixedBytes = size_t(kQOffStack) * 4;
@@ -91,7 +99,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   }
   // queues: every context starts "fresh" in the terminal queue (stage T hands out work items)
   if (tid < QC_WORDS) qctl[tid] = 0;
-  for (int i = tid; i < 3 * kQRing; i += kQBlock) ring[i] = 0;
+  for (int i = tid; i < QS_COUNT * kQRing; i += kQBlock) ring[i] = 0;
   __syncthreads();
   for (int i = tid; i < kQCtx; i += kQBlock) {
     ring[QS_T * kQRing + i] = unsigned(i + 1);
@@ -121,6 +129,31 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     }
   };
 
+  // trace the context's new ray (closest hit), record the hit, classify the vertex it reaches:
+  // emissive / miss / path-length limit -> terminal queue, otherwise -> shade queue
+  auto extend = [&](int id, f3 o, f3 d, float tmax, PackedState st, bool& to_shade, bool& to_term) {
+    DRay ray{o, d, 0.0f, tmax};
+    int geom = -1, prim = 0;
+    const bool hit = scene_traverse<false, F, kQBlock>(V, ray, stack, geom, prim);
+    cstf[CF_OX * kQCtx + id] = o.x;
+    cstf[CF_OY * kQCtx + id] = o.y;
+    cstf[CF_OZ * kQCtx + id] = o.z;
+    cstf[CF_DX * kQCtx + id] = d.x;
+    cstf[CF_DY * kQCtx + id] = d.y;
+    cstf[CF_DZ * kQCtx + id] = d.z;
+    cstf[CF_TMAX * kQCtx + id] = ray.tmax;
+    cstu[CF_ST * kQCtx + id] = st.v;
+    cstu[CF_GEOM * kQCtx + id] = unsigned(hit ? geom : -1);
+    cstu[CF_PRIM * kQCtx + id] = unsigned(prim);
+    bool terminal = !hit;
+    if (hit) {
+      const DShape* shape = &V.shapes[geom];
+      terminal = V.materials[shape->material].kind == MAT_EMISSIVE || st.length() + 1 >= S.max_path_length;
+    }
+    to_shade = !terminal;
+    to_term = terminal;
+  };
+
   unsigned shadow_count = 0;
   unsigned spins = 0;
   unsigned idle_polls = 0;
@@ -144,9 +177,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     unsigned n = 0, h = 0;
     bool finished = false;
     if (lane == 0) {
-      unsigned cnt[3];
+      unsigned cnt[QS_COUNT];
       int best = 0;
-      for (int q = 0; q < 3; q++) {
+      for (int q = 0; q < QS_COUNT; q++) {
         const unsigned hq = lds_load(&qctl[QC_HEAD + q]);  // head first: both only grow, so the
         const unsigned tq = lds_load(&qctl[QC_TAIL + q]);  // difference can only be over-estimated
         cnt[q] = tq - hq;
@@ -169,7 +202,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           atomicSub(&qctl[QC_BUSY], 1u);
         }
       } else {
-        finished = cnt[0] == 0u && cnt[1] == 0u && cnt[2] == 0u && busy == 0u;
+        finished = cnt[0] == 0u && cnt[1] == 0u && busy == 0u;
       }
     }
     stage = __shfl(stage, 0);
@@ -183,8 +216,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       if (++idle_polls > kQSpinLimit) {
         if (lane == 0)
           bail(1, lds_load(&qctl[QC_BUSY]),
-               (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 11) |
-                   ((lds_load(&qctl[QC_TAIL + 2]) - lds_load(&qctl[QC_HEAD + 2])) << 22));
+               (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 16));
         break;
       }
       __builtin_amdgcn_s_sleep(4);
@@ -213,33 +245,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if (id < 0) valid = false;  // (only after a bounded-spin bail-out)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    if (stage == QS_E) {
-      // ================= extend: closest hit + classification =================
-      bool to_shade = false, to_term = false;
-      if (valid) {
-        DRay ray{f3{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]},
-                 f3{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]}, 0.0f,
-                 cstf[CF_TMAX * kQCtx + id]};
-        int geom = -1, prim = 0;
-        const bool hit = scene_traverse<false, F, kQBlock>(V, ray, stack, geom, prim);
-        cstf[CF_TMAX * kQCtx + id] = ray.tmax;
-        cstu[CF_GEOM * kQCtx + id] = unsigned(hit ? geom : -1);
-        cstu[CF_PRIM * kQCtx + id] = unsigned(prim);
-        const PackedState st{cstu[CF_ST * kQCtx + id]};
-        bool terminal = !hit;
-        if (hit) {
-          const DShape* shape = &V.shapes[geom];
-          terminal = V.materials[shape->material].kind == MAT_EMISSIVE || st.length() + 1 >= S.max_path_length;
-        }
-        to_shade = !terminal;
-        to_term = terminal;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      push(QS_S, to_shade, id);
-      push(QS_T, to_term, id);
-    } else if (stage == QS_S) {
+    if (stage == QS_S) {
       // ================= shade a non-terminal vertex (path.cpp:91-120) =================
-      bool to_extend = false, to_term = false;
+      bool to_shade = false, to_term = false;
       if (valid) {
         const f3 ray_o{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
         const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
@@ -407,17 +415,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           q[0] = make_float4(nee.x, nee.y, nee.z, bs.f.x);
           q[1] = make_float4(bs.f.y, bs.f.z, cosine / bs.pdf, bs.pdf);
           const DRay nr = spawn_ray(it.p, it.n, wo_world, kFloatMax);
-          cstf[CF_OX * kQCtx + id] = nr.o.x;
-          cstf[CF_OY * kQCtx + id] = nr.o.y;
-          cstf[CF_OZ * kQCtx + id] = nr.o.z;
-          cstf[CF_DX * kQCtx + id] = nr.d.x;
-          cstf[CF_DY * kQCtx + id] = nr.d.y;
-          cstf[CF_DZ * kQCtx + id] = nr.d.z;
-          cstf[CF_TMAX * kQCtx + id] = nr.tmax;
           st.set_dim(sampler.dimension);
           st.next_vertex(bs.is_delta);
-          cstu[CF_ST * kQCtx + id] = st.v;
-          to_extend = true;
+          extend(id, nr.o, nr.d, nr.tmax, st, to_shade, to_term);
         } else {
           // no continuation: the vertex resolves with lo = nee (path.cpp:121); stage T folds it
           f3 beta = mk3(1.0f);
@@ -434,11 +434,12 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      push(QS_E, to_extend, id);
+      push(QS_S, to_shade, id);
       push(QS_T, to_term, id);
     } else {
       // ================= terminal: result, backward fold, store, next sample / item =================
       bool need_item = false, have_path = false;
+      bool to_shade2 = false, to_term2 = false;
       unsigned pxy = 0, sample_base = 0;
       int s_next = 0;
       if (valid) {
@@ -479,9 +480,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           }
           // backward fold (path.cpp:114-121)
           f3 Li = Lo;
-          for (int level = pv_length - 1; level >= 0; level--) {
-            const float4* q = fold_entry(id, level);
-            const float4 a = q[0], b = q[1];
+          auto fold_step = [&](const float4& a, const float4& b) {
             const f3 e_nee{a.x, a.y, a.z};
             const f3 e_f{a.w, b.x, b.y};
             const float e_cp = b.z, e_pdf = b.w;
@@ -489,7 +488,31 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             const f3 lo = e_nee + Li * e_f * (e_cp * mis);
             Li = mk3(0.0f) + vmin(mk3(1.0f) * mk3(1.0f) * lo, mk3(8.0f));
             lp_valid = false;
+          };
+          int level = pv_length - 1;
+#if PINE_QFOLD_BATCH > 1
+          // entries are fetched PINE_QFOLD_BATCH levels at a time (all loads in flight together)
+          // instead of one dependent L2 round trip per level
+          while (level >= 0) {
+            float4 pa[PINE_QFOLD_BATCH], pb[PINE_QFOLD_BATCH];
+#pragma unroll
+            for (int j = 0; j < PINE_QFOLD_BATCH; j++)
+              if (level - j >= 0) {
+                const float4* q = fold_entry(id, level - j);
+                pa[j] = q[0];
+                pb[j] = q[1];
+              }
+#pragma unroll
+            for (int j = 0; j < PINE_QFOLD_BATCH; j++)
+              if (level - j >= 0) fold_step(pa[j], pb[j]);
+            level -= PINE_QFOLD_BATCH;
           }
+#else
+          for (; level >= 0; level--) {
+            const float4* q = fold_entry(id, level);
+            fold_step(q[0], q[1]);
+          }
+#endif
           const int s_now = st.s_cur();
           sample_base = cstu[CF_SBASE * kQCtx + id];
           pxy = cstu[CF_PXY * kQCtx + id];
@@ -593,21 +616,15 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const int px = int(pxy & 0xffffu), py = int(pxy >> 16);
         const f2 pf{(float(px) + jx) / float(S.cam.W), (float(py) + jy) / float(S.cam.H)};
         const DRay r = camera_gen_ray(S.cam, pf, f2{lx, ly});
-        cstf[CF_OX * kQCtx + id] = r.o.x;
-        cstf[CF_OY * kQCtx + id] = r.o.y;
-        cstf[CF_OZ * kQCtx + id] = r.o.z;
-        cstf[CF_DX * kQCtx + id] = r.d.x;
-        cstf[CF_DY * kQCtx + id] = r.d.y;
-        cstf[CF_DZ * kQCtx + id] = r.d.z;
-        cstf[CF_TMAX * kQCtx + id] = r.tmax;
         PackedState st{0};
         st.start_sample(s_next);
-        cstu[CF_ST * kQCtx + id] = st.v;
         cstu[CF_PXY * kQCtx + id] = pxy;
         cstu[CF_SBASE * kQCtx + id] = sample_base;
+        extend(id, r.o, r.d, r.tmax, st, to_shade2, to_term2);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      push(QS_E, valid && have_path, id);
+      push(QS_S, to_shade2, id);
+      push(QS_T, to_term2, id);
     }
     if (lane == 0) atomicSub(&qctl[QC_BUSY], 1u);
   }
