@@ -97,8 +97,10 @@ struct DTables {
   // table, and for THIS lane's current pixel the 40 ranking bytes + 8 scrambling bytes the
   // lookup needs (refreshed whenever the lane takes a new work item).
   const uint8_t* lds_sobol;
-  const uint32_t* lds_tile;  // lane / context slice: dword j at lds_tile[j * tile_stride]
-  int tile_stride;           // 256 for the per-lane LDS slices, 1 for a context's 64-byte global record
+  const uint32_t* lds_tile;  // ranking bytes: dword j (dims 4j..4j+3) at lds_tile[j * tile_stride]
+  const uint32_t* lds_scr;   // scrambling bytes: dword k (dims 4k..4k+3 mod 8) at lds_scr[k * tile_stride]
+  int tile_stride;           // = workgroup size: the slices are [dword][thread]
+  int win_lo, win_len;       // dimensions [win_lo, win_lo + win_len) are present in the cache
 };
 // value = sobol[dim + (index ^ rank[(dim + pix*8) % N]) * 256] ^ scramble[dim % 8 + pix*8]
 // (bluenoise_*spp.cpp:14-34); LDS = true reads dims < kLdsSamplerDims from the workgroup cache.
@@ -110,12 +112,12 @@ PINE_HD float blue_sample_dimension(const DTables& t, int px, int py, int index,
   const int si = index & 255;
   const int sd = dim & 255;
   if constexpr (LDS) {
-    if (sd < kLdsSamplerDims) {
+    if (unsigned(sd - t.win_lo) < unsigned(t.win_len)) {
       const unsigned sh = 8u * unsigned(sd & 3);
       const uint32_t rw = t.lds_tile[(sd >> 2) * t.tile_stride];
       const int ranked = si ^ int((rw >> sh) & 255u);
       int value = t.lds_sobol[sd * 256 + ranked];
-      const uint32_t sw = t.lds_tile[(10 + ((sd & 7) >> 2)) * t.tile_stride];
+      const uint32_t sw = t.lds_scr[((sd & 7) >> 2) * t.tile_stride];
       value = value ^ int((sw >> sh) & 255u);
       return (0.5f + float(value)) / 256.0f;
     }
@@ -266,7 +268,7 @@ PINE_HD bool box_slabs(f3 lo, f3 hi, f3 o, f3 d, float& tmin, float& tmax) {
       if (oi < l || oi > h) return false;
       continue;
     }
-    const float inv_d = 1.0f / di;
+    const float inv_d = prcp(di);
     float t_near = (l - oi) * inv_d;
     float t_far = (h - oi) * inv_d;
     if (inv_d < 0.0f) {
@@ -607,7 +609,7 @@ PINE_HD bool shape_sample(const DShape* S, const float* tri_verts, f3 o, f2 u, f
       w = mul(coordinate_system((c - o) / l), w);
       ss.w = w;
       ss.distance = sphere_compute_t(o, w, 0.0f, c, r);
-      ss.pdf = 1.0f / Sa;
+      ss.pdf = prcp(Sa);
       ss.p = o + w * ss.distance;
       ss.n = (ss.p - c) / r;
       break;
@@ -643,7 +645,7 @@ PINE_HD float shape_pdf(const DShape* S, const DRay& ray, f3 ns) {
       const float l = length(ld3(f) - ray.o);
       const float cos_theta = psqrt(1 - sqr(f[3] / l));
       const float Sa = 2 * kPi * (1 - cos_theta);
-      return 1.0f / Sa;
+      return prcp(Sa);
     }
     case SHAPE_DISK: if constexpr (!(F & F_DISK)) __builtin_unreachable(); else { return sqr(ray.tmax) / (f[13] * absdot(ns, ray.d)); }  // :166-168
     case SHAPE_CONE: if constexpr (!(F & F_CONE)) __builtin_unreachable(); else { return sqr(ray.tmax) / f[11] * absdot(ns, ray.d); }  // :462-464

@@ -49,7 +49,11 @@ constexpr int kMaxDepth = 32;    // max_path_length supported (2 beta bits per l
 // product build; the stamps only go to Counters::section_cycles, which nothing else reads.
 #ifdef PINE_PROFILE_SECTIONS
 __device__ unsigned long long g_region_lanes[16], g_region_hits[16];
-// REGION(id): average number of active lanes at a code region's entry (divergence probe)
+// REGION(id): average number of active lanes at a code region's entry (divergence probe;
+// -DPINE_PROFILE_REGIONS on top, as its global atomics distort the section times)
+#ifndef PINE_PROFILE_REGIONS
+#define REGION(id)
+#else
 #define REGION(id)                                                                  \
   do {                                                                              \
     const unsigned long long m_ = __ballot(1);                                      \
@@ -58,6 +62,7 @@ __device__ unsigned long long g_region_lanes[16], g_region_hits[16];
       atomicAdd(&g_region_hits[id], 1ull);                                          \
     }                                                                               \
   } while (0)
+#endif
 #define SEC_DECL unsigned long long sec_t = __builtin_readcyclecounter(), sec_acc[16] = {0}
 #define SEC_MARK(id)                                              \
   do {                                                            \
@@ -381,7 +386,10 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   DTables T = S.tables;
   T.lds_sobol = reinterpret_cast<const uint8_t*>(lds_raw + kOffSobol);
   T.lds_tile = lds_u + kOffTile + tid;
+  T.lds_scr = lds_u + kOffTile + tid + 10 * kLdsLaneStride;
   T.tile_stride = kLdsLaneStride;
+  T.win_lo = 0;
+  T.win_len = kLdsSamplerDims;
   SceneView V;
   V.tri_verts = S.tri_verts;
   V.stack_top = S.stack_top;
@@ -1204,7 +1212,10 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.tables.rank = p->d_tables + 65536 + 131072;
   S.tables.lds_sobol = nullptr;
   S.tables.lds_tile = nullptr;
+  S.tables.lds_scr = nullptr;
   S.tables.tile_stride = 0;
+  S.tables.win_lo = 0;
+  S.tables.win_len = 0;
   S.spp = spp;
   S.max_path_length = prm->max_path_length;
   int d_top = 0, d_mesh = 0;

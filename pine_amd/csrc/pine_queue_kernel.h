@@ -25,7 +25,10 @@
 
 namespace pine_gpu {
 
-constexpr int kQBlock = 1024;  // threads per workgroup
+#ifndef PINE_QBLOCK
+#define PINE_QBLOCK 1024
+#endif
+constexpr int kQBlock = PINE_QBLOCK;  // threads per workgroup (one workgroup per CU: kQBlock / 256 waves per SIMD)
 #ifndef PINE_QCTX
 #define PINE_QCTX 1536
 #endif
@@ -38,7 +41,7 @@ enum : int { QS_S = 0, QS_T = 1, QS_COUNT = 2 };
 enum : int { CF_OX, CF_OY, CF_OZ, CF_DX, CF_DY, CF_DZ, CF_TMAX, CF_ST, CF_PXY, CF_SBASE, CF_GEOM, CF_PRIM };
 constexpr unsigned kStFresh = 0xffffffffu;  // context has no path yet
 // control words
-enum : int { QC_HEAD = 0, QC_TAIL = 3, QC_BUSY = 6, /* heads at 0..1, tails at 3..4 */ QC_LOCK = 7, QC_PNEXT = 8, QC_PEND = 10, QC_EXHAUSTED = 12, QC_ABORT = 13, QC_WORDS = 16 };
+enum : int { QC_HEAD = 0, QC_TAIL = 2, QC_BUSY = 6, /* heads at 0..1, tails at 2..3 (one u64) */ QC_LOCK = 7, QC_PNEXT = 8, QC_PEND = 10, QC_EXHAUSTED = 12, QC_ABORT = 13, QC_WORDS = 16 };
 constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a protocol bug must end the kernel, not hang the GPU
 
 // LDS layout (dword offsets)
@@ -46,7 +49,9 @@ constexpr int kQOffCtl = 0;
 constexpr int kQOffRing = kQOffCtl + QC_WORDS;                 // 3 rings of kQRing dwords (id + 1, 0 = empty)
 constexpr int kQOffState = kQOffRing + QS_COUNT * kQRing;
 constexpr int kQOffSobol = kQOffState + kQFields * kQCtx;
-constexpr int kQOffStack = kQOffSobol + kLdsSamplerDims * 256 / 4;
+constexpr int kQWinDwords = 5;  // per-thread sampler window: 3 dwords of ranking bytes (12 dimensions) + 2 of scrambling bytes
+constexpr int kQOffWin = kQOffSobol + kLdsSamplerDims * 256 / 4;
+constexpr int kQOffStack = kQOffWin + kQWinDwords * kQBlock;
 constexpr size_t kQLdsFixedBytes = size_t(kQOffStack) * 4;
 
 // per-context global record: 16 dwords = one 64-byte line
@@ -56,7 +61,7 @@ constexpr int kQCtxGlobalDwords = 16;
 // Not instantiated with F_SSS: the BSSRDF beta channel per pending level is not carried by the
 // contexts (scenes with Subsurface materials run path_trace_kernel).
 template <unsigned F>
-__global__ void __launch_bounds__(kQBlock, 4)
+__global__ void __launch_bounds__(kQBlock, kQBlock / 256)
 path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -115,26 +120,34 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   auto ctx_global = [&](int id) -> uint32_t* { return ctxg + (ctx_base + size_t(id)) * kQCtxGlobalDwords; };
   auto lds_load = [](const unsigned* p) -> unsigned { return __atomic_load_n(p, __ATOMIC_RELAXED); };
 
-  // push the contexts of lanes with `pred` to queue q (ballot compaction: one LDS atomic per wave)
-  auto push = [&](int q, bool pred, int id) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0) return;
-    const unsigned cnt = __popcll(m);
-    unsigned base = 0;
-    if (lane == unsigned(__ffsll((long long)m) - 1)) base = atomicAdd(&qctl[QC_TAIL + q], cnt);
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (pred) {
-      const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
-      __atomic_store_n(&ring[q * kQRing + ((base + rank) & (kQRing - 1))], unsigned(id + 1), __ATOMIC_RELAXED);
+  // push the contexts of lanes with to_s / to_t to the shade / terminal queue: ballot compaction,
+  // and ONE 64-bit LDS atomic per wave reserves the slots in both rings (the two tails are one u64)
+  auto push2 = [&](bool to_s, bool to_t, int id) {
+    const unsigned long long ms = __ballot(to_s), mt = __ballot(to_t);
+    if ((ms | mt) == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0)
+      base = atomicAdd(reinterpret_cast<unsigned long long*>(&qctl[QC_TAIL]),
+                       (unsigned long long)__popcll(ms) | ((unsigned long long)__popcll(mt) << 32));
+    const unsigned base_s = __builtin_amdgcn_readfirstlane(unsigned(base));
+    const unsigned base_t = __builtin_amdgcn_readfirstlane(unsigned(base >> 32));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (to_s | to_t) {
+      const unsigned slot = to_s ? unsigned(QS_S * kQRing) + ((base_s + unsigned(__popcll(ms & below))) & (kQRing - 1))
+                                 : unsigned(QS_T * kQRing) + ((base_t + unsigned(__popcll(mt & below))) & (kQRing - 1));
+      __atomic_store_n(&ring[slot], unsigned(id + 1), __ATOMIC_RELAXED);
     }
   };
 
+  SEC_DECL;
   // trace the context's new ray (closest hit), record the hit, classify the vertex it reaches:
   // emissive / miss / path-length limit -> terminal queue, otherwise -> shade queue
   auto extend = [&](int id, f3 o, f3 d, float tmax, PackedState st, bool& to_shade, bool& to_term) {
     DRay ray{o, d, 0.0f, tmax};
     int geom = -1, prim = 0;
+    SEC_MARK(5);  // S: BSDF sample + fold store + spawn  /  T: camera ray
     const bool hit = scene_traverse<false, F, kQBlock>(V, ray, stack, geom, prim);
+    SEC_MARK(6);  // closest-hit traversal
     cstf[CF_OX * kQCtx + id] = o.x;
     cstf[CF_OY * kQCtx + id] = o.y;
     cstf[CF_OZ * kQCtx + id] = o.z;
@@ -168,49 +181,49 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
   unsigned main_trips = 0;
   while (true) {
+    SEC_MARK(10);  // push + busy release
     if (++main_trips > (1u << 26)) {  // safety net: a wave never loops unboundedly
       if (lane == 0) bail(5, main_trips, 0);
       break;
     }
     // ---------------- pick a stage: the fullest queue (lane 0 decides, result broadcast) ----------------
+    // All lanes read the same control words (LDS broadcast) and the values are made wave-uniform
+    // (readfirstlane), so the decision itself is scalar code; only the atomics run on lane 0.
     int stage = -1;
     unsigned n = 0, h = 0;
     bool finished = false;
-    if (lane == 0) {
-      unsigned cnt[QS_COUNT];
-      int best = 0;
-      for (int q = 0; q < QS_COUNT; q++) {
-        const unsigned hq = lds_load(&qctl[QC_HEAD + q]);  // head first: both only grow, so the
-        const unsigned tq = lds_load(&qctl[QC_TAIL + q]);  // difference can only be over-estimated
-        cnt[q] = tq - hq;
-        if (cnt[q] > cnt[best]) best = q;
-      }
-      const unsigned busy = lds_load(&qctl[QC_BUSY]);
-      if (cnt[best] >= 64u || (cnt[best] > 0u && (busy == 0u || spins >= 8u))) {
+    {
+      auto uload = [&](int w) -> unsigned { return __builtin_amdgcn_readfirstlane(lds_load(&qctl[w])); };
+      const unsigned h_s = uload(QC_HEAD + QS_S), h_t = uload(QC_HEAD + QS_T);  // heads first: heads and tails
+      const unsigned t_s = uload(QC_TAIL + QS_S), t_t = uload(QC_TAIL + QS_T);  // only grow, so a count can only be over-estimated
+      const unsigned busy = uload(QC_BUSY);
+      const unsigned cnt_s = t_s - h_s, cnt_t = t_t - h_t;
+      const int best = cnt_t > cnt_s ? QS_T : QS_S;
+      const unsigned cnt_best = cnt_t > cnt_s ? cnt_t : cnt_s;
+      if (cnt_best >= 64u || (cnt_best > 0u && (busy == 0u || spins >= 8u))) {
         // count ourselves busy BEFORE taking items out of the queue, so that "all queues empty and
         // nobody busy" really means no work can appear any more (idle pollers never touch the
         // counter: two of them must not keep each other alive)
-        atomicAdd(&qctl[QC_BUSY], 1u);
-        const unsigned h0 = lds_load(&qctl[QC_HEAD + best]);
-        const unsigned avail = lds_load(&qctl[QC_TAIL + best]) - h0;
-        const unsigned want = avail < 64u ? avail : 64u;
-        if (want > 0u && want <= 64u && atomicCAS(&qctl[QC_HEAD + best], h0, h0 + want) == h0) {
+        const unsigned h0 = cnt_t > cnt_s ? h_t : h_s;
+        const unsigned want = cnt_best < 64u ? cnt_best : 64u;
+        unsigned got = 0;
+        if (lane == 0) {
+          atomicAdd(&qctl[QC_BUSY], 1u);
+          if (atomicCAS(&qctl[QC_HEAD + best], h0, h0 + want) == h0) got = 1;  // head unchanged => [h0, h0+want) is ours (tail >= the value read)
+          else atomicSub(&qctl[QC_BUSY], 1u);
+        }
+        if (__builtin_amdgcn_readfirstlane(got)) {
           stage = best;
           n = want;
           h = h0;
-        } else {
-          atomicSub(&qctl[QC_BUSY], 1u);
         }
       } else {
-        finished = cnt[0] == 0u && cnt[1] == 0u && busy == 0u;
+        finished = cnt_s == 0u && cnt_t == 0u && busy == 0u;
       }
     }
-    stage = __shfl(stage, 0);
-    n = __shfl(n, 0);
-    h = __shfl(h, 0);
-    finished = __shfl(int(finished), 0) != 0;
-    if (lds_load(&qctl[QC_ABORT]) != 0u) break;
+    if (__builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_ABORT])) != 0u) break;
     if (stage < 0) {
+      SEC_MARK(11);  // idle poll
       if (finished) break;
       spins++;
       if (++idle_polls > kQSpinLimit) {
@@ -244,6 +257,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     }
     if (id < 0) valid = false;  // (only after a bounded-spin bail-out)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    SEC_MARK(0);  // pick + pop
 
     if (stage == QS_S) {
       // ================= shade a non-terminal vertex (path.cpp:91-120) =================
@@ -257,10 +271,28 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const int geom = int(cstu[CF_GEOM * kQCtx + id]);
         const int prim = int(cstu[CF_PRIM * kQCtx + id]);
         uint32_t* const cg = ctx_global(id);
+        // Sampler window: this vertex draws dimensions dim .. dim+4 (light 2+1, BSDF 2).  Fetch the
+        // ranking dwords covering [4*(dim/4), +12) and the two scrambling dwords from the context's
+        // record NOW, all at once (one L2 round trip instead of one per draw), and park them in this
+        // thread's LDS slots; draws outside the window fall back to the global tables.
+        const int wbase = (st.dim() >> 2) < 9 ? (st.dim() >> 2) : 9;  // the loads stay inside the 16-dword record
+        unsigned* const win = reinterpret_cast<unsigned*>(lds_raw + kQOffWin) + tid;
+        {
+          const uint32_t w0 = cg[wbase], w1 = cg[wbase + 1], w2 = cg[wbase + 2];
+          const uint2 sc = *reinterpret_cast<const uint2*>(cg + 10);
+          win[0] = w0;
+          win[kQBlock] = w1;
+          win[2 * kQBlock] = w2;
+          win[3 * kQBlock] = sc.x;
+          win[4 * kQBlock] = sc.y;
+        }
         DTables T = S.tables;
         T.lds_sobol = reinterpret_cast<const uint8_t*>(lds_raw + kQOffSobol);
-        T.lds_tile = cg;
-        T.tile_stride = 1;
+        T.lds_tile = win - wbase * kQBlock;
+        T.lds_scr = win + 3 * kQBlock;
+        T.tile_stride = kQBlock;
+        T.win_lo = wbase * 4;
+        T.win_len = (wbase * 4 + 12 <= kLdsSamplerDims ? 12 : kLdsSamplerDims - wbase * 4);
         DSampler sampler;
         sampler.px = int(pxy & 0xffffu);
         sampler.py = int(pxy >> 16);
@@ -373,6 +405,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             }
           }
         }
+        SEC_MARK(1);  // S: state load, surface, frame, material
         // ---- next-event estimation (path.cpp:98-113) ----
         f3 nee = mk3(0.0f);
         if (!bxdf_is_delta<F>(bx)) {
@@ -390,7 +423,10 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                 shadow_count++;
                 DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
                 int g2, p2;
-                if (!scene_traverse<true, F, kQBlock>(V, sr, stack, g2, p2)) {
+                SEC_MARK(2);  // S: sampler draws + light sampling
+                const bool occluded = scene_traverse<true, F, kQBlock>(V, sr, stack, g2, p2);
+                SEC_MARK(3);  // S: shadow traversal
+                if (!occluded) {
                   const f3 le = ld3(lmat->color);
                   bx.albedo = ld3(mat->color);
                   bx.albedo_over_pi = ld3(mat->color_over_pi);
@@ -404,6 +440,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             }
           }
         }
+        SEC_MARK(4);  // S: NEE evaluation
         // ---- BSDF sampling + continuation (path.cpp:114-120) ----
         bx.albedo = ld3(mat->color);
         bx.albedo_over_pi = ld3(mat->color_over_pi);
@@ -433,9 +470,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           to_term = true;
         }
       }
+      SEC_MARK(9);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      push(QS_S, to_shade, id);
-      push(QS_T, to_term, id);
+      push2(to_shade, to_term, id);
     } else {
       // ================= terminal: result, backward fold, store, next sample / item =================
       bool need_item = false, have_path = false;
@@ -522,6 +559,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           else have_path = true;
         }
       }
+      SEC_MARK(7);  // T: terminal result + backward fold + sample store
       // ---- hand out work items to the contexts that need one (block pool, refilled from the global queue) ----
       for (unsigned rounds = 0;; rounds++) {
         const unsigned long long m = __ballot(need_item);
@@ -603,6 +641,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           }
         }
       }
+      SEC_MARK(8);  // T: work-item hand-out
       // ---- start the next camera sample (path.cpp:34-36) ----
       if (valid && have_path) {
         uint4* cg4 = reinterpret_cast<uint4*>(ctx_global(id));
@@ -622,13 +661,14 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         cstu[CF_SBASE * kQCtx + id] = sample_base;
         extend(id, r.o, r.d, r.tmax, st, to_shade2, to_term2);
       }
+      SEC_MARK(9);  // state store + classification
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      push(QS_S, to_shade2, id);
-      push(QS_T, to_term2, id);
+      push2(to_shade2, to_term2, id);
     }
     if (lane == 0) atomicSub(&qctl[QC_BUSY], 1u);
   }
 
+  SEC_FLUSH();
   unsigned long long sc = shadow_count;
   for (int off = 32; off > 0; off >>= 1) sc += __shfl_down(sc, off);
   if (lane == 0) atomicAdd(&counters->shadow_rays, sc);

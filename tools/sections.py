@@ -7,6 +7,9 @@ import torch, pine_amd
 from pine_amd import scenes, _lib
 names = ["loop", "regen", "trav_closest", "surface+terminal", "sample_bxdf", "light_sample", "trav_shadow",
          "nee_eval", "bsdf_sample+push", "fold+store"]
+if os.environ.get("PINE_GPU_KERNEL") == "queue":
+    names = ["pick+pop", "S:load+surface", "S:sampler+light", "S:shadow trav", "S:nee eval", "bsdf+fold store / camera",
+             "closest trav", "T:result+fold", "T:items", "state store", "push", "idle"]
 cam = sys.argv[1] if len(sys.argv) > 1 else "committed"
 scene = scenes.cbox((640, 640), cam)
 plan = pine_amd.Plan(scene, 256, 8, timing=True)
