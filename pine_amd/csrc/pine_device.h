@@ -358,9 +358,9 @@ PINE_HD bool cone_quadratic(const float* f, const DRay& ray, float& tmax, float&
 }
 
 template <unsigned F = F_ALL>
-PINE_HD bool shape_hit(const DShape* S, const DRay& ray) {
+PINE_HD bool shape_hit(int kind, const DShape* S, const DRay& ray) {
   const float* f = S->f;
-  switch (S->kind) {
+  switch (kind) {
     case SHAPE_RECT: {
       float t;
       return rect_test(f, ray, t);
@@ -401,9 +401,14 @@ PINE_HD bool shape_hit(const DShape* S, const DRay& ray) {
 }
 
 template <unsigned F = F_ALL>
-PINE_HD bool shape_intersect(const DShape* S, DRay& ray) {
+PINE_HD bool shape_hit(const DShape* S, const DRay& ray) {
+  return shape_hit<F>(S->kind, S, ray);
+}
+
+template <unsigned F = F_ALL>
+PINE_HD bool shape_intersect(int kind, const DShape* S, DRay& ray) {
   const float* f = S->f;
-  switch (S->kind) {
+  switch (kind) {
     case SHAPE_RECT: {
       float t;
       if (!rect_test(f, ray, t)) return false;
@@ -456,6 +461,11 @@ PINE_HD bool shape_intersect(const DShape* S, DRay& ray) {
     }
     default: return false;
   }
+}
+
+template <unsigned F = F_ALL>
+PINE_HD bool shape_intersect(const DShape* S, DRay& ray) {
+  return shape_intersect<F>(S->kind, S, ray);
 }
 
 // AABB::compute_surface_info bbox.cpp:122-129

@@ -383,6 +383,7 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
     tp.index = int(gi);
     top.push_back(tp);
   }
+  accel.top_prim_begin = int(accel.prims.size());
   if (!top.empty()) accel.bvhs[0] = build_one(std::move(top), accel.nodes, accel.prims, 0, nullptr);
   accel.built = true;
 }

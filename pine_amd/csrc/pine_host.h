@@ -67,6 +67,7 @@ struct HostGeometry {
 struct FlatAccel {
   std::vector<DNode> nodes;
   std::vector<int> prims;  // leaf primitive ids (top level: geometry index; mesh: triangle index)
+  int top_prim_begin = 0;  // prims[top_prim_begin ..) belong to the top-level BVH
   std::vector<DBvh> bvhs;  // [0] = top level, then one per mesh in lbvh order
   std::vector<float> tri_verts;    // all meshes: 9 floats per triangle (v0,v1,v2), mesh after mesh
   bool built = false;

@@ -192,6 +192,7 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
 
 // ANY: BVH::hit (bvh.cpp:497-511).  !ANY: BVH::intersect (bvh.cpp:513-548) minus the final
 // compute_surface_info, which the caller does once for the winning primitive.
+// geom_out receives the winning primitive's PACKED word (index | emissive bit | kind).
 template <bool ANY, unsigned F, int STRIDE = kBlock>
 __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, int* stack, int& geom_out,
                                                int& prim_out) {
@@ -202,10 +203,12 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
   auto leaf = [&](int start, int count) -> bool {
     for (int i = start; i < start + count; i++) {
       REGION(ANY ? 5 : 2);  // leaf primitive test
-      const int g = S.prims[i];
+      const int word = S.prims[i];
+      const int g = word & kPrimIndexMask;
+      const int kind = word >> kPrimKindShift;
       const DShape* sh = &S.shapes[g];
       bool is_mesh = false;
-      if constexpr (F & F_MESH) is_mesh = sh->kind == SHAPE_MESH;
+      if constexpr (F & F_MESH) is_mesh = kind == SHAPE_MESH;
       if (is_mesh) {
         if constexpr (F & F_MESH) {
           const DBvh mb = S.bvhs[as_int(sh->f[2])];
@@ -215,15 +218,15 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
             if (h) return true;
           } else if (h) {
             hit = true;
-            geom_out = g;
+            geom_out = word;
             prim_out = prim;
           }
         }
       } else if (ANY) {
-        if (shape_hit<F>(sh, ray)) return true;
-      } else if (shape_intersect<F>(sh, ray)) {
+        if (shape_hit<F>(kind, sh, ray)) return true;
+      } else if (shape_intersect<F>(kind, sh, ray)) {
         hit = true;
-        geom_out = g;
+        geom_out = word;
       }
     }
     return false;
@@ -584,6 +587,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     {
       DRay ray{ray_o, ray_d, 0.0f, ray_tmax};
       hit = scene_traverse<false, F>(V, ray, stack, geom, prim);
+      if (hit) geom &= kPrimIndexMask;  // (the packed word's flag bits are used by the queue kernel only)
       ray_tmax = ray.tmax;
     }
     SEC_MARK(2);  // closest-hit traversal
@@ -1175,7 +1179,17 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.off_shapes = put(shapes.data(), shapes.size() * sizeof(DShape));
   S.off_materials = put(H.materials.data(), H.materials.size() * sizeof(DMaterial));
   S.off_bvhs = put(A.bvhs.data(), A.bvhs.size() * sizeof(DBvh));
-  S.off_prims = put(A.prims.data(), A.prims.size() * sizeof(int));
+  std::vector<int> packed_prims = A.prims;  // top-level entries: geometry | emissive | kind (pine_types.h)
+  for (size_t i = size_t(A.top_prim_begin); i < packed_prims.size(); i++) {
+    const int g = packed_prims[i];
+    if (g > kPrimIndexMask) {
+      set_error("too many geometries for the packed primitive word");
+      return -1;
+    }
+    const DShape& sh = shapes[size_t(g)];
+    packed_prims[i] = g | (H.materials[size_t(sh.material)].kind == MAT_EMISSIVE ? kPrimEmissiveBit : 0) | (sh.kind << kPrimKindShift);
+  }
+  S.off_prims = put(packed_prims.data(), packed_prims.size() * sizeof(int));
   S.off_lights = put(H.lights.data(), H.lights.size() * sizeof(int));
   blob.resize((blob.size() + 15) & ~size_t(15));
   S.blob_bytes = int(blob.size());
@@ -1264,15 +1278,18 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     return -1;
   }
   if (kVariants[p->variant].features & F_LDS_SCENE) p->lds_bytes += size_t(S.blob_bytes);
-  // optional: the stage-queued kernel (PINE_GPU_KERNEL=queue), when a variant covers the scene and its LDS fits
+  // The stage-queued kernel is the default whenever a variant covers the scene and its LDS fits
+  // (not for Subsurface materials and meshes: see pine_queue_kernel.h); PINE_GPU_KERNEL=mega forces
+  // the lane-owns-a-path kernel, which covers every scene.
   p->queue_variant = -1;
   {
     const char* ksel = getenv("PINE_GPU_KERNEL");
-    if (ksel && std::string(ksel) == "queue" && !(need & (F_SSS | F_MESH))) {
+    const bool want_queue = !(ksel && std::string(ksel) == "mega");
+    if (want_queue && !(need & (F_SSS | F_MESH))) {
       for (int v = 0; v < kNumQueueVariants; v++) {
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
-        if (((F & F_LDS_SCENE) != 0) != lds_ok) continue;
+        if ((F & F_LDS_SCENE) && !lds_ok) continue;  // (a scene-in-global variant later in the table is the fallback when LDS is short)
         const size_t lds = kQLdsFixedBytes + size_t(S.stack_total) * kQBlock * sizeof(int) +
                            ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0);
         if (lds > 160 * 1024) continue;

@@ -158,11 +158,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     cstu[CF_ST * kQCtx + id] = st.v;
     cstu[CF_GEOM * kQCtx + id] = unsigned(hit ? geom : -1);
     cstu[CF_PRIM * kQCtx + id] = unsigned(prim);
-    bool terminal = !hit;
-    if (hit) {
-      const DShape* shape = &V.shapes[geom];
-      terminal = V.materials[shape->material].kind == MAT_EMISSIVE || st.length() + 1 >= S.max_path_length;
-    }
+    // (geom is the packed primitive word: the emissive flag rides along, no record fetch needed)
+    const bool terminal = !hit || (geom & kPrimEmissiveBit) != 0 || st.length() + 1 >= S.max_path_length;
     to_shade = !terminal;
     to_term = terminal;
   };
@@ -268,7 +265,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const float ray_tmax = cstf[CF_TMAX * kQCtx + id];
         PackedState st{cstu[CF_ST * kQCtx + id]};
         const unsigned pxy = cstu[CF_PXY * kQCtx + id];
-        const int geom = int(cstu[CF_GEOM * kQCtx + id]);
+        const int geom = int(cstu[CF_GEOM * kQCtx + id]) & kPrimIndexMask;
         const int prim = int(cstu[CF_PRIM * kQCtx + id]);
         uint32_t* const cg = ctx_global(id);
         // Sampler window: this vertex draws dimensions dim .. dim+4 (light 2+1, BSDF 2).  Fetch the
@@ -491,10 +488,10 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           float lp = 0.0f;
           if (geom == -2) {
             Lo = f3{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
-          } else if (geom >= 0) {
-            const DShape* shape = &V.shapes[geom];
+          } else if (geom >= 0 && (geom & kPrimEmissiveBit) != 0) {
+            const DShape* shape = &V.shapes[geom & kPrimIndexMask];
             const DMaterial* mat = &V.materials[shape->material];
-            if (mat->kind == MAT_EMISSIVE) {  // path.cpp:83-87
+            {  // path.cpp:83-87
               const f3 ray_o{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
               const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
               const float ray_tmax = cstf[CF_TMAX * kQCtx + id];

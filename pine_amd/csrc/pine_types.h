@@ -67,6 +67,14 @@ struct alignas(16) DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
 
+// Top-level leaf primitive words on the DEVICE are packed: geometry index | emissive flag | kind, so
+// that the leaf loop knows which intersection routine to run (and the path kernel whether the hit is
+// a light) without first fetching the shape / material records -- one dependent LDS/L2 round trip
+// less per primitive.  (The host-side FlatAccel::prims and the accel dump keep plain indices.)
+constexpr int kPrimIndexMask = 0x07ffffff;
+constexpr int kPrimEmissiveBit = 1 << 27;
+constexpr int kPrimKindShift = 28;  // kinds 0..6 -> the packed word stays non-negative
+
 // One BVH (top level or per mesh).  If root_count > 0 the root itself is a leaf
 // (bvh.cpp:331-334,396-399): test prim_index[root_start .. root_start+root_count) and stop.
 struct DBvh {

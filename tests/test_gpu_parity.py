@@ -17,6 +17,18 @@ from conftest import GOLDEN, FILM_NAMES, assert_bit_equal, load_film
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["queue", "mega"])
+def path_kernel(request, monkeypatch):
+    """Every test runs against both path kernels: the stage-queued one (the default wherever it
+    applies) and the lane-owns-a-path megakernel (PINE_GPU_KERNEL=mega; the only one for meshes and
+    Subsurface).  Both must reproduce the reference bit for bit."""
+    if request.param == "mega":
+        monkeypatch.setenv("PINE_GPU_KERNEL", "mega")
+    else:
+        monkeypatch.delenv("PINE_GPU_KERNEL", raising=False)
+    return request.param
+
+
 def _loaded_native():
     """Fail loudly if the HIP extension is not the thing that runs."""
     from pine_amd import _lib
@@ -136,11 +148,12 @@ def test_one_shot_host_film_entry_point():
     ("cbox", (128, 128), "readme", False, 128, 8),
     ("cbox", (8, 8), "readme", True, 2, 12),
 ])
-def test_film_matches_oracle(oracle, cfg):
+def test_film_matches_oracle(oracle, cfg, path_kernel):
     from pine_amd import scenes
     _, size, cam, boxes, spp, depth = cfg
     sc = scenes.cbox(size, cam, boxes)
     film, st = _render(sc, spp, depth)
+    assert st.block_threads == (1024 if path_kernel == "queue" else 256)  # the kernel under test is the one that ran
     ref, ost = oracle.render(sc.describe(), size, spp, depth)
     assert_bit_equal(film, ref, str(cfg))
     assert st.vertices == ost.vertices and st.shadow_rays == ost.shadow_rays  # same work, vertex for vertex
