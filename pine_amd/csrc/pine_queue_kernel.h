@@ -54,9 +54,9 @@ constexpr int kQOffWin = kQOffSobol + kLdsSamplerDims * 256 / 4;
 constexpr int kQOffStack = kQOffWin + kQWinDwords * kQBlock;
 constexpr size_t kQLdsFixedBytes = size_t(kQOffStack) * 4;
 
-// per-context global record: 16 dwords = one 64-byte line
-//   [0..9] ranking bytes of the pixel for dims 0..39, [10..11] scrambling bytes, [12..15] RNG state
-constexpr int kQCtxGlobalDwords = 16;
+// per-context global record: the pixel's RNG state (2 x u64).  The sampler's per-pixel ranking and
+// scrambling bytes are read straight from the 256 KB tables (L2-resident, shared by every context).
+constexpr int kQCtxGlobalDwords = 4;
 
 // Not instantiated with F_SSS: the BSSRDF beta channel per pending level is not carried by the
 // contexts (scenes with Subsurface materials run path_trace_kernel).
@@ -268,15 +268,18 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const int geom = int(cstu[CF_GEOM * kQCtx + id]) & kPrimIndexMask;
         const int prim = int(cstu[CF_PRIM * kQCtx + id]);
         uint32_t* const cg = ctx_global(id);
-        // Sampler window: this vertex draws dimensions dim .. dim+4 (light 2+1, BSDF 2).  Fetch the
-        // ranking dwords covering [4*(dim/4), +12) and the two scrambling dwords from the context's
-        // record NOW, all at once (one L2 round trip instead of one per draw), and park them in this
-        // thread's LDS slots; draws outside the window fall back to the global tables.
-        const int wbase = (st.dim() >> 2) < 9 ? (st.dim() >> 2) : 9;  // the loads stay inside the 16-dword record
+        // Sampler window: this vertex draws dimensions dim .. dim+4 (light 2+1, BSDF 2).  The pixel's
+        // ranking bytes for dimension d sit at rank[pix*8 + d] (bluenoise_*spp.cpp:14-34), so the
+        // dwords covering [4*(dim/4), +12) and the 8 scrambling bytes are fetched NOW, all at once
+        // (one L2 round trip instead of one per draw), and parked in this thread's LDS slots; draws
+        // outside the window fall back to the byte-wise table path.
+        const int wbase = (st.dim() >> 2) < 9 ? (st.dim() >> 2) : 9;  // (the device table has 64 bytes of wrap-around padding)
         unsigned* const win = reinterpret_cast<unsigned*>(lds_raw + kQOffWin) + tid;
         {
-          const uint32_t w0 = cg[wbase], w1 = cg[wbase + 1], w2 = cg[wbase + 2];
-          const uint2 sc = *reinterpret_cast<const uint2*>(cg + 10);
+          const int pix = int(pxy & 127u) + int((pxy >> 16) & 127u) * 128;
+          const uint32_t* rk = reinterpret_cast<const uint32_t*>(S.tables.rank + size_t(pix) * 8) + wbase;
+          const uint32_t w0 = rk[0], w1 = rk[1], w2 = rk[2];
+          const uint2 sc = *reinterpret_cast<const uint2*>(S.tables.scramble + size_t(pix) * 8);
           win[0] = w0;
           win[kQBlock] = w1;
           win[2 * kQBlock] = w2;
@@ -322,13 +325,13 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         if constexpr (F & F_UBER) is_uber = mat->kind == MAT_UBER;
         if constexpr (F & F_SSS) is_sss = mat->kind == MAT_SUBSURFACE;
         auto rng_load = [&]() -> DRng {
-          return DRng{uint64_t(cg[12]) | (uint64_t(cg[13]) << 32), uint64_t(cg[14]) | (uint64_t(cg[15]) << 32)};
+          return DRng{uint64_t(cg[0]) | (uint64_t(cg[1]) << 32), uint64_t(cg[2]) | (uint64_t(cg[3]) << 32)};
         };
         auto rng_store = [&](const DRng& g) {
-          cg[12] = uint32_t(g.s0);
-          cg[13] = uint32_t(g.s0 >> 32);
-          cg[14] = uint32_t(g.s1);
-          cg[15] = uint32_t(g.s1 >> 32);
+          cg[0] = uint32_t(g.s0);
+          cg[1] = uint32_t(g.s0 >> 32);
+          cg[2] = uint32_t(g.s1);
+          cg[3] = uint32_t(g.s1 >> 32);
         };
         if (is_uber) {
           DRng g = rng_load();
@@ -474,9 +477,15 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       // ================= terminal: result, backward fold, store, next sample / item =================
       bool need_item = false, have_path = false;
       bool to_shade2 = false, to_term2 = false;
+      bool fresh_rng = false;  // the context took a new work item this round: its RNG state is in item_rng, not yet in memory
+      DRng item_rng{0, 0};
       unsigned pxy = 0, sample_base = 0;
       int s_next = 0;
+      uint4 rng_words = make_uint4(0, 0, 0, 0);
       if (valid) {
+        // the pixel's RNG state is needed only for the next camera sample, but its L2 round trip
+        // starts here so that it overlaps the fold loop's
+        rng_words = *reinterpret_cast<const uint4*>(ctx_global(id));
         const PackedState st{cstu[CF_ST * kQCtx + id]};
         if (st.v == kStFresh) {
           need_item = true;
@@ -618,15 +627,6 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             pxy = unsigned(itf.px) | (unsigned(itf.py) << 16);
             sample_base = unsigned(itf.sample_base);
             s_next = itf.chunk * W.samples_per_item;
-            uint32_t* const cg = ctx_global(id);
-            const int pix = (itf.px & 127) + (itf.py & 127) * 128;
-            const uint2* rsrc = reinterpret_cast<const uint2*>(S.tables.rank + size_t(pix) * 8);
-            const uint2 sc = *reinterpret_cast<const uint2*>(S.tables.scramble + size_t(pix) * 8);
-            uint4* cg4 = reinterpret_cast<uint4*>(cg);
-            const uint2 r0 = rsrc[0], r1 = rsrc[1], r2 = rsrc[2], r3 = rsrc[3], r4 = rsrc[4];
-            cg4[0] = make_uint4(r0.x, r0.y, r1.x, r1.y);
-            cg4[1] = make_uint4(r2.x, r2.y, r3.x, r3.y);
-            cg4[2] = make_uint4(r4.x, r4.y, sc.x, sc.y);
             DRng g;
             if (W.items_per_pixel == 1) {
               g = rng_seed(hash_pixel(itf.px, itf.py, 0));
@@ -634,7 +634,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               const ulonglong2 c = ckpt[item];
               g = DRng{c.x, c.y};
             }
-            cg4[3] = make_uint4(uint32_t(g.s0), uint32_t(g.s0 >> 32), uint32_t(g.s1), uint32_t(g.s1 >> 32));
+            item_rng = g;
+            fresh_rng = true;
           }
         }
       }
@@ -642,13 +643,14 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       // ---- start the next camera sample (path.cpp:34-36) ----
       if (valid && have_path) {
         uint4* cg4 = reinterpret_cast<uint4*>(ctx_global(id));
-        const uint4 rs = cg4[3];
-        DRng g{uint64_t(rs.x) | (uint64_t(rs.y) << 32), uint64_t(rs.z) | (uint64_t(rs.w) << 32)};
+        DRng g = item_rng;
+        if (!fresh_rng)
+          g = DRng{uint64_t(rng_words.x) | (uint64_t(rng_words.y) << 32), uint64_t(rng_words.z) | (uint64_t(rng_words.w) << 32)};
         const float lx = rng_nextf(g);  // g++ argument order: lens sample first, then pixel jitter
         const float ly = rng_nextf(g);
         const float jx = rng_nextf(g);
         const float jy = rng_nextf(g);
-        cg4[3] = make_uint4(uint32_t(g.s0), uint32_t(g.s0 >> 32), uint32_t(g.s1), uint32_t(g.s1 >> 32));
+        cg4[0] = make_uint4(uint32_t(g.s0), uint32_t(g.s0 >> 32), uint32_t(g.s1), uint32_t(g.s1 >> 32));
         const int px = int(pxy & 0xffffu), py = int(pxy >> 16);
         const f2 pf{(float(px) + jx) / float(S.cam.W), (float(py) + jy) / float(S.cam.H)};
         const DRay r = camera_gen_ray(S.cam, pf, f2{lx, ly});
