@@ -13,6 +13,7 @@ N > 1    : 8x8-pixel tiles dealt round-robin to ranks (strong scaling: the film 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -140,6 +141,16 @@ def main():
         # roofline of the dominant kernel (path_trace_kernel) on this rank: algorithmic bytes per
         # launch = (192 B * vertices + 16 B * pixels) of this rank's shard / average launch duration
         k_ms = sum(trace_ms) / len(trace_ms)
+        kernel = "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel"
+        # HBM-side traffic of that kernel per launch: measured off-line with rocprofv3 PMC passes
+        # (tools/profile_round.sh -> profiles/rNN_traffic.json, latest round); null if not measured
+        # for this kernel / this GPU count
+        traffic = None
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+        if tfiles and world == 1:
+            tj = json.load(open(tfiles[-1]))
+            if tj.get("kernel", "").startswith(kernel):
+                traffic = tj["traffic_bytes_per_launch"]
         alg_bytes = B_VERTEX * verts + 16.0 * local_samples / spp_eff
         achieved = alg_bytes / (k_ms * 1e-3) * 1e-9
         out = {
@@ -152,9 +163,11 @@ def main():
                        "parallelism": f"tiles8x8-roundrobin x{world}", "samples_per_item": st.samples_per_item,
                        "grid_blocks": st.grid_blocks, "vertices_per_sample": vbar},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "path_trace_kernel", "kernel_ms": k_ms,
-                         "bytes_per_vertex": B_VERTEX, "note": "algorithmic bytes of the streaming formulation (SURVEY.md 8(d)); the kernel keeps path state in registers, so real HBM traffic is far below it and the kernel is VALU/latency bound"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 2*FETCH_SIZE+WRITE_SIZE, fabric side incl. Infinity-Cache hits)",
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": kernel, "kernel_ms": k_ms,
+                         "bytes_per_vertex": B_VERTEX, "note": "algorithmic bytes of the streaming formulation (SURVEY.md 8(d)); the kernel keeps path state in LDS and the fold stack in L2/Infinity Cache, so it is latency/VALU bound, not HBM bound"},
             "kernels_ms": {"prepass": st.prepass_ms, "path_trace": k_ms, "resolve": st.resolve_ms},
         }
         if world == 1 and not args.no_cpu:

@@ -22,14 +22,40 @@ PINE_HD float pmax(float a, float b) { return a > b ? a : b; }
 PINE_HD float sqr(float v) { return v * v; }
 PINE_HD float pclamp(float v, float a, float b) { return pmin(pmax(v, a), b); }
 PINE_HD float pabs(float v) { return fabsf(v); }
-// sqrt and reciprocal are hipcc's IEEE-correct expansions (16 and 11 VALU instructions).  Shorter
-// sequences that are ALSO correctly rounded exist for ordinary operands -- tools/rcp_test.hip shows it
-// exhaustively (v_rsq_f32, s = x*y, h = y/2, one residual step for biased exponents in [26, 230];
-// v_rcp_f32 + one Newton step for [2, 252]) -- and were tried here: -4.8 % VALU instructions but
-// only -0.4 % time (the kernels are latency-bound), and the wave-uniform fallback
-// branch they need made the analytic-shapes megakernel hang on the GPU.  Not worth it: plain forms.
-PINE_HD float psqrt(float v) { return sqrtf(v); }
-PINE_HD float prcp(float v) { return 1.0f / v; }
+// Correctly rounded sqrt / reciprocal, short forms.  hipcc's IEEE expansions cost 16 (sqrtf) and 11
+// (1.0f/x) VALU instructions because they also cover operands near the exponent limits.  For
+// ordinary operands a shorter sequence returns the SAME correctly rounded result; that is not an
+// argument but a measurement: tools/rcp_test.hip compares them with the expansions over all 2^32 bit
+// patterns on gfx950 and finds zero mismatches for biased exponents in [26, 230] (sqrt: v_rsq_f32,
+// s = x*y, h = y/2, one residual step) and [2, 252] (reciprocal: v_rcp_f32 + one Newton step).  The
+// guards below are strictly inside those ranges; anything else (zero, denormal, huge, inf, NaN)
+// redoes the operation with the full expansion in a rarely taken branch.
+// (-DPINE_NO_SHORT_FORMS: plain expansions everywhere, for A/B runs.)
+PINE_HD float psqrt(float v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PINE_NO_SHORT_FORMS)
+  const float y = __builtin_amdgcn_rsqf(v);
+  const float s0 = v * y;
+  const float h = 0.5f * y;
+  const float r = __builtin_fmaf(-s0, s0, v);
+  float s1 = __builtin_fmaf(r, h, s0);
+  if (__builtin_expect(!(v >= 0x1p-96f && v <= 0x1p+96f), 0)) s1 = sqrtf(v);
+  return s1;
+#else
+  return sqrtf(v);
+#endif
+}
+PINE_HD float prcp(float v) {  // == 1.0f / v
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PINE_NO_SHORT_FORMS)
+  const float r0 = __builtin_amdgcn_rcpf(v);
+  const float e0 = __builtin_fmaf(-v, r0, 1.0f);
+  float r1 = __builtin_fmaf(e0, r0, r0);
+  const float a = fabsf(v);
+  if (__builtin_expect(!(a >= 0x1p-120f && a <= 0x1p+120f), 0)) r1 = 1.0f / v;
+  return r1;
+#else
+  return 1.0f / v;
+#endif
+}
 // libm-exact sin/cos (see pine_libm.h); on the host these equal std::sin/std::cos of glibc.
 #ifdef PINE_ABL_SINCOS  /* experiment builds only: hardware approximations (timing only) */
 PINE_HD float psin(float v) { return __sinf(v); }

@@ -8,5 +8,5 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU S
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INST_LEVEL_VMEM --output-format csv -d gpurun_out/pmc_${tag}_C -- $B > gpurun_out/pmc_${tag}_C.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_D -- $B > gpurun_out/pmc_${tag}_D.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_${tag}_E -- $B > gpurun_out/pmc_${tag}_E.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_${tag}_*/ > gpurun_out/pmc_${tag}_summary.txt 2>&1
+python tools/pmc_summary.py --traffic-json=gpurun_out/pmc_${tag}_traffic.json gpurun_out/pmc_${tag}_*/ > gpurun_out/pmc_${tag}_summary.txt 2>&1
 cat gpurun_out/pmc_${tag}_summary.txt
