@@ -95,11 +95,26 @@ def main():
                          samples_per_item=args.spi, timing=True)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    # N > 1: every rank writes only its own tiles, tile-major, into a slab (1/N of the film); the
+    # slabs are gathered to rank 0 (direct sends over xGMI, 6.55/N MB each) and scattered into the
+    # row-major film there.  PINE_BENCH_COLLECTIVE=reduce selects the simpler form instead: full-size
+    # zero-initialised films summed to rank 0 (exact: x + 0), 6.55 MB per rank.
+    collective = os.environ.get("PINE_BENCH_COLLECTIVE", "gather") if use_dist else "none"
+    if collective == "gather":
+        slab = torch.empty(plan.slab_floats(), dtype=torch.float32, device="cuda")
+        slabs = torch.empty((world, plan.slab_floats()), dtype=torch.float32, device="cuda") if rank == 0 else None
+        slab_list = list(slabs.unbind(0)) if rank == 0 else None
 
     def step():
-        plan.launch(film.data_ptr(), stream)
-        if use_dist:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+        if collective == "gather":
+            plan.launch_packed(slab.data_ptr(), stream)
+            dist.gather(slab, slab_list, dst=0)
+            if rank == 0:
+                pine_amd.film_unpack((W, H), world, slabs.data_ptr(), film.data_ptr(), local_rank, stream)
+        else:
+            plan.launch(film.data_ptr(), stream)
+            if collective == "reduce":
+                dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
 
     def barrier():
         if use_dist:
@@ -109,13 +124,10 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    trace_ms = []
+    plan.stats()  # (discard the warm-up launches' kernel timings)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        # per-kernel HIP-event timings of this launch (events recorded on the launch stream);
-        # reading them synchronises the stream, which the next step would do anyway (same buffers)
-        trace_ms.append(plan.stats().trace_ms)
+        step()  # no host synchronisation inside the timed loop
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -123,6 +135,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # per-kernel HIP-event timings (events recorded on the launch stream inside the library): mean
+    # over the timed launches (the library keeps the last 64)
     st = plan.stats()
     spp_eff = st.spp_effective
     local_samples = st.camera_samples
@@ -140,7 +154,7 @@ def main():
         vbar = total_verts / total_samples
         # roofline of the dominant kernel (path_trace_kernel) on this rank: algorithmic bytes per
         # launch = (192 B * vertices + 16 B * pixels) of this rank's shard / average launch duration
-        k_ms = sum(trace_ms) / len(trace_ms)
+        k_ms = st.trace_ms
         kernel = "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel"
         # HBM-side traffic of that kernel per launch: measured off-line with rocprofv3 PMC passes
         # (tools/profile_round.sh -> profiles/rNN_traffic.json, latest round); null if not measured
@@ -160,7 +174,7 @@ def main():
             "data": "synthetic (scenes/cbox.pine geometry rebuilt through the API; sampler tables are the published BlueSobol data)",
             "config": {"workload": "cbox 640x640 256spp depth=8, as-committed camera, BlueSampler, pine-BVH order",
                        "film": [W, H], "spp_effective": spp_eff, "max_path_length": DEPTH,
-                       "parallelism": f"tiles8x8-roundrobin x{world}", "samples_per_item": st.samples_per_item,
+                       "parallelism": f"tiles8x8-roundrobin x{world}", "collective": collective, "samples_per_item": st.samples_per_item,
                        "grid_blocks": st.grid_blocks, "vertices_per_sample": vbar},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -168,7 +182,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel": kernel, "kernel_ms": k_ms,
                          "bytes_per_vertex": B_VERTEX, "note": "algorithmic bytes of the streaming formulation (SURVEY.md 8(d)); the kernel keeps path state in LDS and the fold stack in L2/Infinity Cache, so it is latency/VALU bound, not HBM bound"},
-            "kernels_ms": {"prepass": st.prepass_ms, "path_trace": k_ms, "resolve": st.resolve_ms},
+            "kernels_ms": {"prepass": st.prepass_ms, "path_trace": k_ms, "resolve": st.resolve_ms, "launches_averaged": st.timed_launches},
         }
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(scene)

@@ -144,19 +144,30 @@ pine_gpu_plan* pine_gpu_plan_create(pine_gpu_scene*, const pine_gpu_render_param
 int pine_gpu_plan_launch(pine_gpu_plan*, void* film_dev, void* stream);
 void pine_gpu_plan_destroy(pine_gpu_plan*);
 
+/* Multi-GPU without moving the zeros: the rank writes only its own tiles, tile-major, into a slab
+ * of pine_gpu_packed_slab_floats(...) floats ([local tile][pixel in 8x8 tile] float4; equal size on
+ * every rank, the last tile may be padding); the slabs are gathered to one rank ([rank][slab]) and
+ * pine_gpu_film_unpack scatters them into the row-major W*H float4 film there.  This replaces the
+ * reference's shared-memory film (src/pine/impl/integrator/path.cpp:38 writes film[p] from any
+ * thread) across devices.  pine_gpu_packed_offset is the host-side statement of the same mapping. */
+int pine_gpu_plan_launch_packed(pine_gpu_plan*, void* slab_dev, void* stream);
+int64_t pine_gpu_packed_slab_floats(int film_w, int film_h, int world);
+int pine_gpu_packed_offset(int film_w, int film_h, int world, int x, int y, int* rank_out, int64_t* float4_index_out);
+int pine_gpu_film_unpack(int film_w, int film_h, int world, int device, const void* slabs_dev, void* film_dev, void* stream);
+
 typedef struct {
   uint64_t camera_samples;   /* samples this plan renders per launch (its shard)              */
   uint64_t vertices;         /* radiance() invocations of the last launch    */
   uint64_t shadow_rays;
-  float trace_ms;            /* last launch: path kernel, HIP events on the launch stream      */
-  float resolve_ms;          /* last launch: ordered per-pixel sum kernel                      */
-  float prepass_ms;          /* last launch: RNG checkpoint kernel                             */
+  float trace_ms;            /* path kernel, HIP events on the launch stream: mean over the launches   */
+  float resolve_ms;          /* ordered per-pixel sum kernel                since the previous stats_get */
+  float prepass_ms;          /* RNG checkpoint kernel                       (at most the last 64)       */
   int32_t spp_effective;
   int32_t samples_per_item;
   int32_t grid_blocks;
   int32_t block_threads;
   int32_t lds_bytes;
-  int32_t reserved;
+  int32_t timed_launches;    /* number of launches the three timings are averaged over        */
 } pine_gpu_plan_stats;
 /* Blocks until the last launch has finished (needed to read the device-side counters). */
 int pine_gpu_plan_stats_get(pine_gpu_plan*, pine_gpu_plan_stats* out);

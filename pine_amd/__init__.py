@@ -2,5 +2,5 @@
 from .api import (  # noqa: F401
     Scene, Diffuse, Emissive, Uber, Subsurface, Rect, AABB, OBB, Box, Sphere, Disk, Cone, Mesh,
     Film, Uncharted2, ACES, ThinLenCamera, BlueSampler, PathIntegrator, Plan, PineError,
-    mat4, translate, scale, rotate_x, rotate_y, rotate_z, inverse, look_at,
+    mat4, translate, scale, rotate_x, rotate_y, rotate_z, inverse, look_at, film_unpack, packed_offset,
 )

@@ -48,7 +48,7 @@ class PlanStats(C.Structure):
         ("grid_blocks", C.c_int32),
         ("block_threads", C.c_int32),
         ("lds_bytes", C.c_int32),
-        ("reserved", C.c_int32),
+        ("timed_launches", C.c_int32),
     ]
 
 
@@ -91,6 +91,10 @@ SIGNATURES = {
     "pine_gpu_path_render": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), c_f_p]),
     "pine_gpu_plan_create": (C.c_void_p, [C.c_void_p, C.POINTER(RenderParams)]),
     "pine_gpu_plan_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pine_gpu_plan_launch_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pine_gpu_packed_slab_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "pine_gpu_packed_offset": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "pine_gpu_film_unpack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pine_gpu_plan_destroy": (None, [C.c_void_p]),
     "pine_gpu_plan_stats_get": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
     "pine_gpu_plan_read_samples": (C.c_int, [C.c_void_p, c_f_p, C.c_int64]),

@@ -332,6 +332,14 @@ class Plan:
     def launch(self, film_dev_ptr, stream_ptr=0):
         check(lib.pine_gpu_plan_launch(self._h, C.c_void_p(film_dev_ptr), C.c_void_p(stream_ptr)), "render")
 
+    def launch_packed(self, slab_dev_ptr, stream_ptr=0):
+        """Multi-GPU form: write only this rank's tiles, tile-major, into a slab of slab_floats() floats."""
+        check(lib.pine_gpu_plan_launch_packed(self._h, C.c_void_p(slab_dev_ptr), C.c_void_p(stream_ptr)), "render")
+
+    def slab_floats(self):
+        w, h = self.scene.camera.film().size
+        return int(lib.pine_gpu_packed_slab_floats(w, h, self.params.shard_world))
+
     def stats(self):
         st = _lib.PlanStats()
         check(lib.pine_gpu_plan_stats_get(self._h, C.byref(st)), "stats")
@@ -354,6 +362,19 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+def film_unpack(size, world, slabs_dev_ptr, film_dev_ptr, device=0, stream_ptr=0):
+    """Scatter gathered per-rank slabs ([rank][slab]) into the row-major film (device pointers)."""
+    check(lib.pine_gpu_film_unpack(int(size[0]), int(size[1]), int(world), int(device), C.c_void_p(slabs_dev_ptr),
+                                   C.c_void_p(film_dev_ptr), C.c_void_p(stream_ptr)), "film_unpack")
+
+
+def packed_offset(size, world, x, y):
+    """(rank, float4 index inside that rank's slab) of pixel (x, y): host statement of the slab layout."""
+    r, o = C.c_int(0), C.c_int64(0)
+    check(lib.pine_gpu_packed_offset(int(size[0]), int(size[1]), int(world), int(x), int(y), C.byref(r), C.byref(o)), "packed_offset")
+    return r.value, o.value
 
 
 class PathIntegrator:

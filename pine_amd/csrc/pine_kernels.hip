@@ -891,9 +891,11 @@ constexpr int kNumQueueVariants = int(sizeof(kQueueVariants) / sizeof(kQueueVari
 
 // Ordered per-pixel sum: film[p] = (sum_{s=0..spp-1, in order} L_s) / spp  (path.cpp:34-38).
 // One wave per tile, lane = pixel in tile: every sample row is one coalesced 1 KiB read.
+// `packed` != 0: the output is this rank's tile-major slab [local tile][pixel in tile] (multi-GPU gather)
+// instead of the row-major film.
 __global__ void __launch_bounds__(kBlock) resolve_kernel(WorkParams W, int film_w, int film_h, int spp,
                                                         const float4* __restrict__ samples, float4* __restrict__ film,
-                                                        Counters* __restrict__ counters) {
+                                                        Counters* __restrict__ counters, int packed) {
   const unsigned long long t = blockIdx.x * (unsigned long long)kBlock + threadIdx.x;
   const int ltile = int(t >> 6);
   if (ltile >= W.num_local_tiles) return;
@@ -904,16 +906,43 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(WorkParams W, int film_
   const float4* row = samples + (unsigned long long)ltile * (unsigned)spp * 64ull + p;
   f3 L = mk3(0.0f);
   unsigned long long verts = 0;
-  for (int s = 0; s < spp; s++) {
+  // the sum is sequential in s (path.cpp:34-37), the loads need not be: 8 rows in flight per lane
+  int s = 0;
+  for (; s + 8 <= spp; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = row[(unsigned long long)(s + j) * 64ull];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      L = L + f3{v[j].x, v[j].y, v[j].z};
+      verts += (unsigned long long)v[j].w;
+    }
+  }
+  for (; s < spp; s++) {
     const float4 v = row[(unsigned long long)s * 64ull];
     L = L + f3{v.x, v.y, v.z};
     verts += (unsigned long long)v.w;
   }
   const f3 m = L / float(spp);
-  film[size_t(py) * film_w + px] = make_float4(m.x, m.y, m.z, 1.0f);
+  const size_t out_index = packed ? size_t(ltile) * 64u + size_t(p) : size_t(py) * film_w + px;
+  film[out_index] = make_float4(m.x, m.y, m.z, 1.0f);
   // radiance() invocation count of the launch (the unit of the roofline's algorithmic bytes)
   for (int off = 32; off > 0; off >>= 1) verts += __shfl_down(verts, off);
   if ((threadIdx.x & 63) == 0) atomicAdd(&counters->vertices, verts);
+}
+
+// Multi-GPU: scatter the gathered per-rank slabs [rank][local tile][pixel in tile] into the row-major film.
+__global__ void __launch_bounds__(kBlock) unpack_film_kernel(int film_w, int film_h, int tiles_x, int total_tiles, int world,
+                                                            int tiles_per_rank, const float4* __restrict__ slabs,
+                                                            float4* __restrict__ film) {
+  const unsigned long long t = blockIdx.x * (unsigned long long)kBlock + threadIdx.x;
+  const int tile = int(t >> 6);
+  if (tile >= total_tiles) return;
+  const int p = int(t & 63);
+  const int px = (tile % tiles_x) * kTile + (p & 7), py = (tile / tiles_x) * kTile + (p >> 3);
+  if (px >= film_w || py >= film_h) return;
+  const int rank = tile % world, ltile = tile / world;
+  film[size_t(py) * film_w + px] = slabs[(size_t(rank) * tiles_per_rank + ltile) * 64u + p];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1092,7 +1121,12 @@ struct pine_gpu_plan {
   int grid = 0;
   size_t lds_bytes = 0;
   bool serial_rng = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // per-launch HIP events (prepass start / path kernel start / resolve start / end) for the last
+  // kEvRing launches: reading them (stats_get) averages over the launches since the previous read,
+  // so a timed loop never has to synchronise inside
+  static constexpr int kEvRing = 64;
+  hipEvent_t ev[kEvRing][4] = {};
+  unsigned long long launch_count = 0, stats_read_upto = 0;
   bool timed = false;
   bool launched = false;
   hipStream_t last_stream = nullptr;
@@ -1124,8 +1158,9 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_samples);
   (void)hipFree(p->d_fold);
   (void)hipFree(p->d_counters);
-  for (auto& e : p->ev)
-    if (e) (void)hipEventDestroy(e);
+  for (auto& slot : p->ev)
+    for (auto& e : slot)
+      if (e) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -1314,7 +1349,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   p->serial_rng = in_path_rng;
   int kspi = prm->samples_per_item;
   if (in_path_rng) kspi = spp;
-  else if (kspi <= 0) kspi = std::min(spp, 4);
+  else if (kspi <= 0) kspi = p->queue_variant >= 0 ? 1 : std::min(spp, 4);  // (queue kernel: one sample per item balances small shards best)
   if (kspi > spp) kspi = spp;
   {  // spp is a power of two; k must be a power of two dividing it
     int k2 = 1;
@@ -1363,7 +1398,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
   p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
   if (p->timed)
-    for (auto& e : p->ev) HIP_OK(hipEventCreate(&e));
+    for (auto& slot : p->ev)
+      for (auto& e : slot) HIP_OK(hipEventCreate(&e));
   return 0;
 }
 
@@ -1382,7 +1418,7 @@ pine_gpu_plan* pine_gpu_plan_create(pine_gpu_scene* scene, const pine_gpu_render
   return p;
 }
 
-int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_) {
+static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool packed) {
   if (!p || !film_dev) {
     set_error("null argument");
     return -1;
@@ -1391,31 +1427,70 @@ int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_) {
   HIP_OK(hipSetDevice(p->device));
   g_progress.store(0.0f);
   const size_t film_bytes = size_t(p->film_w) * p->film_h * sizeof(float4);
-  if (p->W.shard_world > 1) HIP_OK(hipMemsetAsync(film_dev, 0, film_bytes, stream));
+  if (p->W.shard_world > 1 && !packed) HIP_OK(hipMemsetAsync(film_dev, 0, film_bytes, stream));
   HIP_OK(hipMemsetAsync(p->d_counters, 0, sizeof(Counters), stream));
-  if (p->timed) HIP_OK(hipEventRecord(p->ev[0], stream));
+  hipEvent_t* ev = p->ev[p->launch_count % pine_gpu_plan::kEvRing];
+  if (p->timed) HIP_OK(hipEventRecord(ev[0], stream));
   if (p->W.items_per_pixel > 1) {
     const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
     hipLaunchKernelGGL(rng_checkpoint_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                        p->W, p->film_w, p->film_h, p->S.spp, p->d_ckpt);
   }
-  if (p->timed) HIP_OK(hipEventRecord(p->ev[1], stream));
+  if (p->timed) HIP_OK(hipEventRecord(ev[1], stream));
   if (p->queue_variant >= 0)
     hipLaunchKernelGGL(kQueueVariants[p->queue_variant].fn, dim3(p->grid), dim3(kQBlock), p->lds_bytes, stream, p->S,
                        p->W, (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_ctxg, p->d_counters);
   else
     hipLaunchKernelGGL(kVariants[p->variant].fn, dim3(p->grid), dim3(kBlock), p->lds_bytes, stream, p->S, p->W,
                        (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_counters);
-  if (p->timed) HIP_OK(hipEventRecord(p->ev[2], stream));
+  if (p->timed) HIP_OK(hipEventRecord(ev[2], stream));
   {
     const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
     hipLaunchKernelGGL(resolve_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, p->W,
-                       p->film_w, p->film_h, p->S.spp, p->d_samples, (float4*)film_dev, p->d_counters);
+                       p->film_w, p->film_h, p->S.spp, p->d_samples, (float4*)film_dev, p->d_counters, packed ? 1 : 0);
   }
-  if (p->timed) HIP_OK(hipEventRecord(p->ev[3], stream));
+  if (p->timed) HIP_OK(hipEventRecord(ev[3], stream));
   HIP_OK(hipGetLastError());
   p->launched = true;
+  p->launch_count++;
   p->last_stream = stream;
+  return 0;
+}
+
+int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream) { return plan_launch(p, film_dev, stream, false); }
+int pine_gpu_plan_launch_packed(pine_gpu_plan* p, void* slab_dev, void* stream) { return plan_launch(p, slab_dev, stream, true); }
+
+int64_t pine_gpu_packed_slab_floats(int film_w, int film_h, int world) {
+  if (film_w <= 0 || film_h <= 0 || world < 1) return -1;
+  const int64_t tiles = int64_t((film_w + kTile - 1) / kTile) * ((film_h + kTile - 1) / kTile);
+  return (tiles + world - 1) / world * 64 * 4;
+}
+
+int pine_gpu_packed_offset(int film_w, int film_h, int world, int x, int y, int* rank_out, int64_t* float4_index_out) {
+  if (film_w <= 0 || film_h <= 0 || world < 1 || x < 0 || y < 0 || x >= film_w || y >= film_h) {
+    set_error("bad argument");
+    return -1;
+  }
+  const int tiles_x = (film_w + kTile - 1) / kTile;
+  const int tile = (y / kTile) * tiles_x + x / kTile;
+  if (rank_out) *rank_out = tile % world;
+  if (float4_index_out) *float4_index_out = int64_t(tile / world) * 64 + (y % kTile) * kTile + x % kTile;
+  return 0;
+}
+
+int pine_gpu_film_unpack(int film_w, int film_h, int world, int device, const void* slabs_dev, void* film_dev, void* stream_) {
+  if (!slabs_dev || !film_dev || film_w <= 0 || film_h <= 0 || world < 1) {
+    set_error("bad argument");
+    return -1;
+  }
+  HIP_OK(hipSetDevice(device));
+  const int tiles_x = (film_w + kTile - 1) / kTile, tiles_y = (film_h + kTile - 1) / kTile;
+  const int total = tiles_x * tiles_y;
+  const int per_rank = (total + world - 1) / world;
+  const unsigned long long n = (unsigned long long)total * 64ull;
+  hipLaunchKernelGGL(unpack_film_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream_,
+                     film_w, film_h, tiles_x, total, world, per_rank, (const float4*)slabs_dev, (float4*)film_dev);
+  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -1450,9 +1525,25 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
     out->vertices = c.vertices;
     out->shadow_rays = c.shadow_rays;
     if (p->timed) {
-      HIP_OK(hipEventElapsedTime(&out->prepass_ms, p->ev[0], p->ev[1]));
-      HIP_OK(hipEventElapsedTime(&out->trace_ms, p->ev[1], p->ev[2]));
-      HIP_OK(hipEventElapsedTime(&out->resolve_ms, p->ev[2], p->ev[3]));
+      // mean over the launches since the previous read (at most the last kEvRing of them)
+      unsigned long long first = p->stats_read_upto;
+      if (p->launch_count - first > (unsigned long long)pine_gpu_plan::kEvRing) first = p->launch_count - pine_gpu_plan::kEvRing;
+      if (first == p->launch_count) first = p->launch_count - 1;  // nothing new: report the last launch again
+      double a = 0, b = 0, c3 = 0;
+      for (unsigned long long i = first; i < p->launch_count; i++) {
+        hipEvent_t* ev = p->ev[i % pine_gpu_plan::kEvRing];
+        float x = 0, y = 0, z = 0;
+        HIP_OK(hipEventElapsedTime(&x, ev[0], ev[1]));
+        HIP_OK(hipEventElapsedTime(&y, ev[1], ev[2]));
+        HIP_OK(hipEventElapsedTime(&z, ev[2], ev[3]));
+        a += x, b += y, c3 += z;
+      }
+      const double n = double(p->launch_count - first);
+      out->prepass_ms = float(a / n);
+      out->trace_ms = float(b / n);
+      out->resolve_ms = float(c3 / n);
+      out->timed_launches = int32_t(p->launch_count - first);
+      p->stats_read_upto = p->launch_count;
     }
   }
   return 0;

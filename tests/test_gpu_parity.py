@@ -191,6 +191,30 @@ def test_scheduling_invariance():
     assert_bit_equal(again, base, "run-to-run determinism")
 
 
+def test_packed_slabs_unpack_to_the_same_film():
+    """The multi-GPU form bench.py uses: per-rank tile-major slabs, concatenated as a gather would, then
+    scattered on the device -- must equal the one-rank film bit for bit (ragged film: border tiles)."""
+    import torch
+    import pine_amd as pa
+    from pine_amd import scenes
+    sc = scenes.cbox((77, 45), "readme")
+    base, _ = _render(sc, 16, 5)
+    for world in (1, 2, 5):
+        slabs = []
+        for r in range(world):
+            plan = pa.Plan(sc, 16, 5, shard_rank=r, shard_world=world)
+            slab = torch.full((plan.slab_floats(),), -7.0, dtype=torch.float32, device="cuda")
+            plan.launch_packed(slab.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            slabs.append(slab)
+            plan.close()
+        allslabs = torch.stack(slabs)
+        film = torch.full((45, 77, 4), -1.0, dtype=torch.float32, device="cuda")
+        pa.film_unpack((77, 45), world, allslabs.data_ptr(), film.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_equal(film.cpu().numpy(), base, f"packed, {world} ranks")
+
+
 def test_edge_cases():
     import pine_amd as pa
     # empty scene: every ray misses -> black film with w = 1 (path.cpp:38,75-81)
