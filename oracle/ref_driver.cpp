@@ -12,6 +12,9 @@
 //   pine_ref rng     <out.bin>           hash()/RNG known answers (fixture 1)
 //   pine_ref host    <out.bin>           host-side math known answers (matrices, look_at, ctors)
 //   pine_ref shapes  <scene.pscene> <rays.bin> <out.bin>   per-shape hit/intersect records
+//   pine_ref prl     <literal>...        psl::stof / stoi / to_string of each literal, and the constant
+//                                        expressions of a cbox-class script evaluated with psl::stof values
+//                                        (pins the PRL front-end's literal and vector arithmetic)
 #include <pine/core/lightsampler.h>
 #include <pine/core/sampler.h>
 #include <pine/core/scene.h>
@@ -250,6 +253,59 @@ int main(int argc, char** argv) {
                  normalize(vec3(-3, 2, 0.5f))};
     for (auto n : ns) push3(coordinate_system(n));
     write_file(argv[2], out.data(), out.size() * 4);
+    return 0;
+  }
+  if (cmd == "prl") {
+    auto hex = [](float x) {
+      char b[64];
+      snprintf(b, sizeof b, "%a", double(x));
+      return std::string(b);
+    };
+    for (int i = 2; i < argc; i++) {
+      psl::string lit = argv[i];
+      const bool is_float = psl::contains(lit, '.');
+      if (is_float) {
+        const float v = psl::stof(lit);
+        printf("literal %s f32 %s str %s\n", argv[i], hex(v).c_str(), psl::to_string(v).c_str());
+      } else {
+        printf("literal %s i32 %d str %s\n", argv[i], psl::stoi(lit), psl::to_string(psl::stoi(lit)).c_str());
+      }
+    }
+    auto F = [](const char* t) { return psl::stof(psl::string(t)); };
+    auto p3 = [&](const char* name, vec3 v) { printf("expr %s vec3 %s %s %s\n", name, hex(v.x).c_str(), hex(v.y).c_str(), hex(v.z).c_str()); };
+    auto p16 = [&](const char* name, mat4 m) {
+      printf("expr %s mat4", name);
+      for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) printf(" %s", hex(m[c][r]).c_str());
+      printf("\n");
+    };
+    p3("600*[1.0,0.64,0.185]", 600 * vec3(F("1.0"), F("0.64"), F("0.185")));
+    p3("[1.0,0.64,0.185]*600", vec3(F("1.0"), F("0.64"), F("0.185")) * 600);
+    p3("[0.9,0.1,0.05]/3", vec3(F("0.9"), F("0.1"), F("0.05")) / 3);
+    p3("2.5/[0.9,0.1,0.05]", F("2.5") / vec3(F("0.9"), F("0.1"), F("0.05")));
+    p3("[0.2,0.5,0.9]*[0.9,0.1,0.05]", vec3(F("0.2"), F("0.5"), F("0.9")) * vec3(F("0.9"), F("0.1"), F("0.05")));
+    p3("[0.2,0.5,0.9]+[1,2,3]", vec3(F("0.2"), F("0.5"), F("0.9")) + vec3(vec3i(1, 2, 3)));
+    {
+      vec3i a = vec3i(1, 1, 1) * 160;
+      printf("expr [1,1,1]*160 vec3i %d %d %d\n", a.x, a.y, a.z);
+      vec2i b = vec2i(256, 256) * 4;
+      printf("expr [256,256]*4 vec2i %d %d\n", b.x, b.y);
+      vec2i c = 7 / vec2i(2, 3);
+      printf("expr 7/[2,3] vec2i %d %d\n", c.x, c.y);
+    }
+    p16("translate([0.0,0.0,0.6])*rotate_y(0.4)*scale([0.6,0.6,0.6])",
+        translate(vec3(F("0.0"), F("0.0"), F("0.6"))) * rotate_y(F("0.4")) * scale(vec3(F("0.6"), F("0.6"), F("0.6"))));
+    p16("translate([-0.6,0.0,1.0])*rotate_y(-0.4)*scale([0.6,1.3,0.6])",
+        translate(vec3(-F("0.6"), F("0.0"), F("1.0"))) * rotate_y(-F("0.4")) * scale(vec3(F("0.6"), F("1.3"), F("0.6"))));
+    p16("rotate_x(0.3)*rotate_z(1.1)*translate(1.5,0.25,3.0)", rotate_x(F("0.3")) * rotate_z(F("1.1")) * translate(F("1.5"), F("0.25"), F("3.0")));
+    p16("look_at([0,4,-8],[0,1,0])", look_at(vec3(0, 4, -8), vec3(0, 1, 0)));
+    printf("expr 2^10 i32 %d\n", psl::powi(2, 10));
+    printf("expr 0.5^2.5 f32 %s\n", hex(psl::pow(F("0.5"), F("2.5"))).c_str());
+    printf("expr 7+0.25 f32 %s\n", hex(7 + F("0.25")).c_str());
+    printf("expr 0.1+0.2-0.3 f32 %s\n", hex(F("0.1") + (F("0.2") - F("0.3"))).c_str());   // `-` binds before `+` (jit.cpp:1772-1792)
+    printf("expr 0.3-0.2+0.1 f32 %s\n", hex((F("0.3") - F("0.2")) + F("0.1")).c_str());
+    printf("expr 0.7*0.3/0.9 f32 %s\n", hex(F("0.7") * (F("0.3") / F("0.9"))).c_str());   // `/` binds before `*`
+    printf("expr 0.7/0.3*0.9 f32 %s\n", hex((F("0.7") / F("0.3")) * F("0.9")).c_str());
     return 0;
   }
   if (cmd == "shapes" && argc == 5) {

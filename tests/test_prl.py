@@ -1,0 +1,184 @@
+"""PRL front-end (pine_amd/host/prl.cpp, include/pine_prl.h).
+
+CPU part: literal and constant-expression semantics against the REAL reference's psl::stof / stoi /
+to_string and vecmath (tests/golden/prl_semantics.txt, written by `oracle/_ref/pine_ref prl`), the
+grammar's documented quirks (jit.cpp:1772-1820), overload resolution, control flow, error behaviour,
+and that a script builds exactly the scene the API builds from the same values.
+GPU part: a script rendered through the front-end equals the oracle's render of the scene it built."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, assert_bit_equal
+
+
+def _golden():
+    lits, exprs = {}, {}
+    for line in open(os.path.join(GOLDEN, "prl_semantics.txt")):
+        t = line.split()
+        if t[0] == "literal":
+            lits[t[1]] = (t[2], t[3], t[5])
+        elif t[0] == "expr":
+            exprs[t[1]] = " ".join(t[2:])
+    return lits, exprs
+
+
+def test_abi_exports_every_declared_symbol():
+    from pine_amd import prl
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pine_prl.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(pine_prl_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(prl.SIGNATURES) and len(names) == 5
+    for n in names:
+        assert hasattr(prl.lib, n)
+
+
+def test_literals_match_the_reference_psl_conversions():
+    from pine_amd import prl
+    lits, _ = _golden()
+    assert len(lits) >= 30
+    for text, (typ, value, as_str) in lits.items():
+        assert prl.evaluate(text) == f"{typ} {value}", text
+        assert prl.evaluate(f'"" + {text}') == f"str {as_str}", text  # @convert.<T>.str == psl::to_string
+    # the point of restating psl::stof: it is NOT strtof
+    assert prl.evaluate("0.64") == "f32 0x1.47ae16p-1" and float.fromhex("0x1.47ae16p-1") != np.float32(0.64)
+
+
+def test_constant_expressions_match_the_reference_vecmath():
+    from pine_amd import prl
+    _, exprs = _golden()
+    assert len(exprs) >= 18
+    for text, expect in exprs.items():
+        assert prl.evaluate(text) == expect, text
+
+
+def test_precedence_table_quirks():
+    """jit.cpp:1772-1792: codes with a leading 0 are octal, `* / % ^` are decimal; the highest code
+    reduces first, first occurrence on ties: `-` before `+`, `/` before `*`, `%`/`^` before `/`."""
+    from pine_amd import prl
+    ev = prl.evaluate
+    assert ev("10 - 4 + 3") == "i32 9"      # (10 - 4) + 3
+    assert ev("10 + 4 - 3") == "i32 11"     # 10 + (4 - 3)
+    assert ev("7 / 2 * 2") == "i32 6"       # (7 / 2) * 2
+    assert ev("2 * 7 / 2") == "i32 6"       # 2 * (7 / 2): `/` outranks `*`
+    assert ev("2 * 3 ^ 2") == "i32 18" and ev("2 ^ 3 * 2") == "i32 16"
+    assert ev("8 - 2 - 1") == "i32 5"       # equal codes: leftmost first
+    assert ev("1 + 2 * 3") == "i32 7" and ev("(1 + 2) * 3") == "i32 9"
+    assert ev("1 + 2 < 4 && 2 > 1") == "bool true"
+    assert ev("7 % 4 + 1") == "i32 4"
+    assert ev("-2 * 3") == "i32 -6" and ev("2 * -3") == "i32 -6"
+    assert ev("-0.6") == "f32 -0x1.333334p-1"
+
+
+def test_typing_and_overload_resolution():
+    from pine_amd import prl
+    ev = prl.evaluate
+    assert ev("[1, 2, 3]") == "vec3i 1 2 3" and ev("[1, 2.0, 3]").startswith("vec3 ")   # jit.cpp:1014-1023
+    assert ev("1 + 2.5") == "f32 0x1.cp+1" and ev("7 / 2") == "i32 3" and ev("7 / 2.0") == "f32 0x1.cp+1"
+    assert ev("1 < 2.5") == "bool true"          # <(f32, f32) after ONE i32 -> f32 conversion
+    assert ev("[1, 2] + [3, 4.0]") == "vec2 0x1p+2 0x1.8p+2"
+    assert ev("i32(2.9)") == "i32 2" and ev("f32(3)") == "f32 0x1.8p+1"
+    assert ev("[256, 256] * 4") == "vec2i 1024 1024" and ev("vec3(2.0)") == "vec3 0x1p+1 0x1p+1 0x1p+1"
+    assert ev("X") == "vec3 0x1p+0 0x0p+0 0x0p+0" and ev("Pi") == "f32 0x1.921fb6p+1"
+    assert ev("[1.5, 2.5, 3.5].y") == "f32 0x1.4p+1" and ev("[4, 5, 6].z") == "i32 6"
+    assert ev("true + 1") == "str true1"         # +(str, str) with two conversions is the only candidate (context.cpp:143-189)
+    for bad, msg in [("1.5 % 2.0", "is not found"), ("Diffuse(0.5)", "is not found"), ("nope(1)", "is not found"),
+                     ("[1]", "Only 2, 3, or 4 items"), ("true * 2", "is not found"), ("undefined_name", "is not found"),
+                     ("1 +", "primary expression"), ("12345678901234567890", "too large")]:
+        with pytest.raises(prl.PrlError, match=msg):
+            ev(bad)
+
+
+def test_statements_and_control_flow():
+    from pine_amd import prl
+    out = prl.interpret('''
+        # declarations, assignment-if-exists, compound assignment
+        a := 1; b = 2; b = b + a; a += 4; a *= 2;
+        println(a); println(b);
+        x := 0.5; x += 1; println(x);
+        # ranges: a..b is half-open with ++, a ~ s ~ b is inclusive with += s   (jit.cpp:1519-1546)
+        s := 0; for i in 0..5 { s += i; } println(s);
+        t := 0.0; for v in 0.0 ~ 0.25 ~ 1.0 { t += v; } println(t);
+        n := 0; for k := 10; k > 0; k -= 3 { n++; } println(n);   # C-style: no parentheses (jit.cpp:1548-1556)
+        w := 0; while w < 100 { w += 7; if w > 20 { break; } } println(w);
+        c := 0; for i in 0..6 { if i % 2 == 0 { continue; } c += i; } println(c);
+        if a > 100 { println("big"); } else if a == 10 { println("ten"); } else { println("other"); }
+        { shadow := 1; shadow += 1; }
+        v := [1, 2, 3] * 2; println(v); println([0.5, 0.25]);
+        println(true && false || true); println("a" + "b" + 3);
+    ''', dry_run=True)
+    assert out.split("\n") == ["10", "3", "1.5000", "10", "2.5000", "4", "21", "9", "ten", "[2 4 6]", "[0.5000 0.2500]",
+                               "true", "ab3", ""]
+    for src, msg in [("x := 1; y := x +;", "primary expression"), ("break;", "loop"), ("a := 1 a := 2;", "Expect `;`"),
+                     ("fn f(): i32 { }", "not supported"), ("s := Scene(); s.render(3);", "is not found"),
+                     ("for i in 0..3 { undefined_thing; }", "is not found"), ("PathIntegrator(BlueSampler(4), 0);", "max_path_length"),
+                     ("BlueSampler(0);", "positive samples"), ("s := Scene(); s.add(Rect([0,0,0],[1,0,0],[0,0,1]), \"m\");", "Can't find material")]:
+        with pytest.raises(prl.PrlError, match=msg):
+            prl.interpret(src, dry_run=True)
+
+
+def _cornell(size, spp, depth):
+    src = open(os.path.join(ROOT, "examples", "cornell.pine")).read()
+    src = src.replace("size := [640, 640];", f"size := [{size[0]}, {size[1]}];").replace("spp := 16;", f"spp := {spp};")
+    return src.replace("depth := 4;", f"depth := {depth};")
+
+
+def test_script_builds_the_scene_the_api_builds_from_the_same_values():
+    """examples/cornell.pine through the front-end (dry run) == the Python API fed with the reference's
+    psl::stof values and reference-evaluated constant expressions (independent construction path)."""
+    import pine_amd as pa
+    from pine_amd import prl
+    lits, exprs = _golden()
+    F = lambda t: float.fromhex(lits[t][1])  # noqa: E731
+    V = lambda key: [float.fromhex(x) for x in exprs[key].split()[1:]]  # noqa: E731
+    out = prl.interpret(_cornell((640, 640), 16, 4), dry_run=True)
+    ps, spp, depth = prl.scene_of_dry_run(out)
+    assert (spp, depth) == (16, 4) and out.rstrip().endswith("@save cornell.png 640x640")
+
+    s = pa.Scene()
+    s.add("white", pa.Diffuse([F("0.9")] * 3))
+    s.add("blue", pa.Diffuse([F("0.2"), F("0.5"), F("0.9")]))
+    s.add("red", pa.Diffuse([F("0.9"), F("0.1"), F("0.05")]))
+    s.add("green", pa.Diffuse([F("0.2"), F("0.9"), F("0.05")]))
+    s.add(pa.Rect([0, 0, 1], [2, 0, 0], [0, 0, 2], True), "white")
+    s.add(pa.Rect([0, 2, 1], [2, 0, 0], [0, 0, 2]), "white")
+    s.add(pa.Rect([-1, 1, 1], [0, 0, 2], [0, 2, 0], True), "red")
+    s.add(pa.Rect([1, 1, 1], [0, 0, 2], [0, 2, 0]), "green")
+    s.add(pa.Rect([0, 1, 2], [2, 0, 0], [0, 2, 0], True), "blue")
+    unit = pa.AABB([0, 0, 0], [1, 1, 1])
+    m0 = pa.mat4(V("translate([0.0,0.0,0.6])*rotate_y(0.4)*scale([0.6,0.6,0.6])"))
+    m1 = pa.mat4(V("translate([-0.6,0.0,1.0])*rotate_y(-0.4)*scale([0.6,1.3,0.6])"))
+    s.add(pa.Box(unit, m0), "white")
+    s.add(pa.Box(unit, m1), "white")
+    s.add(pa.Rect([0.0, F("1.9"), 1], [F("0.1"), 0, 0], [0, 0, F("0.1")]), pa.Emissive(V("600*[1.0,0.64,0.185]")))
+    s.set(pa.ThinLenCamera(pa.Film([640, 640], pa.Uncharted2()), [0, 0, 0], [0, 0, 1], F("0.4")))
+    assert ps == s.describe()
+
+
+def test_save_extension_rule_and_png_writer(tmp_path):
+    """fileio.cpp:55-76: the extension is what follows the FIRST dot; unknown -> warning + '.png'."""
+    from pine_amd import prl
+    out = prl.interpret('f := Film([4, 2]); f.save("out.v2.png");', dry_run=True)
+    assert "Unknown format `v2.png`" in out and "@save out.v2.png.png 4x2" in out
+    # real save of an unrendered (black) film: host-only path, no GPU involved
+    target = tmp_path / "black.png"
+    prl.interpret(f'f := Film([5, 3]); f.save("{target}");')
+    data = target.read_bytes() if target.exists() else (tmp_path / "black.png.png").read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    import zlib
+    idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]
+    raw = zlib.decompress(idat)
+    assert len(raw) == 3 * (5 * 4 + 1) and set(raw[1:21:4]) == {0} and raw[4] == 255  # black, opaque
+
+
+@pytest.mark.gpu
+def test_script_render_equals_oracle_of_the_scene_it_built(oracle):
+    from pine_amd import prl
+    src = _cornell((72, 56), 16, 5).replace('world.camera.film().save("cornell.png");', "")
+    ps, spp, depth = prl.scene_of_dry_run(prl.interpret(src, dry_run=True))
+    prl.interpret(src)
+    film = prl.last_film()
+    assert film is not None and film.shape == (56, 72, 4)
+    ref, _ = oracle.render(ps, (72, 56), spp, depth)
+    assert_bit_equal(film, ref, "front-end render vs oracle of the same scene description")

@@ -69,6 +69,13 @@ def main():
         run_ref("host", fp)
         np.save(os.path.join(OUT, "host_math.npy"), np.fromfile(fp, dtype=np.float32))
 
+        # 1b. PRL literal / constant-expression semantics from the reference's own psl::stof / stoi /
+        #     to_string and vecmath (pins pine_amd/host/prl.cpp; the JIT itself needs LLVM-18)
+        literals = ["0.64", "0.9", "0.185", "1.0", "0.05", "0.1", "0.2", "0.5", "600", "256", "1.3", "0.4", "1.", ".5",
+                    "3.14159", "123456.789", "0.001", "100", "2147483647", "0.333333333", "16777217.0", "0.6", "1.9",
+                    "0.25", "2.5", "0.3", "0.7", "7", "0", "0.0", "12.375", "99.99999", "0.98", "0.55", "0.02", "160"]
+        open(os.path.join(OUT, "prl_semantics.txt"), "w").write(run_ref("prl", *literals))
+
         # 2. per-shape records on a fixed ray set (grazing / inside / behind / tmax-clipped included)
         zoo = scenes.shapes_zoo((48, 48))
         rng = np.random.default_rng(12345)
