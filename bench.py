@@ -83,12 +83,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the PathIntegrator hot path has no CPU fallback")
+    # Rehearsal knobs (not used by the driver): PINE_BENCH_BACKEND=gloo runs the N > 1 code path with the
+    # collectives staged through host memory, PINE_BENCH_DEVICE pins every rank to one GPU -- together
+    # they let a one-GPU box execute the multi-rank logic end to end (tools/rehearse_ranks.sh).
+    backend = os.environ.get("PINE_BENCH_BACKEND", "nccl")
+    if os.environ.get("PINE_BENCH_DEVICE"):
+        local_rank = int(os.environ["PINE_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     use_dist = world > 1 or os.environ.get("PINE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL calls at N=1
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"  # where collective buffers live
 
     scene = scenes.cbox((W, H), "committed")
     plan = pine_amd.Plan(scene, SPP, DEPTH, device=local_rank, shard_rank=rank, shard_world=world,
@@ -103,18 +113,26 @@ def main():
     if collective == "gather":
         slab = torch.empty(plan.slab_floats(), dtype=torch.float32, device="cuda")
         slabs = torch.empty((world, plan.slab_floats()), dtype=torch.float32, device="cuda") if rank == 0 else None
-        slab_list = list(slabs.unbind(0)) if rank == 0 else None
+        slabs_c = slabs if cdev == "cuda" else (torch.empty(slabs.shape, dtype=torch.float32) if rank == 0 else None)
+        slab_list = list(slabs_c.unbind(0)) if rank == 0 else None
 
     def step():
         if collective == "gather":
             plan.launch_packed(slab.data_ptr(), stream)
-            dist.gather(slab, slab_list, dst=0)
+            dist.gather(slab if cdev == "cuda" else slab.cpu(), slab_list, dst=0)
             if rank == 0:
+                if cdev != "cuda":
+                    slabs.copy_(slabs_c)
                 pine_amd.film_unpack((W, H), world, slabs.data_ptr(), film.data_ptr(), local_rank, stream)
         else:
             plan.launch(film.data_ptr(), stream)
             if collective == "reduce":
-                dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+                if cdev == "cuda":
+                    dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+                else:
+                    host = film.cpu()
+                    dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                    film.copy_(host)
 
     def barrier():
         if use_dist:
@@ -131,7 +149,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -142,7 +160,7 @@ def main():
     local_samples = st.camera_samples
     verts = st.vertices
     if use_dist:
-        t = torch.tensor([local_samples, verts], dtype=torch.float64, device="cuda")
+        t = torch.tensor([local_samples, verts], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         total_samples, total_verts = float(t[0]), float(t[1])
     else:
@@ -182,6 +200,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel": kernel, "kernel_ms": k_ms,
                          "bytes_per_vertex": B_VERTEX, "note": "algorithmic bytes of the streaming formulation (SURVEY.md 8(d)); the kernel keeps path state in LDS and the fold stack in L2/Infinity Cache, so it is latency/VALU bound, not HBM bound"},
+            "film_md5": __import__("hashlib").md5(film.cpu().numpy().tobytes()).hexdigest(),
             "kernels_ms": {"prepass": st.prepass_ms, "path_trace": k_ms, "resolve": st.resolve_ms, "launches_averaged": st.timed_launches},
         }
         if world == 1 and not args.no_cpu:
