@@ -67,6 +67,34 @@ int pine_gpu_scene_add_material_subsurface(pine_gpu_scene*, const char* name, co
 int pine_gpu_scene_find_material(pine_gpu_scene*, const char* name);
                                          /* Scene::find_material src/pine/core/scene.cpp:49-54 */
 
+/* Shading nodes (Nodef / Node3f: src/pine/core/node.h:13-297, registered node.cpp:29-116).  A node
+ * lives in the scene's node table; each call returns its id (or < 0).  Supported: constants, the
+ * surface inputs Position / Normal / UV, NodeBinary (+ - * / ^), NodeUnary (- abs sqr sqrt fract),
+ * NodeComponent, NodeToVec3, NodeCheckerboard; `lerp` etc. are compositions of these exactly as
+ * node.cpp:88-102 composes them.  Not supported: noise, image and function nodes.  Subtrees that do
+ * not read the surface are folded to literals on the host with the same float operations; the rest
+ * run as small postfix programs in the shading stage of the kernels. */
+int pine_gpu_scene_node_constf(pine_gpu_scene*, float value);                 /* Nodef(float)   node.h:262 */
+int pine_gpu_scene_node_const3(pine_gpu_scene*, const float value[3]);        /* Node3f(vec3)   node.h:281 */
+int pine_gpu_scene_node_input(pine_gpu_scene*, int which);                    /* 0 Position, 1 Normal, 2 UV  node.h:113-127 */
+int pine_gpu_scene_node_binary(pine_gpu_scene*, int op, int a, int b);        /* op: one of + - * / ^ (as a char); both Nodef or both Node3f  node.h:129-152 */
+int pine_gpu_scene_node_unary(pine_gpu_scene*, int op, int a);                /* '-' neg, 'a' abs, 's' sqr, 'r' sqrt, 'f' fract  node.h:154-178 */
+int pine_gpu_scene_node_component(pine_gpu_scene*, int a, int component);     /* NodeComponent(Node3f, 0..2) node.h:180-193 */
+int pine_gpu_scene_node_to_vec3(pine_gpu_scene*, int x, int y, int z);        /* NodeToVec3(x) when y = z = -1  node.h:195-210 */
+int pine_gpu_scene_node_checkerboard(pine_gpu_scene*, int p, float ratio);    /* NodeCheckerboard node.h:232-239, node.cpp:15-18 */
+int pine_gpu_scene_node_splat(pine_gpu_scene*, int a);                        /* a Nodef where a Node3f is expected  node.h:78,291-293 */
+int pine_gpu_scene_node_is_vec3(pine_gpu_scene*, int id);                     /* 1 Node3f, 0 Nodef */
+/* Materials whose parameters are nodes (albedo: Node3f; the others: Nodef). */
+int pine_gpu_scene_add_material_diffuse_n(pine_gpu_scene*, const char* name, int albedo);
+int pine_gpu_scene_add_material_uber_n(pine_gpu_scene*, const char* name, int albedo, int roughness, int metallic,
+                                       int transmission, float ior);
+int pine_gpu_scene_add_material_metal(pine_gpu_scene*, const char* name, int albedo, int roughness);
+                                         /* Metal(Node3f, Nodef)         src/pine/core/material.h:39-50 */
+int pine_gpu_scene_add_material_glossy(pine_gpu_scene*, const char* name, int albedo, int roughness, int ior);
+                                         /* Glossy(Node3f, Nodef, Nodef) src/pine/core/material.h:52-64 */
+int pine_gpu_scene_add_material_glass(pine_gpu_scene*, const char* name, int albedo, int roughness, int ior);
+                                         /* Glass(Node3f, Nodef, Nodef)  src/pine/core/material.h:66-78 */
+
 /* scene.add(Shape, material): Scene::add_geometry src/pine/core/scene.cpp:14-22 (emissive geometry
  * becomes an AreaLight automatically).  Returns the geometry index.  Shape constructors:
  * src/pine/core/geometry.cpp:901-946. */

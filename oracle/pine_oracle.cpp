@@ -1346,12 +1346,98 @@ float BXDF::pdf(vec3 wo) const {
   return 0.0f;
 }
 
-enum MatKind { M_EMISSIVE, M_DIFFUSE, M_UBER, M_SUBSURFACE };
+// Shading nodes (node.h:13-297): a node table in creation order; a material parameter is either a
+// literal or a node id.  Evaluation recurses over the tree exactly as Mnode<T>::operator() does.
+struct NodeEvalCtx {
+  vec3 p, n;
+  vec2 uv;
+};
+struct ShadingNode {
+  enum Kind { ConstF, Const3, Position, Normal, UV, BinF, Bin3, UnF, Un3, Comp, ToVec3, Checker, Splat } kind = ConstF;
+  char op = 0;
+  int a = -1, b = -1, c = -1, n = 0;
+  float f = 0;  // ConstF value / Checkerboard ratio
+  vec3 v;
+};
+struct NodeTable {
+  std::vector<ShadingNode> nodes;
+  static float un(char op, float x) {  // NodeUnary::eval node.h:158-175
+    switch (op) {
+      case '-': return -x;
+      case 'a': return std::abs(x);
+      case 's': return x * x;
+      case 'r': return std::sqrt(x);
+      default: return x - std::floor(x);  // 'f': psl::fract math.h:152-154
+    }
+  }
+  static float bin(char op, float x, float y) {  // NodeBinary::eval node.h:134-150
+    switch (op) {
+      case '+': return x + y;
+      case '-': return x - y;
+      case '*': return x * y;
+      case '/': return x / y;
+      default: return std::pow(x, y);  // psl::pow == std::pow (math.h:201-202)
+    }
+  }
+  float evalf(int id, const NodeEvalCtx& c) const {
+    const ShadingNode& k = nodes[size_t(id)];
+    switch (k.kind) {
+      case ShadingNode::ConstF: return k.f;
+      case ShadingNode::BinF: return bin(k.op, evalf(k.a, c), evalf(k.b, c));
+      case ShadingNode::UnF: return un(k.op, evalf(k.a, c));
+      case ShadingNode::Comp: return eval3(k.a, c)[k.n];
+      case ShadingNode::Checker: {  // node.cpp:15-18
+        const vec3 q = eval3(k.a, c);
+        const vec3 x = vec3(un('f', q.x), un('f', q.y), un('f', q.z)) - vec3(k.f, k.f, k.f);
+        return float(x.x * x.y * x.z > 0);
+      }
+      default: return 0.0f;
+    }
+  }
+  vec3 eval3(int id, const NodeEvalCtx& c) const {
+    const ShadingNode& k = nodes[size_t(id)];
+    switch (k.kind) {
+      case ShadingNode::Const3: return k.v;
+      case ShadingNode::Position: return c.p;
+      case ShadingNode::Normal: return c.n;
+      case ShadingNode::UV: return vec3(c.uv.x, c.uv.y, 0.0f);  // explicit Vector3(Vector2) vecmath.h:167
+      case ShadingNode::Bin3: {
+        const vec3 x = eval3(k.a, c), y = eval3(k.b, c);
+        return vec3(bin(k.op, x.x, y.x), bin(k.op, x.y, y.y), bin(k.op, x.z, y.z));
+      }
+      case ShadingNode::Un3: {
+        const vec3 x = eval3(k.a, c);
+        return vec3(un(k.op, x.x), un(k.op, x.y), un(k.op, x.z));
+      }
+      case ShadingNode::ToVec3: {  // node.h:197-208
+        const float x = evalf(k.a, c);
+        if (k.b < 0) return vec3(x, x, x);
+        return vec3(x, evalf(k.b, c), evalf(k.c, c));
+      }
+      case ShadingNode::Splat: {  // a Nodef held by a Node3f: vec3{x.eval(nc)} (node.h:291-293)
+        const float x = evalf(k.a, c);
+        return vec3(x, x, x);
+      }
+      default: return vec3(0.0f, 0.0f, 0.0f);
+    }
+  }
+};
+
+enum MatKind { M_EMISSIVE, M_DIFFUSE, M_UBER, M_SUBSURFACE, M_METAL, M_GLOSSY, M_GLASS };
 struct Material {
   MatKind kind = M_DIFFUSE;
   vec3 color;  // albedo / emission
   float roughness = 0, metallic = 0, transmission = 0, ior = 1.45f;
   vec3 sigma_s;
+  // node ids (>= 0) overriding the literals above: albedo (Node3f), roughness / metallic /
+  // transmission / ior (Nodef)
+  int n_albedo = -1, n_rough = -1, n_metal = -1, n_trans = -1, n_ior = -1;
+  const NodeTable* table = nullptr;
+  vec3 albedo_at(const NodeEvalCtx& c) const { return n_albedo >= 0 ? table->eval3(n_albedo, c) : color; }
+  float roughness_at(const NodeEvalCtx& c) const { return n_rough >= 0 ? table->evalf(n_rough, c) : roughness; }
+  float metallic_at(const NodeEvalCtx& c) const { return n_metal >= 0 ? table->evalf(n_metal, c) : metallic; }
+  float transmission_at(const NodeEvalCtx& c) const { return n_trans >= 0 ? table->evalf(n_trans, c) : transmission; }
+  float ior_at(const NodeEvalCtx& c) const { return n_ior >= 0 ? table->evalf(n_ior, c) : ior; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1657,6 +1743,7 @@ struct BVHImpl {
 };
 
 struct Scene {
+  NodeTable node_table;
   std::vector<Material> materials;
   std::vector<std::string> material_names;
   std::vector<Geometry> geometries;
@@ -1878,25 +1965,43 @@ struct Integrator {
     float min_roughness = diffused ? 0.6f : 0.0f;
     vec3 bc_p = it.p, bc_n = it.n;
     BXDF bxdf;
+    const NodeEvalCtx nc{it.p, it.n, it.uv};  // BxdfSampleCtx -> NodeEvalCtx(it) (bxdf.h:10-21, node.h:13-20)
     switch (mat.kind) {  // material.h:30-131, material.cpp:9-28
       case M_DIFFUSE:
         bxdf.kind = BX_DIFFUSE;
-        bxdf.albedo = mat.color;
+        bxdf.albedo = mat.albedo_at(nc);
+        break;
+      case M_METAL:  // material.h:39-50
+        bxdf.kind = BX_CONDUCTOR;
+        bxdf.albedo = mat.albedo_at(nc);
+        bxdf.roughness = fmax_(mat.roughness_at(nc), min_roughness);
+        break;
+      case M_GLOSSY:  // material.h:52-64
+        bxdf.kind = BX_DIFF_DIEL;
+        bxdf.albedo = mat.albedo_at(nc);
+        bxdf.roughness = fmax_(mat.roughness_at(nc), min_roughness);
+        bxdf.ior = mat.ior_at(nc);
+        break;
+      case M_GLASS:  // material.h:66-78
+        bxdf.kind = BX_REFR_DIEL;
+        bxdf.albedo = mat.albedo_at(nc);
+        bxdf.roughness = fmax_(mat.roughness_at(nc), min_roughness);
+        bxdf.ior = mat.ior_at(nc);
         break;
       case M_UBER:
-        if (with_probability(mat.metallic, sampler)) {
+        if (with_probability(mat.metallic_at(nc), sampler)) {
           bxdf.kind = BX_CONDUCTOR;
-          bxdf.albedo = mat.color;
-          bxdf.roughness = mat.roughness;
-        } else if (with_probability(mat.transmission, sampler)) {
+          bxdf.albedo = mat.albedo_at(nc);
+          bxdf.roughness = mat.roughness_at(nc);
+        } else if (with_probability(mat.transmission_at(nc), sampler)) {
           bxdf.kind = BX_REFR_DIEL;
-          bxdf.albedo = mat.color;
-          bxdf.roughness = mat.roughness;
+          bxdf.albedo = mat.albedo_at(nc);
+          bxdf.roughness = mat.roughness_at(nc);
           bxdf.ior = mat.ior;
         } else {
           bxdf.kind = BX_DIFF_DIEL;
-          bxdf.albedo = mat.color;
-          bxdf.roughness = mat.roughness;
+          bxdf.albedo = mat.albedo_at(nc);
+          bxdf.roughness = mat.roughness_at(nc);
           bxdf.ior = mat.ior;
         }
         break;
@@ -1980,11 +2085,57 @@ bool parse_pscene(const char* text, Scene& scene) {
     std::istringstream in(line);
     std::string kw;
     in >> kw;
-    if (kw == "material") {
+    if (kw == "node") {  // node <id> <kind> args (ids are consecutive from 0)
+      int id = -1;
+      std::string kind;
+      in >> id >> kind;
+      if (id != int(scene.node_table.nodes.size())) {
+        g_error = "node ids must be consecutive";
+        return false;
+      }
+      ShadingNode k;
+      auto opc = [&]() {
+        std::string o;
+        in >> o;
+        return o.empty() ? '?' : o[0];
+      };
+      if (kind == "constf") { k.kind = ShadingNode::ConstF; k.f = rdf(in); }
+      else if (kind == "const3") { k.kind = ShadingNode::Const3; k.v = rd3(in); }
+      else if (kind == "position") k.kind = ShadingNode::Position;
+      else if (kind == "normal") k.kind = ShadingNode::Normal;
+      else if (kind == "uv") k.kind = ShadingNode::UV;
+      else if (kind == "binf") { k.kind = ShadingNode::BinF; k.op = opc(); in >> k.a >> k.b; }
+      else if (kind == "bin3") { k.kind = ShadingNode::Bin3; k.op = opc(); in >> k.a >> k.b; }
+      else if (kind == "unf") { k.kind = ShadingNode::UnF; k.op = opc(); in >> k.a; }
+      else if (kind == "un3") { k.kind = ShadingNode::Un3; k.op = opc(); in >> k.a; }
+      else if (kind == "comp") { k.kind = ShadingNode::Comp; in >> k.a >> k.n; }
+      else if (kind == "tovec3") { k.kind = ShadingNode::ToVec3; in >> k.a; if (!(in >> k.b >> k.c)) k.b = k.c = -1; }
+      else if (kind == "checker") { k.kind = ShadingNode::Checker; in >> k.a; k.f = rdf(in); }
+      else if (kind == "splat") { k.kind = ShadingNode::Splat; in >> k.a; }
+      else {
+        g_error = "unknown node kind " + kind;
+        return false;
+      }
+      scene.node_table.nodes.push_back(k);
+    } else if (kw == "material") {
       std::string name, kind;
       in >> name >> kind;
       Material m;
-      if (kind == "emissive") {
+      m.table = &scene.node_table;
+      if (kind == "diffuse_n") {
+        m.kind = M_DIFFUSE;
+        in >> m.n_albedo;
+      } else if (kind == "uber_n") {
+        m.kind = M_UBER;
+        in >> m.n_albedo >> m.n_rough >> m.n_metal >> m.n_trans;
+        m.ior = rdf(in);
+      } else if (kind == "metal") {
+        m.kind = M_METAL;
+        in >> m.n_albedo >> m.n_rough;
+      } else if (kind == "glossy" || kind == "glass") {
+        m.kind = kind == "glossy" ? M_GLOSSY : M_GLASS;
+        in >> m.n_albedo >> m.n_rough >> m.n_ior;
+      } else if (kind == "emissive") {
         m.kind = M_EMISSIVE;
         m.color = rd3(in);
       } else if (kind == "diffuse") {

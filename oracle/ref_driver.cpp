@@ -56,16 +56,102 @@ static void load_pscene(const char* path, Loaded& out) {
     exit(2);
   }
   auto& scene = out.scene;
+  // shading-node table of the description: each entry is a Nodef or a Node3f of the reference
+  std::vector<psl::optional<Nodef>> nf;
+  std::vector<psl::optional<Node3f>> n3;
+  auto F = [&](int id) -> Nodef { return *nf[size_t(id)]; };
+  auto V = [&](int id) -> Node3f { return *n3[size_t(id)]; };
   std::string line;
   while (std::getline(f, line)) {
     if (line.empty() || line[0] == '#') continue;
     std::istringstream in(line);
     std::string kw;
     in >> kw;
-    if (kw == "material") {
+    if (kw == "node") {
+      int id, a = -1, b = -1, c = -1;
+      std::string kind, op;
+      in >> id >> kind;
+      nf.emplace_back();
+      n3.emplace_back();
+      if (kind == "constf") nf[id] = Nodef(rdf(in));
+      else if (kind == "const3") n3[id] = Node3f(rd3(in));
+      else if (kind == "position") n3[id] = Node3f(NodePosition());
+      else if (kind == "normal") n3[id] = Node3f(NodeNormal());
+      else if (kind == "uv") n3[id] = Node3f(NodeUV());
+      else if (kind == "binf") {
+        in >> op >> a >> b;
+        switch (op[0]) {
+          case '+': nf[id] = Nodef(NodeBinary<float, '+'>(F(a), F(b))); break;
+          case '-': nf[id] = Nodef(NodeBinary<float, '-'>(F(a), F(b))); break;
+          case '*': nf[id] = Nodef(NodeBinary<float, '*'>(F(a), F(b))); break;
+          case '/': nf[id] = Nodef(NodeBinary<float, '/'>(F(a), F(b))); break;
+          default: nf[id] = Nodef(NodeBinary<float, '^'>(F(a), F(b))); break;
+        }
+      } else if (kind == "bin3") {
+        in >> op >> a >> b;
+        switch (op[0]) {
+          case '+': n3[id] = Node3f(NodeBinary<vec3, '+'>(V(a), V(b))); break;
+          case '-': n3[id] = Node3f(NodeBinary<vec3, '-'>(V(a), V(b))); break;
+          case '*': n3[id] = Node3f(NodeBinary<vec3, '*'>(V(a), V(b))); break;
+          case '/': n3[id] = Node3f(NodeBinary<vec3, '/'>(V(a), V(b))); break;
+          default: n3[id] = Node3f(NodeBinary<vec3, '^'>(V(a), V(b))); break;
+        }
+      } else if (kind == "unf") {
+        in >> op >> a;
+        switch (op[0]) {
+          case '-': nf[id] = Nodef(NodeUnary<float, '-'>(F(a))); break;
+          case 'a': nf[id] = Nodef(NodeUnary<float, 'a'>(F(a))); break;
+          case 's': nf[id] = Nodef(NodeUnary<float, 's'>(F(a))); break;
+          case 'r': nf[id] = Nodef(NodeUnary<float, 'r'>(F(a))); break;
+          default: nf[id] = Nodef(NodeUnary<float, 'f'>(F(a))); break;
+        }
+      } else if (kind == "un3") {
+        in >> op >> a;
+        switch (op[0]) {
+          case '-': n3[id] = Node3f(NodeUnary<vec3, '-'>(V(a))); break;
+          case 'a': n3[id] = Node3f(NodeUnary<vec3, 'a'>(V(a))); break;
+          case 's': n3[id] = Node3f(NodeUnary<vec3, 's'>(V(a))); break;
+          case 'r': n3[id] = Node3f(NodeUnary<vec3, 'r'>(V(a))); break;
+          default: n3[id] = Node3f(NodeUnary<vec3, 'f'>(V(a))); break;
+        }
+      } else if (kind == "comp") {
+        int n;
+        in >> a >> n;
+        nf[id] = Nodef(NodeComponent(V(a), n));
+      } else if (kind == "tovec3") {
+        in >> a;
+        if (in >> b >> c) n3[id] = Node3f(NodeToVec3(F(a), F(b), F(c)));
+        else n3[id] = Node3f(NodeToVec3(F(a)));
+      } else if (kind == "checker") {
+        in >> a;
+        nf[id] = Nodef(NodeCheckerboard(V(a), rdf(in)));
+      } else if (kind == "splat") {
+        in >> a;
+        n3[id] = Node3f(F(a));  // Mnode<vec3> holding an Mnode<float> (node.h:78)
+      } else {
+        fprintf(stderr, "unknown node kind %s\n", kind.c_str());
+        exit(2);
+      }
+    } else if (kw == "material") {
       std::string name, kind;
       in >> name >> kind;
-      if (kind == "emissive") {
+      int a, r, m, t, i;
+      if (kind == "diffuse_n") {
+        in >> a;
+        scene.add_material(name.c_str(), Material(DiffuseMaterial(V(a))));
+      } else if (kind == "uber_n") {
+        in >> a >> r >> m >> t;
+        scene.add_material(name.c_str(), Material(UberMaterial(V(a), F(r), F(m), F(t), rdf(in))));
+      } else if (kind == "metal") {
+        in >> a >> r;
+        scene.add_material(name.c_str(), Material(MetalMaterial(V(a), F(r))));
+      } else if (kind == "glossy") {
+        in >> a >> r >> i;
+        scene.add_material(name.c_str(), Material(GlossyMaterial(V(a), F(r), F(i))));
+      } else if (kind == "glass") {
+        in >> a >> r >> i;
+        scene.add_material(name.c_str(), Material(GlassMaterial(V(a), F(r), F(i))));
+      } else if (kind == "emissive") {
         scene.add_material(name.c_str(), Material(EmissiveMaterial(rd3(in))));
       } else if (kind == "diffuse") {
         scene.add_material(name.c_str(), Material(DiffuseMaterial(rd3(in))));

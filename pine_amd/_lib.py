@@ -75,6 +75,21 @@ SIGNATURES = {
     "pine_gpu_scene_add_material_uber": (C.c_int, [C.c_void_p, C.c_char_p, f3, C.c_float, C.c_float, C.c_float, C.c_float]),
     "pine_gpu_scene_add_material_subsurface": (C.c_int, [C.c_void_p, C.c_char_p, f3, C.c_float, f3]),
     "pine_gpu_scene_find_material": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "pine_gpu_scene_node_constf": (C.c_int, [C.c_void_p, C.c_float]),
+    "pine_gpu_scene_node_const3": (C.c_int, [C.c_void_p, f3]),
+    "pine_gpu_scene_node_input": (C.c_int, [C.c_void_p, C.c_int]),
+    "pine_gpu_scene_node_binary": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "pine_gpu_scene_node_unary": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pine_gpu_scene_node_component": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pine_gpu_scene_node_to_vec3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "pine_gpu_scene_node_checkerboard": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "pine_gpu_scene_node_splat": (C.c_int, [C.c_void_p, C.c_int]),
+    "pine_gpu_scene_node_is_vec3": (C.c_int, [C.c_void_p, C.c_int]),
+    "pine_gpu_scene_add_material_diffuse_n": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "pine_gpu_scene_add_material_uber_n": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "pine_gpu_scene_add_material_metal": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "pine_gpu_scene_add_material_glossy": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "pine_gpu_scene_add_material_glass": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "pine_gpu_scene_add_rect": (C.c_int, [C.c_void_p, f3, f3, f3, C.c_int, C.c_int]),
     "pine_gpu_scene_add_aabb": (C.c_int, [C.c_void_p, f3, f3, C.c_int]),
     "pine_gpu_scene_add_obb": (C.c_int, [C.c_void_p, f3, f3, f16, C.c_int]),

@@ -92,6 +92,105 @@ def look_at(frm, to):
 
 
 # ---- materials (src/pine/core/material.cpp:46-62) ---------------------------------------------
+# ---- shading nodes (src/pine/core/node.h:13-297, node.cpp:29-116) --------------------------------
+class Node:
+    """A Nodef (is_vec3 False) or Node3f (True) expression; built lazily, instantiated in a scene's node
+    table when a material using it is added.  Operators compose nodes the way node.cpp:70-102 does."""
+    is_vec3 = False
+
+    def __init__(self, kind, *args, is_vec3=False):
+        self.kind, self.args, self.is_vec3 = kind, args, is_vec3
+
+    @staticmethod
+    def of(x, want_vec3=None):
+        if isinstance(x, Node):
+            n = x
+        elif isinstance(x, (int, float, np.floating)):
+            n = Node("constf", float(np.float32(x)))
+        else:
+            n = Node("const3", [float(np.float32(v)) for v in x], is_vec3=True)
+        if want_vec3 is True and not n.is_vec3:
+            n = Node("splat", n, is_vec3=True)     # Node3f(Nodef): vec3{x.eval} (node.h:78,291-293)
+        if want_vec3 is False and n.is_vec3:
+            raise PineError("a Nodef is required here")
+        return n
+
+    def _bin(self, op, other, swap=False):
+        o = Node.of(other)
+        a, b = (o, self) if swap else (self, o)
+        v = a.is_vec3 or b.is_vec3
+        return Node("bin", op, Node.of(a, v), Node.of(b, v), is_vec3=v)
+
+    def __add__(self, o): return self._bin("+", o)
+    def __radd__(self, o): return self._bin("+", o, True)
+    def __sub__(self, o): return self._bin("-", o)
+    def __rsub__(self, o): return self._bin("-", o, True)
+    def __mul__(self, o): return self._bin("*", o)
+    def __rmul__(self, o): return self._bin("*", o, True)
+    def __truediv__(self, o): return self._bin("/", o)
+    def __rtruediv__(self, o): return self._bin("/", o, True)
+    def __pow__(self, o): return self._bin("^", o)
+    def __neg__(self): return Node("un", "-", self, is_vec3=self.is_vec3)
+    def __getitem__(self, n): return Node("comp", self, int(n))
+
+    def _instantiate(self, scene, memo):
+        if id(self) in memo:
+            return memo[id(self)][1]
+        h, k, a = scene._h, self.kind, self.args
+        sub = lambda x: x._instantiate(scene, memo)  # noqa: E731
+        if k == "constf":
+            r = lib.pine_gpu_scene_node_constf(h, float(a[0]))
+        elif k == "const3":
+            r = lib.pine_gpu_scene_node_const3(h, _v3(a[0]))
+        elif k in ("position", "normal", "uv"):
+            r = lib.pine_gpu_scene_node_input(h, {"position": 0, "normal": 1, "uv": 2}[k])
+        elif k == "bin":
+            r = lib.pine_gpu_scene_node_binary(h, ord(a[0]), sub(a[1]), sub(a[2]))
+        elif k == "un":
+            r = lib.pine_gpu_scene_node_unary(h, ord(a[0]), sub(a[1]))
+        elif k == "comp":
+            r = lib.pine_gpu_scene_node_component(h, sub(a[0]), a[1])
+        elif k == "tovec3":
+            ids = [sub(x) for x in a]
+            r = lib.pine_gpu_scene_node_to_vec3(h, ids[0], ids[1] if len(ids) == 3 else -1, ids[2] if len(ids) == 3 else -1)
+        elif k == "checker":
+            r = lib.pine_gpu_scene_node_checkerboard(h, sub(a[0]), float(a[1]))
+        elif k == "splat":
+            r = lib.pine_gpu_scene_node_splat(h, sub(a[0]))
+        else:
+            raise PineError("unknown node kind " + k)
+        memo[id(self)] = (self, check(r, "node"))  # (keeps the node alive: ids of dead temporaries get reused)
+        return memo[id(self)][1]
+
+
+def Position(): return Node("position", is_vec3=True)
+def Normal(): return Node("normal", is_vec3=True)
+def UV(): return Node("uv", is_vec3=True)
+def Checkerboard(p, ratio=0.5): return Node("checker", Node.of(p, True), float(np.float32(ratio)))
+def Vec3(x, y=None, z=None):
+    if y is None:
+        return Node("tovec3", Node.of(x, False), is_vec3=True)
+    return Node("tovec3", Node.of(x, False), Node.of(y, False), Node.of(z, False), is_vec3=True)
+def node_abs(x): return Node("un", "a", Node.of(x), is_vec3=Node.of(x).is_vec3)
+def node_sqr(x): return Node("un", "s", Node.of(x), is_vec3=Node.of(x).is_vec3)
+def node_sqrt(x): return Node("un", "r", Node.of(x), is_vec3=Node.of(x).is_vec3)
+def node_fract(x): return Node("un", "f", Node.of(x), is_vec3=Node.of(x).is_vec3)
+
+
+def lerp(t, a, b):
+    """lerp over nodes exactly as node.cpp:88-102 composes it (plain numbers lerp numerically)."""
+    if not any(isinstance(x, Node) for x in (t, a, b)):
+        raise PineError("lerp: at least one argument must be a node (use numpy for plain numbers)")
+    t, a, b = Node.of(t), Node.of(a), Node.of(b)
+    one = Node("constf", 1.0)
+    if not t.is_vec3 and not a.is_vec3 and not b.is_vec3:      # (Nodef, Nodef, Nodef)
+        return (t * b) + ((one - t) * a)
+    if not t.is_vec3:                                           # (Nodef, Node3f, Node3f)
+        return (Vec3(t) * Node.of(b, True)) + (Vec3(one - t) * Node.of(a, True))
+    one3 = Node("const3", [1.0, 1.0, 1.0], is_vec3=True)        # (Node3f, Node3f, Node3f)
+    return (t * Node.of(b, True)) + ((one3 - t) * Node.of(a, True))
+
+
 class Material:
     pass
 
@@ -114,6 +213,21 @@ class Uber(Material):
 class Subsurface(Material):
     def __init__(self, albedo, roughness, sigma_s):
         self.albedo, self.roughness, self.sigma_s = albedo, roughness, sigma_s
+
+
+class Metal(Material):       # material.h:39-50
+    def __init__(self, albedo, roughness):
+        self.albedo, self.roughness = albedo, roughness
+
+
+class Glossy(Material):      # material.h:52-64
+    def __init__(self, albedo, roughness, ior=1.4):
+        self.albedo, self.roughness, self.ior = albedo, roughness, ior
+
+
+class Glass(Material):       # material.h:66-78
+    def __init__(self, albedo, roughness, ior=1.4):
+        self.albedo, self.roughness, self.ior = albedo, roughness, ior
 
 
 # ---- shapes (src/pine/core/geometry.cpp:901-946) ------------------------------------------------
@@ -275,6 +389,21 @@ class Scene:
         n = name.encode()
         if isinstance(m, Emissive):
             return check(lib.pine_gpu_scene_add_material_emissive(self._h, n, _v3(m.color)), "Emissive")
+        memo = {}
+        nid = lambda x, v: Node.of(x, v)._instantiate(self, memo)  # noqa: E731
+        if isinstance(m, Diffuse) and isinstance(m.albedo, Node):
+            return check(lib.pine_gpu_scene_add_material_diffuse_n(self._h, n, nid(m.albedo, True)), "Diffuse")
+        if isinstance(m, Uber) and any(isinstance(x, Node) for x in (m.albedo, m.roughness, m.metallic, m.transmission)):
+            return check(lib.pine_gpu_scene_add_material_uber_n(self._h, n, nid(m.albedo, True), nid(m.roughness, False),
+                                                                nid(m.metallic, False), nid(m.transmission, False), float(m.ior)), "Uber")
+        if isinstance(m, Metal):
+            return check(lib.pine_gpu_scene_add_material_metal(self._h, n, nid(m.albedo, True), nid(m.roughness, False)), "Metal")
+        if isinstance(m, Glossy):
+            return check(lib.pine_gpu_scene_add_material_glossy(self._h, n, nid(m.albedo, True), nid(m.roughness, False),
+                                                                nid(m.ior, False)), "Glossy")
+        if isinstance(m, Glass):
+            return check(lib.pine_gpu_scene_add_material_glass(self._h, n, nid(m.albedo, True), nid(m.roughness, False),
+                                                               nid(m.ior, False)), "Glass")
         if isinstance(m, Diffuse):
             return check(lib.pine_gpu_scene_add_material_diffuse(self._h, n, _v3(m.albedo)), "Diffuse")
         if isinstance(m, Uber):

@@ -24,7 +24,8 @@ enum : unsigned {
   F_UBER = 1u << 6,
   F_SSS = 1u << 7,
   F_LDS_SCENE = 1u << 8,  // scene records staged in LDS
-  F_ALL = 0xffu,
+  F_NODES = 1u << 9,      // material parameters may be shading-node programs (node.h)
+  F_ALL = 0xffu | F_NODES,
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -768,6 +769,88 @@ PINE_HD bool bxdf_is_delta(const DBxdf& b) {
     default: return b.roughness < 1e-2f;
   }
 }
+// ------------------------------------------------------------------------------------------------
+// Shading nodes: postfix programs over vec3 (pine_types.h DNodeOp; node.h:13-297, node.cpp:15-18).
+// A float node travels as a splat; every operation is componentwise, so the float result is each
+// component of the vec3 result.
+// ------------------------------------------------------------------------------------------------
+PINE_HD f3 node_program_eval(const DNodeOp* ops, int start, f3 p, f3 n, f2 uv) {
+  f3 st[kNodeStack];
+  int sp = 0;
+  for (int pc = start;; pc++) {
+    const DNodeOp o = ops[pc];
+    if (o.op == N_END) break;
+    switch (o.op) {
+      case N_CONST: st[sp++] = f3{o.x, o.y, o.z}; break;
+      case N_POS: st[sp++] = p; break;
+      case N_NORMAL: st[sp++] = n; break;
+      case N_UV: st[sp++] = f3{uv.x, uv.y, 0.0f}; break;  // explicit Vector3(Vector2) vecmath.h:167
+      case N_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+      case N_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+      case N_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+      case N_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+      case N_POW: {
+        sp--;
+        const f3 a = st[sp - 1], b = st[sp];
+        st[sp - 1] = f3{powf(a.x, b.x), powf(a.y, b.y), powf(a.z, b.z)};
+        break;
+      }
+      case N_NEG: st[sp - 1] = -st[sp - 1]; break;
+      case N_ABS: st[sp - 1] = vabs(st[sp - 1]); break;
+      case N_SQR: st[sp - 1] = st[sp - 1] * st[sp - 1]; break;
+      case N_SQRT: {
+        const f3 a = st[sp - 1];
+        st[sp - 1] = f3{psqrt(a.x), psqrt(a.y), psqrt(a.z)};
+        break;
+      }
+      case N_FRACT: {
+        const f3 a = st[sp - 1];
+        st[sp - 1] = f3{a.x - floorf(a.x), a.y - floorf(a.y), a.z - floorf(a.z)};
+        break;
+      }
+      case N_COMP: {
+        const float v = get(st[sp - 1], int(o.x));
+        st[sp - 1] = f3{v, v, v};
+        break;
+      }
+      case N_TOVEC3: sp -= 2; st[sp - 1] = f3{st[sp - 1].x, st[sp].x, st[sp + 1].x}; break;
+      case N_CHECKER: {
+        const f3 a = st[sp - 1];
+        const f3 x{(a.x - floorf(a.x)) - o.x, (a.y - floorf(a.y)) - o.x, (a.z - floorf(a.z)) - o.x};
+        const float v = float(x.x * x.y * x.z > 0);
+        st[sp - 1] = f3{v, v, v};
+        break;
+      }
+      default: break;
+    }
+  }
+  return st[0];
+}
+// A material's parameters at a surface point: the literals of the record, or (F_NODES variants) the
+// values of its node programs there -- BxdfSampleCtx -> NodeEvalCtx(it) (bxdf.h:10-21, node.h:13-20).
+struct MatParams {
+  f3 albedo, albedo_over_pi;
+  float roughness, metallic, transmission, ior;
+};
+template <unsigned F = F_ALL>
+PINE_HD MatParams material_params(const DMaterial* m, const DNodeOp* ops, f3 p, f3 n, f2 uv) {
+  MatParams r{ld3(m->color), ld3(m->color_over_pi), m->roughness, m->metallic, m->transmission, m->ior};
+  if constexpr (F & F_NODES) {
+    if (m->prog[0] >= 0) {
+      r.albedo = node_program_eval(ops, m->prog[0], p, n, uv);
+      r.albedo_over_pi = r.albedo / kPi;  // the Lambertian f (bxdf.cpp:21,27)
+    }
+    if (m->prog[1] >= 0) r.roughness = node_program_eval(ops, m->prog[1], p, n, uv).x;
+    if (m->prog[2] >= 0) r.metallic = node_program_eval(ops, m->prog[2], p, n, uv).x;
+    if (m->prog[3] >= 0) {
+      const float v = node_program_eval(ops, m->prog[3], p, n, uv).x;
+      if (m->kind == MAT_GLOSSY || m->kind == MAT_GLASS) r.ior = v;
+      else r.transmission = v;
+    }
+  }
+  return r;
+}
+
 struct DBsdfSample {
   f3 wo, f;
   float pdf;

@@ -140,10 +140,207 @@ int SceneHost::find_material(const char* name) const {
     if (material_names[i] == name) return i;
   return -1;
 }
+// ---- shading nodes (node.h:13-297) ----------------------------------------------------------------
+int SceneHost::add_node(const HostNode& n) {
+  auto ok = [&](int id, bool want_vec3) {
+    if (id < 0 || id >= int(nodes.size())) {
+      set_error("node: operand id out of range");
+      return false;
+    }
+    if (nodes[size_t(id)].is_vec3() != want_vec3) {
+      set_error(want_vec3 ? "node: a Node3f operand is required" : "node: a Nodef operand is required");
+      return false;
+    }
+    return true;
+  };
+  switch (n.kind) {
+    case HostNode::BinF:
+      if (!ok(n.a, false) || !ok(n.b, false)) return -1;
+      break;
+    case HostNode::Bin3:
+      if (!ok(n.a, true) || !ok(n.b, true)) return -1;
+      break;
+    case HostNode::UnF:
+    case HostNode::Splat:
+      if (!ok(n.a, false)) return -1;
+      break;
+    case HostNode::Un3:
+    case HostNode::Checker:
+      if (!ok(n.a, true)) return -1;
+      break;
+    case HostNode::Comp:
+      if (!ok(n.a, true)) return -1;
+      if (n.n < 0 || n.n > 2) {  // node.h:181-182
+        set_error("NodeComponent's second parameter should be 0, 1, or 2");
+        return -1;
+      }
+      break;
+    case HostNode::ToVec3:
+      if (!ok(n.a, false)) return -1;
+      if (n.b >= 0 || n.c >= 0)
+        if (!ok(n.b, false) || !ok(n.c, false)) return -1;
+      break;
+    default: break;
+  }
+  if ((n.kind == HostNode::BinF || n.kind == HostNode::Bin3) && !strchr("+-*/^", n.op)) {
+    set_error("node: unknown binary operator");
+    return -1;
+  }
+  if ((n.kind == HostNode::UnF || n.kind == HostNode::Un3) && !strchr("-asrf", n.op)) {
+    set_error("node: unknown unary operator");
+    return -1;
+  }
+  nodes.push_back(n);
+  return int(nodes.size()) - 1;
+}
+bool SceneHost::node_reads_surface(int id) const {
+  const HostNode& k = nodes[size_t(id)];
+  if (k.kind == HostNode::Position || k.kind == HostNode::Normal || k.kind == HostNode::UV) return true;
+  for (int c : {k.a, k.b, k.c})
+    if (c >= 0 && node_reads_surface(c)) return true;
+  return false;
+}
+static float node_un(char op, float x) {  // NodeUnary::eval node.h:158-175
+  switch (op) {
+    case '-': return -x;
+    case 'a': return fabsf(x);
+    case 's': return x * x;
+    case 'r': return sqrtf(x);
+    default: return x - floorf(x);  // psl::fract math.h:152-154
+  }
+}
+static float node_bin(char op, float x, float y) {  // NodeBinary::eval node.h:134-150
+  switch (op) {
+    case '+': return x + y;
+    case '-': return x - y;
+    case '*': return x * y;
+    case '/': return x / y;
+    default: return powf(x, y);
+  }
+}
+f3 SceneHost::node_fold(int id) const {  // floats come back as splats
+  const HostNode& k = nodes[size_t(id)];
+  switch (k.kind) {
+    case HostNode::ConstF: return f3{k.f, k.f, k.f};
+    case HostNode::Const3: return k.v;
+    case HostNode::BinF:
+    case HostNode::Bin3: {
+      const f3 x = node_fold(k.a), y = node_fold(k.b);
+      return f3{node_bin(k.op, x.x, y.x), node_bin(k.op, x.y, y.y), node_bin(k.op, x.z, y.z)};
+    }
+    case HostNode::UnF:
+    case HostNode::Un3: {
+      const f3 x = node_fold(k.a);
+      return f3{node_un(k.op, x.x), node_un(k.op, x.y), node_un(k.op, x.z)};
+    }
+    case HostNode::Comp: {
+      const float v = get(node_fold(k.a), k.n);
+      return f3{v, v, v};
+    }
+    case HostNode::ToVec3:
+      if (k.b < 0) return node_fold(k.a);
+      return f3{node_fold(k.a).x, node_fold(k.b).x, node_fold(k.c).x};
+    case HostNode::Checker: {
+      const f3 q = node_fold(k.a);
+      const f3 x{node_un('f', q.x) - k.f, node_un('f', q.y) - k.f, node_un('f', q.z) - k.f};
+      const float v = float(x.x * x.y * x.z > 0);
+      return f3{v, v, v};
+    }
+    case HostNode::Splat: return node_fold(k.a);
+    default: return f3{0, 0, 0};
+  }
+}
+// postfix flattening of one node tree; returns the maximum stack depth, or -1
+static int emit_program(const SceneHost& S, int id, std::vector<DNodeOp>& ops, int depth) {
+  const HostNode& k = S.nodes[size_t(id)];
+  auto push = [&](int op, float x = 0, float y = 0, float z = 0) { ops.push_back(DNodeOp{op, x, y, z}); };
+  if (!S.node_reads_surface(id)) {  // constant subtree: one literal
+    const f3 v = S.node_fold(id);
+    push(N_CONST, v.x, v.y, v.z);
+    return depth + 1;
+  }
+  auto binop = [](char c) { return c == '+' ? N_ADD : c == '-' ? N_SUB : c == '*' ? N_MUL : c == '/' ? N_DIV : N_POW; };
+  auto unop = [](char c) { return c == '-' ? N_NEG : c == 'a' ? N_ABS : c == 's' ? N_SQR : c == 'r' ? N_SQRT : N_FRACT; };
+  int m = depth + 1;
+  switch (k.kind) {
+    case HostNode::Position: push(N_POS); break;
+    case HostNode::Normal: push(N_NORMAL); break;
+    case HostNode::UV: push(N_UV); break;
+    case HostNode::BinF:
+    case HostNode::Bin3: {
+      const int m1 = emit_program(S, k.a, ops, depth), m2 = emit_program(S, k.b, ops, depth + 1);
+      if (m1 < 0 || m2 < 0) return -1;
+      push(binop(k.op));
+      m = std::max(m1, m2);
+      break;
+    }
+    case HostNode::UnF:
+    case HostNode::Un3:
+      m = emit_program(S, k.a, ops, depth);
+      push(unop(k.op));
+      break;
+    case HostNode::Comp:
+      m = emit_program(S, k.a, ops, depth);
+      push(N_COMP, float(k.n));
+      break;
+    case HostNode::ToVec3:
+      if (k.b < 0) {
+        m = emit_program(S, k.a, ops, depth);  // splat already
+      } else {
+        const int m1 = emit_program(S, k.a, ops, depth), m2 = emit_program(S, k.b, ops, depth + 1),
+                  m3 = emit_program(S, k.c, ops, depth + 2);
+        if (m1 < 0 || m2 < 0 || m3 < 0) return -1;
+        push(N_TOVEC3);
+        m = std::max(m1, std::max(m2, m3));
+      }
+      break;
+    case HostNode::Checker:
+      m = emit_program(S, k.a, ops, depth);
+      push(N_CHECKER, k.f);
+      break;
+    case HostNode::Splat: m = emit_program(S, k.a, ops, depth); break;
+    default: return -1;
+  }
+  return m;
+}
+bool SceneHost::compile_node_programs(std::vector<DMaterial>& out, std::vector<DNodeOp>& ops) const {
+  out = materials;
+  ops.clear();
+  for (size_t i = 0; i < out.size(); i++) {
+    DMaterial& m = out[i];
+    for (int k = 0; k < 4; k++) {
+      m.prog[k] = -1;
+      const int id = material_nodes[i].id[k];
+      if (id < 0) continue;
+      if (!node_reads_surface(id)) {  // fold to a literal (exactly the arithmetic the node tree would do)
+        const f3 v = node_fold(id);
+        if (k == 0) {
+          m.color[0] = v.x, m.color[1] = v.y, m.color[2] = v.z;
+          for (int c = 0; c < 3; c++) m.color_over_pi[c] = m.color[c] / kPi;
+        } else if (k == 1) m.roughness = v.x;
+        else if (k == 2) m.metallic = v.x;
+        else if (m.kind == MAT_GLOSSY || m.kind == MAT_GLASS) m.ior = v.x;
+        else m.transmission = v.x;
+        continue;
+      }
+      m.prog[k] = int(ops.size());
+      const int depth = emit_program(*this, id, ops, 0);
+      ops.push_back(DNodeOp{N_END, 0, 0, 0});
+      if (depth < 0 || depth > kNodeStack) {
+        set_error("shading-node tree too deep for the device evaluator");
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
 int SceneHost::add_material(const char* name, const DMaterial& m_, const std::string& desc) {
   DMaterial m = m_;
   for (int i = 0; i < 3; i++) m.color_over_pi[i] = m.color[i] / kPi;
+  for (int& p : m.prog) p = -1;
   materials.push_back(m);
+  material_nodes.emplace_back();
   material_names.push_back(name ? name : "");
   material_describe.push_back(desc);
   accel.built = false;
@@ -391,6 +588,26 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
 std::string SceneHost::describe() const {
   std::string s = "# pine scene description v1 (hexfloat); written by libpine_gpu\n";
   // materials and geometry interleaved in creation order is not needed: materials first
+  for (size_t i = 0; i < nodes.size(); i++) {
+    const HostNode& k = nodes[i];
+    std::string l = fmt("node %d ", int(i));
+    switch (k.kind) {
+      case HostNode::ConstF: l += fmt("constf %a", k.f); break;
+      case HostNode::Const3: l += "const3 " + hex3(k.v); break;
+      case HostNode::Position: l += "position"; break;
+      case HostNode::Normal: l += "normal"; break;
+      case HostNode::UV: l += "uv"; break;
+      case HostNode::BinF: l += fmt("binf %c %d %d", k.op, k.a, k.b); break;
+      case HostNode::Bin3: l += fmt("bin3 %c %d %d", k.op, k.a, k.b); break;
+      case HostNode::UnF: l += fmt("unf %c %d", k.op, k.a); break;
+      case HostNode::Un3: l += fmt("un3 %c %d", k.op, k.a); break;
+      case HostNode::Comp: l += fmt("comp %d %d", k.a, k.n); break;
+      case HostNode::ToVec3: l += k.b < 0 ? fmt("tovec3 %d", k.a) : fmt("tovec3 %d %d %d", k.a, k.b, k.c); break;
+      case HostNode::Checker: l += fmt("checker %d %a", k.a, k.f); break;
+      case HostNode::Splat: l += fmt("splat %d", k.a); break;
+    }
+    s += l + "\n";
+  }
   for (auto& d : material_describe) s += d + "\n";
   for (auto& g : geometries) s += g.describe + "\n";
   if (has_camera) s += camera_describe + "\n";
@@ -488,6 +705,145 @@ int pine_gpu_scene_add_material_subsurface(pine_gpu_scene* s, const char* name, 
   return s->host.add_material(
       n.c_str(), m, "material " + n + " subsurface " + hex3(c) + fmt(" %a ", roughness) + hex3(sigma_s));
 }
+// ---- shading nodes + node-parameterised materials ----
+static int add_node(pine_gpu_scene* s, HostNode n) {
+  if (!check(s)) return -1;
+  return s->host.add_node(n);
+}
+int pine_gpu_scene_node_constf(pine_gpu_scene* s, float v) {
+  HostNode n;
+  n.kind = HostNode::ConstF;
+  n.f = v;
+  return add_node(s, n);
+}
+int pine_gpu_scene_node_const3(pine_gpu_scene* s, const float v[3]) {
+  if (!check(s, v)) return -1;
+  HostNode n;
+  n.kind = HostNode::Const3;
+  n.v = ld3(v);
+  return add_node(s, n);
+}
+int pine_gpu_scene_node_input(pine_gpu_scene* s, int which) {
+  if (which < 0 || which > 2) {
+    if (check(s)) set_error("node input: 0 Position, 1 Normal, 2 UV");
+    return -1;
+  }
+  HostNode n;
+  n.kind = which == 0 ? HostNode::Position : which == 1 ? HostNode::Normal : HostNode::UV;
+  return add_node(s, n);
+}
+int pine_gpu_scene_node_is_vec3(pine_gpu_scene* s, int id) {
+  if (!check(s)) return -1;
+  if (id < 0 || id >= int(s->host.nodes.size())) {
+    set_error("node id out of range");
+    return -1;
+  }
+  return s->host.nodes[size_t(id)].is_vec3() ? 1 : 0;
+}
+int pine_gpu_scene_node_binary(pine_gpu_scene* s, int op, int a, int b) {
+  if (!check(s)) return -1;
+  const int va = pine_gpu_scene_node_is_vec3(s, a), vb = pine_gpu_scene_node_is_vec3(s, b);
+  if (va < 0 || vb < 0) return -1;
+  if (va != vb) {
+    set_error("node binary: operands must both be Nodef or both Node3f (wrap the Nodef with node_splat)");
+    return -1;
+  }
+  HostNode n;
+  n.kind = va ? HostNode::Bin3 : HostNode::BinF;
+  n.op = char(op);
+  n.a = a;
+  n.b = b;
+  return add_node(s, n);
+}
+int pine_gpu_scene_node_unary(pine_gpu_scene* s, int op, int a) {
+  if (!check(s)) return -1;
+  const int va = pine_gpu_scene_node_is_vec3(s, a);
+  if (va < 0) return -1;
+  HostNode n;
+  n.kind = va ? HostNode::Un3 : HostNode::UnF;
+  n.op = char(op);
+  n.a = a;
+  return add_node(s, n);
+}
+int pine_gpu_scene_node_component(pine_gpu_scene* s, int a, int comp) {
+  HostNode n;
+  n.kind = HostNode::Comp;
+  n.a = a;
+  n.n = comp;
+  return add_node(s, n);
+}
+int pine_gpu_scene_node_to_vec3(pine_gpu_scene* s, int x, int y, int z) {
+  HostNode n;
+  n.kind = HostNode::ToVec3;
+  n.a = x;
+  n.b = y;
+  n.c = z;
+  return add_node(s, n);
+}
+int pine_gpu_scene_node_checkerboard(pine_gpu_scene* s, int p, float ratio) {
+  HostNode n;
+  n.kind = HostNode::Checker;
+  n.a = p;
+  n.f = ratio;
+  return add_node(s, n);
+}
+int pine_gpu_scene_node_splat(pine_gpu_scene* s, int a) {
+  HostNode n;
+  n.kind = HostNode::Splat;
+  n.a = a;
+  return add_node(s, n);
+}
+static int add_node_material(pine_gpu_scene* s, const char* name, int kind, const int ids[4], const bool used[4],
+                             float ior, const std::string& desc_kind, const std::string& desc_tail) {
+  if (!check(s)) return -1;
+  for (int k = 0; k < 4; k++) {
+    if (!used[k]) continue;
+    const int v = pine_gpu_scene_node_is_vec3(s, ids[k]);
+    if (v < 0) return -1;
+    if ((k == 0) != (v == 1)) {
+      set_error(k == 0 ? "material: albedo must be a Node3f" : "material: roughness / metallic / transmission / ior must be a Nodef");
+      return -1;
+    }
+  }
+  DMaterial m{};
+  m.kind = kind;
+  m.ior = ior;
+  std::string n = mat_name(s, name);
+  std::string desc = "material " + n + " " + desc_kind;
+  for (int k = 0; k < 4; k++)
+    if (used[k]) desc += fmt(" %d", ids[k]);
+  desc += desc_tail;
+  const int id = s->host.add_material(n.c_str(), m, desc);
+  for (int k = 0; k < 4; k++) s->host.material_nodes[size_t(id)].id[k] = used[k] ? ids[k] : -1;
+  return id;
+}
+int pine_gpu_scene_add_material_diffuse_n(pine_gpu_scene* s, const char* name, int albedo) {
+  const int ids[4] = {albedo, -1, -1, -1};
+  const bool used[4] = {true, false, false, false};
+  return add_node_material(s, name, MAT_DIFFUSE, ids, used, 1.45f, "diffuse_n", "");
+}
+int pine_gpu_scene_add_material_uber_n(pine_gpu_scene* s, const char* name, int albedo, int roughness, int metallic,
+                                       int transmission, float ior) {
+  const int ids[4] = {albedo, roughness, metallic, transmission};
+  const bool used[4] = {true, true, true, true};
+  return add_node_material(s, name, MAT_UBER, ids, used, ior, "uber_n", fmt(" %a", ior));
+}
+int pine_gpu_scene_add_material_metal(pine_gpu_scene* s, const char* name, int albedo, int roughness) {
+  const int ids[4] = {albedo, roughness, -1, -1};
+  const bool used[4] = {true, true, false, false};
+  return add_node_material(s, name, MAT_METAL, ids, used, 1.0f, "metal", "");
+}
+int pine_gpu_scene_add_material_glossy(pine_gpu_scene* s, const char* name, int albedo, int roughness, int ior) {
+  const int ids[4] = {albedo, roughness, -1, ior};
+  const bool used[4] = {true, true, false, true};
+  return add_node_material(s, name, MAT_GLOSSY, ids, used, 1.4f, "glossy", "");
+}
+int pine_gpu_scene_add_material_glass(pine_gpu_scene* s, const char* name, int albedo, int roughness, int ior) {
+  const int ids[4] = {albedo, roughness, -1, ior};
+  const bool used[4] = {true, true, false, true};
+  return add_node_material(s, name, MAT_GLASS, ids, used, 1.4f, "glass", "");
+}
+
 int pine_gpu_scene_find_material(pine_gpu_scene* s, const char* name) {
   if (!check(s, name)) return -1;
   int id = s->host.find_material(name);

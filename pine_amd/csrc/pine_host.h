@@ -73,7 +73,25 @@ struct FlatAccel {
   bool built = false;
 };
 
+// One shading node of the scene's node table (node.h:13-297); ids are indices into SceneHost::nodes.
+struct HostNode {
+  enum Kind { ConstF, Const3, Position, Normal, UV, BinF, Bin3, UnF, Un3, Comp, ToVec3, Checker, Splat } kind = ConstF;
+  char op = 0;
+  int a = -1, b = -1, c = -1, n = 0;
+  float f = 0;
+  f3 v{0, 0, 0};
+  bool is_vec3() const {
+    return kind == Const3 || kind == Position || kind == Normal || kind == UV || kind == Bin3 || kind == Un3 || kind == ToVec3 || kind == Splat;
+  }
+};
+// node ids of a material's parameters (-1: the literal in DMaterial is used)
+struct MaterialNodes {
+  int id[4] = {-1, -1, -1, -1};
+};
+
 struct SceneHost {
+  std::vector<HostNode> nodes;
+  std::vector<MaterialNodes> material_nodes;  // parallel to `materials`
   std::vector<DMaterial> materials;
   std::vector<std::string> material_names;
   std::vector<std::string> material_describe;
@@ -86,6 +104,11 @@ struct SceneHost {
   std::string camera_describe;
   FlatAccel accel;
 
+  int add_node(const HostNode& n);  // returns the id, or -1 with the error set
+  bool node_reads_surface(int id) const;
+  f3 node_fold(int id) const;       // value of a node subtree that does not read the surface
+  // flatten the programs of every material into `ops`; fills DMaterial::prog / folded literals of `out`
+  bool compile_node_programs(std::vector<DMaterial>& out, std::vector<DNodeOp>& ops) const;
   int find_material(const char* name) const;
   int add_material(const char* name, const DMaterial& m, const std::string& desc);
   int add_geometry(HostGeometry g);

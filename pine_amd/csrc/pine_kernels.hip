@@ -91,6 +91,7 @@ struct DeviceScene {
   const DBvh* bvhs;
   const float* tri_verts;
   const int* lights;
+  const DNodeOp* node_ops;  // shading-node programs (F_NODES variants)
   int num_lights;
   int num_shapes;
   DCamera cam;
@@ -102,7 +103,7 @@ struct DeviceScene {
   // the small scene records packed in one 16-byte-aligned blob (for LDS staging):
   const uint4* blob;
   int blob_bytes;
-  int off_nodes, off_shapes, off_materials, off_bvhs, off_prims, off_lights;  // byte offsets in the blob
+  int off_nodes, off_shapes, off_materials, off_bvhs, off_prims, off_lights, off_node_ops;  // byte offsets in the blob
 };
 
 // What the traversal and shading code reads.  In the F_LDS_SCENE specialisation every pointer is
@@ -116,6 +117,7 @@ struct SceneView {
   const DBvh* bvhs;
   const int* lights;
   const float* tri_verts;
+  const DNodeOp* node_ops;
   int stack_top;
   int num_shapes;
 };
@@ -409,6 +411,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
     V.prims = reinterpret_cast<const int*>(base + S.off_prims);
     V.lights = reinterpret_cast<const int*>(base + S.off_lights);
+    V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
   } else {
     __syncthreads();  // Sobol rows staged above
     V.nodes = S.nodes;
@@ -417,6 +420,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.bvhs = S.bvhs;
     V.prims = S.prims;
     V.lights = S.lights;
+    V.node_ops = S.node_ops;
   }
   // Global part of the fold stack: lane-major, one 32-byte entry (two float4) per level, so the
   // bytes a lane touches are only the levels its paths really reach -- the hot set (~2.6 levels x
@@ -641,29 +645,35 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       bx.kind = BX_DIFFUSE;
       bx.roughness = 0.0f;
       bx.ior = 1.0f;
-      bool is_uber = false, is_sss = false;
+      bool is_uber = false, is_sss = false, is_lobe = false;
       if constexpr (F & F_UBER) is_uber = mat->kind == MAT_UBER;
+      if constexpr (F & F_UBER) is_lobe = mat->kind >= MAT_METAL;  // Metal / Glossy / Glass: one fixed lobe
       if constexpr (F & F_SSS) is_sss = mat->kind == MAT_SUBSURFACE;
+      const MatParams mp = material_params<F>(mat, V.node_ops, it.p, it.n, it.uv);
       if (is_uber) {
         DRng g = rng_load();
-        if (with_probability(mat->metallic, g)) {
+        if (with_probability(mp.metallic, g)) {
           bx.kind = BX_CONDUCTOR;
-          bx.roughness = mat->roughness;
-        } else if (with_probability(mat->transmission, g)) {
+          bx.roughness = mp.roughness;
+        } else if (with_probability(mp.transmission, g)) {
           bx.kind = BX_REFR_DIEL;
-          bx.roughness = mat->roughness;
-          bx.ior = mat->ior;
+          bx.roughness = mp.roughness;
+          bx.ior = mp.ior;
         } else {
           bx.kind = BX_DIFF_DIEL;
-          bx.roughness = mat->roughness;
-          bx.ior = mat->ior;
+          bx.roughness = mp.roughness;
+          bx.ior = mp.ior;
         }
         rng_store(g);
+      } else if (is_lobe) {  // material.h:39-78
+        bx.kind = mat->kind == MAT_METAL ? BX_CONDUCTOR : mat->kind == MAT_GLOSSY ? BX_DIFF_DIEL : BX_REFR_DIEL;
+        bx.roughness = pmax(mp.roughness, min_roughness);
+        bx.ior = mp.ior;
       } else if (is_sss) {
         const float fr = FrDielectric(dot(wi, it.n), mat->ior);
         if (sampler_get1d<true>(T, sampler) < fr) {
           bx.kind = BX_REFRACTIVE;
-          bx.roughness = pmax(mat->roughness, min_roughness);
+          bx.roughness = pmax(mp.roughness, min_roughness);
           bx.ior = mat->ior;
         } else if (diffused) {
           bx.kind = BX_DIFFUSE;
@@ -751,8 +761,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                 // the material records are re-read here instead of being kept in registers across
                 // the traversal (le is the emitter's colour: the one-sided test passed above)
                 const f3 le = ld3(lmat->color);
-                bx.albedo = ld3(mat->color);
-                bx.albedo_over_pi = ld3(mat->color_over_pi);
+                bx.albedo = mp.albedo;
+                bx.albedo_over_pi = mp.albedo_over_pi;
                 const float cosine = absdot(gs.w, it.n);
                 const f3 wo = mul(w2l, gs.w);
                 const f3 f = bxdf_f<F>(bx, wo);
@@ -766,8 +776,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
       SEC_MARK(7);  // NEE evaluation (and light sampling of lanes without a shadow ray)
       // ---- BSDF sampling + continuation (path.cpp:114-120) ----
-      bx.albedo = ld3(mat->color);
-      bx.albedo_over_pi = ld3(mat->color_over_pi);
+      bx.albedo = mp.albedo;
+      bx.albedo_over_pi = mp.albedo_over_pi;
       DBsdfSample bs;
       if (bxdf_sample<F, true>(bx, T, sampler, bs)) {
         const f3 wo_world = mul(l2w, bs.wo);
@@ -1212,7 +1222,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   DeviceScene& S = p->S;
   S.off_nodes = put(A.nodes.data(), A.nodes.size() * sizeof(DNode));
   S.off_shapes = put(shapes.data(), shapes.size() * sizeof(DShape));
-  S.off_materials = put(H.materials.data(), H.materials.size() * sizeof(DMaterial));
+  std::vector<DMaterial> dev_materials;  // literals folded, node programs attached
+  std::vector<DNodeOp> node_ops;
+  if (!H.compile_node_programs(dev_materials, node_ops)) return -1;
+  S.off_materials = put(dev_materials.data(), dev_materials.size() * sizeof(DMaterial));
+  S.off_node_ops = put(node_ops.data(), node_ops.size() * sizeof(DNodeOp));
   S.off_bvhs = put(A.bvhs.data(), A.bvhs.size() * sizeof(DBvh));
   std::vector<int> packed_prims = A.prims;  // top-level entries: geometry | emissive | kind (pine_types.h)
   for (size_t i = size_t(A.top_prim_begin); i < packed_prims.size(); i++) {
@@ -1252,6 +1266,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.bvhs = reinterpret_cast<const DBvh*>(p->d_blob + S.off_bvhs);
   S.prims = reinterpret_cast<const int*>(p->d_blob + S.off_prims);
   S.lights = reinterpret_cast<const int*>(p->d_blob + S.off_lights);
+  S.node_ops = reinterpret_cast<const DNodeOp*>(p->d_blob + S.off_node_ops);
   S.tri_verts = p->d_tri;
   S.num_lights = int(H.lights.size());
   S.num_shapes = int(shapes.size());
@@ -1294,10 +1309,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
       default: break;
     }
   }
-  for (auto& m : H.materials) {
-    if (m.kind == MAT_UBER) need |= F_UBER;
+  for (auto& m : dev_materials) {
+    if (m.kind == MAT_UBER || m.kind >= MAT_METAL) need |= F_UBER;  // the microfacet lobes
     if (m.kind == MAT_SUBSURFACE) need |= F_SSS;
   }
+  if (!node_ops.empty()) need |= F_NODES;
   const bool lds_ok = size_t(S.blob_bytes) <= 32 * 1024 && getenv("PINE_GPU_NO_LDS_SCENE") == nullptr;
   p->variant = -1;
   for (int v = 0; v < kNumVariants; v++) {
@@ -1339,8 +1355,9 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // metallic/transmission: sampler.h:317-324; BSSRDF channel pick: bxdf.cpp:335) make a pixel's
   // samples sequentially dependent: one item = the whole pixel.
   bool in_path_rng = false;
-  for (auto& m : H.materials) {
+  for (auto& m : dev_materials) {
     if (m.kind == MAT_SUBSURFACE) in_path_rng = true;
+    if (m.kind == MAT_UBER && (m.prog[2] >= 0 || m.prog[3] >= 0)) in_path_rng = true;  // value known only at the surface
     if (m.kind == MAT_UBER) {
       if (m.metallic != 0 && m.metallic != 1) in_path_rng = true;
       if (m.metallic != 1 && m.transmission != 0 && m.transmission != 1) in_path_rng = true;

@@ -94,6 +94,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
     V.prims = reinterpret_cast<const int*>(base + S.off_prims);
     V.lights = reinterpret_cast<const int*>(base + S.off_lights);
+    V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
   } else {
     V.nodes = S.nodes;
     V.shapes = S.shapes;
@@ -101,6 +102,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.bvhs = S.bvhs;
     V.prims = S.prims;
     V.lights = S.lights;
+    V.node_ops = S.node_ops;
   }
   // queues: every context starts "fresh" in the terminal queue (stage T hands out work items)
   if (tid < QC_WORDS) qctl[tid] = 0;
@@ -321,9 +323,11 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         bx.kind = BX_DIFFUSE;
         bx.roughness = 0.0f;
         bx.ior = 1.0f;
-        bool is_uber = false, is_sss = false;
+        bool is_uber = false, is_sss = false, is_lobe = false;
         if constexpr (F & F_UBER) is_uber = mat->kind == MAT_UBER;
+        if constexpr (F & F_UBER) is_lobe = mat->kind >= MAT_METAL;  // Metal / Glossy / Glass: one fixed lobe
         if constexpr (F & F_SSS) is_sss = mat->kind == MAT_SUBSURFACE;
+        const MatParams mp = material_params<F>(mat, V.node_ops, it.p, it.n, it.uv);
         auto rng_load = [&]() -> DRng {
           return DRng{uint64_t(cg[0]) | (uint64_t(cg[1]) << 32), uint64_t(cg[2]) | (uint64_t(cg[3]) << 32)};
         };
@@ -335,19 +339,23 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         };
         if (is_uber) {
           DRng g = rng_load();
-          if (with_probability(mat->metallic, g)) {
+          if (with_probability(mp.metallic, g)) {
             bx.kind = BX_CONDUCTOR;
-            bx.roughness = mat->roughness;
-          } else if (with_probability(mat->transmission, g)) {
+            bx.roughness = mp.roughness;
+          } else if (with_probability(mp.transmission, g)) {
             bx.kind = BX_REFR_DIEL;
-            bx.roughness = mat->roughness;
-            bx.ior = mat->ior;
+            bx.roughness = mp.roughness;
+            bx.ior = mp.ior;
           } else {
             bx.kind = BX_DIFF_DIEL;
-            bx.roughness = mat->roughness;
-            bx.ior = mat->ior;
+            bx.roughness = mp.roughness;
+            bx.ior = mp.ior;
           }
           rng_store(g);
+        } else if (is_lobe) {  // material.h:39-78
+          bx.kind = mat->kind == MAT_METAL ? BX_CONDUCTOR : mat->kind == MAT_GLOSSY ? BX_DIFF_DIEL : BX_REFR_DIEL;
+          bx.roughness = pmax(mp.roughness, min_roughness);
+          bx.ior = mp.ior;
         } else if (is_sss) {
           const float fr = FrDielectric(dot(wi, it.n), mat->ior);
           if (sampler_get1d<true>(T, sampler) < fr) {
@@ -428,8 +436,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                 SEC_MARK(3);  // S: shadow traversal
                 if (!occluded) {
                   const f3 le = ld3(lmat->color);
-                  bx.albedo = ld3(mat->color);
-                  bx.albedo_over_pi = ld3(mat->color_over_pi);
+                  bx.albedo = mp.albedo;
+                  bx.albedo_over_pi = mp.albedo_over_pi;
                   const float cosine = absdot(gs.w, it.n);
                   const f3 wo = mul(w2l, gs.w);
                   const f3 f = bxdf_f<F>(bx, wo);
@@ -442,8 +450,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         }
         SEC_MARK(4);  // S: NEE evaluation
         // ---- BSDF sampling + continuation (path.cpp:114-120) ----
-        bx.albedo = ld3(mat->color);
-        bx.albedo_over_pi = ld3(mat->color_over_pi);
+        bx.albedo = mp.albedo;
+        bx.albedo_over_pi = mp.albedo_over_pi;
         DBsdfSample bs;
         if (bxdf_sample<F, true>(bx, T, sampler, bs)) {
           const f3 wo_world = mul(l2w, bs.wo);

@@ -42,9 +42,15 @@ enum MaterialKind : int {
   MAT_DIFFUSE = 1,
   MAT_UBER = 2,
   MAT_SUBSURFACE = 3,
+  MAT_METAL = 4,   // ConductorBSDF(albedo, max(roughness, min_roughness))              material.h:39-50
+  MAT_GLOSSY = 5,  // DiffusiveDielectricBSDF(albedo, max(roughness, min_roughness), ior) material.h:52-64
+  MAT_GLASS = 6,   // RefractiveDielectricBSDF(...)                                      material.h:66-78
 };
 
-// 64-byte material record (constant shading nodes folded to literals).
+// 80-byte material record.  Parameters are literals (constant shading nodes and node subtrees that do
+// not read the surface are folded on the host) unless prog[k] >= 0: then
+// parameter k (0 albedo, 1 roughness, 2 metallic, 3 transmission / ior of Glossy and Glass) is the
+// result of the node program starting at DNodeOp index prog[k].
 struct alignas(16) DMaterial {
   float color[3];  // albedo or emission
   int kind;
@@ -53,8 +59,23 @@ struct alignas(16) DMaterial {
   int pad;
   float color_over_pi[3];  // albedo / Pi, the Lambertian f (bxdf.cpp:21,27): same IEEE division, done once on the host
   int pad2;
+  int prog[4];
 };
-static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
+static_assert(sizeof(DMaterial) == 80, "DMaterial must be 80 bytes");
+
+// Shading-node program (node.h:13-297 flattened to postfix form): a stack machine over vec3 values; a
+// float node is carried as a splat vec3 (every node operation is componentwise, so that is exact).
+enum NodeOpCode : int {
+  N_END = 0, N_CONST, N_POS, N_NORMAL, N_UV, N_ADD, N_SUB, N_MUL, N_DIV, N_POW, N_NEG, N_ABS, N_SQR, N_SQRT, N_FRACT,
+  N_COMP,     // x = component index (as float): pop v, push splat(v[n])
+  N_TOVEC3,   // pop z, y, x (splats), push (x, y, z)
+  N_CHECKER,  // x = ratio: pop p, push splat(float(prod(fract(p) - ratio) > 0))  node.cpp:15-18
+};
+struct alignas(16) DNodeOp {
+  int op;
+  float x, y, z;
+};
+constexpr int kNodeStack = 8;  // evaluation stack depth the host guarantees
 
 // 64-byte BVH node: the two child boxes live in the parent (as in pine's BVH) so one fetch decides
 // both children.  child[i] >= 0 with count[i] == 0: inner node index.  count[i] > 0: child i is a

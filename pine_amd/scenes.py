@@ -40,11 +40,18 @@ def cbox(size=(640, 640), camera="committed", boxes=True):
     return scene
 
 
-def classic_cones(size=(720, 360), n=100, with_spheres=True):
-    """Config C4: scenes/classic.pine:4-18 materials/shapes with constant-node
-    materials, plus n x n procedurally placed cones Cone([x,0,z], Y, 0.05, 0.05)."""
+def classic_cones(size=(720, 360), n=100, with_spheres=True, checker_floor=False):
+    """Config C4: scenes/classic.pine:4-18 materials/shapes, plus n x n procedurally
+    placed cones Cone([x,0,z], Y, 0.05, 0.05).  checker_floor=True keeps the script's node-graph floor
+    (lerp over Checkerboard(UV(), 0.95) for albedo and roughness, classic.pine:4-7); the default is the
+    constant-node floor the round-1 fixtures were rendered with."""
     scene = Scene()
-    scene.add("floor", Uber([0.5, 0.7, 1.0], 0.4))
+    if checker_floor:
+        from .api import Checkerboard, UV, lerp
+        scene.add("floor", Uber(lerp(Checkerboard(UV(), 0.95), [0.5, 0.7, 1.0], [0.01, 0.02, 0.03]),
+                                lerp(Checkerboard(UV(), 0.95), 0.0, 0.4)))
+    else:
+        scene.add("floor", Uber([0.5, 0.7, 1.0], 0.4))
     scene.add("diffuse", Diffuse([0.8, 0.8, 0.8]))
     scene.add("metal", Uber([1.0, 1.0, 1.0], 0.0, 1.0))
     scene.add("glossy", Uber([0.98, 0.55, 0.02], 0.0, 0.0))
@@ -130,4 +137,36 @@ def shapes_zoo(size=(64, 64)):
     le = (np.float32(600) * np.array([1.0, 0.64, 0.185], dtype=np.float32)).tolist()
     scene.add(Rect([0.0, 1.9, 1], [0.1, 0, 0], [0, 0, 0.1]), Emissive(le))
     scene.set(ThinLenCamera(Film(list(size), Uncharted2()), [0, 1, -4], [0, 1, 0], 0.25))
+    return scene
+
+
+def materials_zoo(size=(64, 64)):
+    """Every material kind of material.h:18-131 except Subsurface, with node-graph parameters: a Rect-only
+    room whose floor is a checkerboard over Position, Metal / Glossy / Glass spheres, an Uber sphere whose
+    roughness and metallic vary with the normal, a Diffuse back wall tinted by fract(Position)."""
+    from .api import (Checkerboard, Position, Normal, UV, Metal, Glossy, Glass, lerp, node_fract, node_abs, Vec3)
+    scene = Scene()
+    scene.add("floor", Diffuse(lerp(Checkerboard(Position() * 2.0, 0.5), [0.85, 0.85, 0.85], [0.15, 0.2, 0.6])))
+    scene.add("wall", Diffuse([0.8, 0.8, 0.8]))
+    # (UV is read on a Rect only: Rect / Disk / triangle uv are plain arithmetic, a Sphere's uv goes through
+    #  atan2f / acosf, where the device libm may differ from glibc in the last bit -- DESIGN.md 1.3)
+    scene.add("back", Diffuse(lerp(Checkerboard(UV() * 4.0, 0.5), node_fract(Position() * 1.5) * 0.5 + [0.3, 0.3, 0.3],
+                                   [0.1, 0.1, 0.1])))
+    scene.add("metal", Metal([1.0, 0.8, 0.6], 0.2))
+    scene.add("glossy", Glossy([0.9, 0.25, 0.2] * node_abs(Normal())[1] + [0.05, 0.05, 0.05], 0.1, 1.5))
+    scene.add("glass", Glass([1.0, 1.0, 1.0], 0.0, 1.5))
+    absn = node_abs(Normal())
+    scene.add("uber", Uber(Vec3(absn[0] * 0.15, 0.5, absn[2] * 0.3) + [0.2, 0.2, 0.2], absn[0] * 0.5 + 0.05,
+                           Checkerboard(Position() * 3.0, 0.5)))
+    scene.add(Rect([0, 0, 1], [2, 0, 0], [0, 0, 2], True), "floor")
+    scene.add(Rect([0, 2, 1], [2, 0, 0], [0, 0, 2]), "wall")
+    scene.add(Rect([-1, 1, 1], [0, 0, 2], [0, 2, 0], True), "wall")
+    scene.add(Rect([1, 1, 1], [0, 0, 2], [0, 2, 0]), "wall")
+    scene.add(Rect([0, 1, 2], [2, 0, 0], [0, 2, 0], True), "back")
+    scene.add(Sphere([-0.55, 0.3, 1.2], 0.3), "metal")
+    scene.add(Sphere([0.1, 0.25, 0.8], 0.25), "glass")
+    scene.add(Sphere([0.6, 0.3, 1.3], 0.3), "glossy")
+    scene.add(Sphere([-0.1, 0.9, 1.5], 0.3), "uber")
+    scene.add(Rect([0.0, 1.9, 1], [0.5, 0, 0], [0, 0, 0.5]), Emissive([20.0, 18.0, 15.0]))
+    scene.set(ThinLenCamera(Film(list(size)), [0, 1, -4], [0, 1, 0], 0.25))
     return scene

@@ -107,6 +107,9 @@ def _render(scene, spp, depth, **kw):
     return out, st
 
 
+LIBM_TOLERANCE_FILMS = {"mats_zoo_64_s32_d6"}
+
+
 def _scene_for(name):
     from pine_amd import scenes
     return {
@@ -119,6 +122,8 @@ def _scene_for(name):
         "zoo_48_s16_d5": lambda: scenes.shapes_zoo((48, 48)),
         "classic_cones12_90x45_s32_d6": lambda: scenes.classic_cones((90, 45), 12),
         "sss_48_s32_d8": lambda: scenes.sss((48, 48), 1),
+        "mats_zoo_64_s32_d6": lambda: scenes.materials_zoo((64, 64)),
+        "classic_checker_cones8_90x45_s32_d6": lambda: scenes.classic_cones((90, 45), 8, checker_floor=True),
     }[name]()
 
 
@@ -129,6 +134,13 @@ def test_film_matches_reference_golden(name):
     sc = _scene_for(name)
     assert sc.describe() == ps
     film, st = _render(sc, spp, depth)
+    if name in LIBM_TOLERANCE_FILMS:
+        # microfacet lobes with Schlick's powf under node-driven parameters: the device powf is within
+        # 1 ulp of glibc's, not identical -- the declared tolerance of SURVEY.md 8(d) applies
+        rel = np.linalg.norm(film[..., :3] - ref[..., :3], axis=2) / (np.linalg.norm(ref[..., :3], axis=2) + 1e-3)
+        assert (rel <= 1e-4).mean() >= 0.999 and rel.max() <= 1e-2, (float((rel <= 1e-4).mean()), float(rel.max()))
+        assert (film.view(np.uint32) != ref.view(np.uint32)).any(axis=2).mean() < 0.01  # and all but a few pixels are identical
+        return
     assert_bit_equal(film, ref, name)
 
 

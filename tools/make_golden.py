@@ -47,6 +47,9 @@ FILMS = {
     "zoo_48_s16_d5": (lambda: scenes.shapes_zoo((48, 48)), 16, 5),
     "classic_cones12_90x45_s32_d6": (lambda: scenes.classic_cones((90, 45), 12), 32, 6),
     "sss_48_s32_d8": (lambda: scenes.sss((48, 48), 1), 32, 8),
+    # node-graph materials + Metal / Glossy / Glass (node.h, material.h:39-78)
+    "mats_zoo_64_s32_d6": (lambda: scenes.materials_zoo((64, 64)), 32, 6),
+    "classic_checker_cones8_90x45_s32_d6": (lambda: scenes.classic_cones((90, 45), 8, checker_floor=True), 32, 6),
 }
 
 
