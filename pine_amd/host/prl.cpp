@@ -113,10 +113,24 @@ struct CameraObj : Object {
   std::shared_ptr<FilmObj> film;
   float from[3], to[3], fov, len_radius = 0.0f, focus = 1.0f;
 };
+// A shading-node expression (Nodef / Node3f, node.h:13-297).  Every float-valued node expression is
+// typed "Nodef" here and every vec3-valued one "Node3f": the reference gives each node struct its own
+// type name ("Addf", "Checkerboard", ...) that converts in one step to Nodef / Node3f and to nothing
+// else, so overload resolution picks the same function either way.
+struct NodeObj : Object {
+  std::string kind;  // constf const3 position normal uv bin un comp tovec3 checker splat
+  char op = 0;
+  int n = 0;
+  float f = 0, v[3] = {0, 0, 0};
+  bool is3 = false;
+  std::shared_ptr<NodeObj> a, b, c;
+  bool constant() const { return kind == "constf" || kind == "const3"; }
+};
+using NodeP3 = std::shared_ptr<NodeObj>;
 struct MaterialObj : Object {
-  std::string kind;  // Emissive | Diffuse | Uber | Subsurface
-  float color[3] = {0, 0, 0};
-  float roughness = 0, metallic = 0, transmission = 0, ior = 1.45f;
+  std::string kind;  // Emissive | Diffuse | Uber | Subsurface | Metal | Glossy | Glass
+  NodeP3 albedo, roughness, metallic, transmission, ior_node;
+  float ior = 1.45f;
   float sigma_s[3] = {0, 0, 0};
 };
 struct ShapeObj : Object {
@@ -881,6 +895,32 @@ static void gpu_check(int rc, const char* what) {
   if (rc < 0) fail(std::string(what) + ": " + pine_gpu_last_error());
 }
 
+// instantiate a node tree in the scene's node table (shared sub-trees once per material)
+static int instantiate_node(SceneObj& s, const NodeP3& n, std::map<const NodeObj*, int>& memo) {
+  auto it = memo.find(n.get());
+  if (it != memo.end()) return it->second;
+  int id = -1;
+  if (n->kind == "constf") id = pine_gpu_scene_node_constf(s.h, n->f);
+  else if (n->kind == "const3") id = pine_gpu_scene_node_const3(s.h, n->v);
+  else if (n->kind == "position") id = pine_gpu_scene_node_input(s.h, 0);
+  else if (n->kind == "normal") id = pine_gpu_scene_node_input(s.h, 1);
+  else if (n->kind == "uv") id = pine_gpu_scene_node_input(s.h, 2);
+  else if (n->kind == "bin") {
+    const int x = instantiate_node(s, n->a, memo), y = instantiate_node(s, n->b, memo);
+    id = pine_gpu_scene_node_binary(s.h, n->op, x, y);
+  } else if (n->kind == "un") id = pine_gpu_scene_node_unary(s.h, n->op, instantiate_node(s, n->a, memo));
+  else if (n->kind == "comp") id = pine_gpu_scene_node_component(s.h, instantiate_node(s, n->a, memo), n->n);
+  else if (n->kind == "tovec3") {
+    const int x = instantiate_node(s, n->a, memo);
+    const int y = n->b ? instantiate_node(s, n->b, memo) : -1, z = n->c ? instantiate_node(s, n->c, memo) : -1;
+    id = pine_gpu_scene_node_to_vec3(s.h, x, y, z);
+  } else if (n->kind == "checker") id = pine_gpu_scene_node_checkerboard(s.h, instantiate_node(s, n->a, memo), n->f);
+  else if (n->kind == "splat") id = pine_gpu_scene_node_splat(s.h, instantiate_node(s, n->a, memo));
+  gpu_check(id, "shading node");
+  memo[n.get()] = id;
+  return id;
+}
+
 Interp::Interp() {
   scopes.emplace_back();
   auto& r = R;
@@ -1268,43 +1308,185 @@ Interp::Interp() {
     return mk_mat(m);
   });
 
-  // ---- shading nodes: constants only (node.cpp:103-114) ----
-  r.convert("i32", "Nodef", [](const Value& v) { return retype(mk_f32(float(v.i[0])), "Nodef"); });
-  r.convert("f32", "Nodef", [](const Value& v) { return retype(v, "Nodef"); });
-  r.convert("vec3i", "Node3f", [](const Value& v) {
+  // ---- shading nodes (node.cpp:29-116) ----
+  r.types["Nodef"] = r.types["Node3f"] = true;
+  auto nobj = [](const Cell& c) { return obj<NodeObj>(c); };
+  auto mk_node = [](NodeP3 n) { return mk_obj(n->is3 ? "Node3f" : "Nodef", n); };
+  auto constf = [](float v) {
+    auto n = std::make_shared<NodeObj>();
+    n->kind = "constf";
+    n->f = v;
+    return n;
+  };
+  auto const3 = [](const float* v) {
+    auto n = std::make_shared<NodeObj>();
+    n->kind = "const3";
+    n->is3 = true;
+    memcpy(n->v, v, 12);
+    return n;
+  };
+  auto splat = [](NodeP3 x) {
+    if (x->is3) return x;
+    auto n = std::make_shared<NodeObj>();
+    n->kind = "splat";
+    n->is3 = true;
+    n->a = x;
+    return n;
+  };
+  auto bin = [](char op, NodeP3 x, NodeP3 y) {
+    auto n = std::make_shared<NodeObj>();
+    n->kind = "bin";
+    n->op = op;
+    n->is3 = x->is3;
+    n->a = x;
+    n->b = y;
+    return n;
+  };
+  auto un = [](char op, NodeP3 x) {
+    auto n = std::make_shared<NodeObj>();
+    n->kind = "un";
+    n->op = op;
+    n->is3 = x->is3;
+    n->a = x;
+    return n;
+  };
+  auto tovec3 = [](NodeP3 x, NodeP3 y, NodeP3 z) {
+    auto n = std::make_shared<NodeObj>();
+    n->kind = "tovec3";
+    n->is3 = true;
+    n->a = x;
+    n->b = y;
+    n->c = z;
+    return n;
+  };
+  r.convert("i32", "Nodef", [=](const Value& v) { return mk_node(constf(float(v.i[0]))); });
+  r.convert("f32", "Nodef", [=](const Value& v) { return mk_node(constf(v.f[0])); });
+  r.convert("vec3i", "Node3f", [=](const Value& v) {
     const float f[3] = {float(v.i[0]), float(v.i[1]), float(v.i[2])};
-    return retype(mk_vecf(3, f), "Node3f");
+    return mk_node(const3(f));
   });
-  r.convert("vec3", "Node3f", [](const Value& v) { return retype(v, "Node3f"); });
+  r.convert("vec3", "Node3f", [=](const Value& v) { return mk_node(const3(v.f)); });
+  for (const char* in : {"Position", "Normal", "UV"}) {
+    const std::string kind = in == std::string("Position") ? "position" : in == std::string("Normal") ? "normal" : "uv";
+    r.def(in, {}, "Node3f", [=](Interp&, std::vector<Cell>&) {
+      auto n = std::make_shared<NodeObj>();
+      n->kind = kind;
+      n->is3 = true;
+      return mk_node(n);
+    });
+  }
+  for (const char* opn : {"+", "-", "*", "/", "^"}) {
+    const char o = opn[0];
+    r.def(opn, {"Nodef", "Nodef"}, "Nodef", [=](Interp&, std::vector<Cell>& a) { return mk_node(bin(o, nobj(a[0]), nobj(a[1]))); });
+    r.def(opn, {"Node3f", "Node3f"}, "Node3f", [=](Interp&, std::vector<Cell>& a) { return mk_node(bin(o, nobj(a[0]), nobj(a[1]))); });
+  }
+  for (const char* opn : {"*", "^", "/"})  // (Node3f, Nodef): node.cpp:82,84,85
+    r.def(opn, {"Node3f", "Nodef"}, "Node3f", [=](Interp&, std::vector<Cell>& a) { return mk_node(bin(opn[0], nobj(a[0]), splat(nobj(a[1])))); });
+  for (const char* opn : {"*", "/"})  // (Nodef, Node3f): node.cpp:83,86
+    r.def(opn, {"Nodef", "Node3f"}, "Node3f", [=](Interp&, std::vector<Cell>& a) { return mk_node(bin(opn[0], splat(nobj(a[0])), nobj(a[1]))); });
+  r.def("-x", {"Nodef"}, "Nodef", [=](Interp&, std::vector<Cell>& a) { return mk_node(un('-', nobj(a[0]))); });
+  r.def("-x", {"Node3f"}, "Node3f", [=](Interp&, std::vector<Cell>& a) { return mk_node(un('-', nobj(a[0]))); });
+  for (auto& f : std::vector<std::pair<const char*, char>>{{"abs", 'a'}, {"sqr", 's'}, {"sqrt", 'r'}, {"fract", 'f'}}) {
+    const char o = f.second;
+    r.def(f.first, {"Nodef"}, "Nodef", [=](Interp&, std::vector<Cell>& a) { return mk_node(un(o, nobj(a[0]))); });
+    r.def(f.first, {"Node3f"}, "Node3f", [=](Interp&, std::vector<Cell>& a) { return mk_node(un(o, nobj(a[0]))); });
+  }
+  auto comp = [=](std::vector<Cell>& a) {
+    if (a[1]->i[0] < 0 || a[1]->i[0] > 2) fail("NodeComponent's second parameter should be 0, 1, or 2, but get " + std::to_string(a[1]->i[0]));
+    auto n = std::make_shared<NodeObj>();
+    n->kind = "comp";
+    n->a = nobj(a[0]);
+    n->n = a[1]->i[0];
+    return mk_node(n);
+  };
+  r.def("[]", {"Node3f", "i32"}, "Nodef", [=](Interp&, std::vector<Cell>& a) { return comp(a); });
+  r.def("Comp", {"Node3f", "i32"}, "Nodef", [=](Interp&, std::vector<Cell>& a) { return comp(a); });
+  r.def("Vec3", {"Nodef"}, "Node3f", [=](Interp&, std::vector<Cell>& a) { return mk_node(tovec3(nobj(a[0]), nullptr, nullptr)); });
+  r.def("Vec3", {"Nodef", "Nodef", "Nodef"}, "Node3f", [=](Interp&, std::vector<Cell>& a) { return mk_node(tovec3(nobj(a[0]), nobj(a[1]), nobj(a[2]))); });
+  auto checker = [=](NodeP3 p, float ratio) {
+    auto n = std::make_shared<NodeObj>();
+    n->kind = "checker";
+    n->a = p;
+    n->f = ratio;
+    return mk_node(n);
+  };
+  r.def("Checkerboard", {"Node3f"}, "Nodef", [=](Interp&, std::vector<Cell>& a) { return checker(nobj(a[0]), 0.5f); });
+  r.def("Checkerboard", {"Node3f", "f32"}, "Nodef", [=](Interp&, std::vector<Cell>& a) { return checker(nobj(a[0]), a[1]->f[0]); });
+  // lerp: node.cpp:88-102 (the scalar one is psl::lerp, math.cpp:21)
+  r.def("lerp", {"f32", "f32", "f32"}, "f32", [](Interp&, std::vector<Cell>& a) { return mk_f32((1 - a[0]->f[0]) * a[1]->f[0] + a[0]->f[0] * a[2]->f[0]); });
+  r.def("lerp", {"Nodef", "Nodef", "Nodef"}, "Nodef", [=](Interp&, std::vector<Cell>& a) {
+    NodeP3 t = nobj(a[0]);
+    return mk_node(bin('+', bin('*', t, nobj(a[2])), bin('*', bin('-', constf(1.0f), t), nobj(a[1]))));
+  });
+  r.def("lerp", {"Nodef", "Node3f", "Node3f"}, "Node3f", [=](Interp&, std::vector<Cell>& a) {
+    NodeP3 t = nobj(a[0]);
+    return mk_node(bin('+', bin('*', tovec3(t, nullptr, nullptr), nobj(a[2])),
+                       bin('*', tovec3(bin('-', constf(1.0f), t), nullptr, nullptr), nobj(a[1]))));
+  });
+  r.def("lerp", {"Node3f", "Node3f", "Node3f"}, "Node3f", [=](Interp&, std::vector<Cell>& a) {
+    NodeP3 t = nobj(a[0]);
+    const float one[3] = {1.0f, 1.0f, 1.0f};
+    return mk_node(bin('+', bin('*', t, nobj(a[2])), bin('*', bin('-', const3(one), t), nobj(a[1]))));
+  });
 
   // ---- materials (material.cpp:46-62) ----
-  auto material = [](const char* kind, const float* color) {
+  auto material = [](const char* kind) {
     auto m = std::make_shared<MaterialObj>();
     m->kind = kind;
-    memcpy(m->color, color, 12);
     return m;
   };
-  r.def("Emissive", {"Node3f"}, "Emissive", [material](Interp&, std::vector<Cell>& a) { return mk_obj("Emissive", material("Emissive", a[0]->f)); });
-  r.def("Diffuse", {"Node3f"}, "Diffuse", [material](Interp&, std::vector<Cell>& a) { return mk_obj("Diffuse", material("Diffuse", a[0]->f)); });
+  r.def("Emissive", {"Node3f"}, "Emissive", [=](Interp&, std::vector<Cell>& a) {
+    auto m = material("Emissive");
+    m->albedo = nobj(a[0]);
+    if (!m->albedo->constant()) fail("Emissive: only a constant colour is supported by this front-end");
+    return mk_obj("Emissive", m);
+  });
+  r.def("Diffuse", {"Node3f"}, "Diffuse", [=](Interp&, std::vector<Cell>& a) {
+    auto m = material("Diffuse");
+    m->albedo = nobj(a[0]);
+    return mk_obj("Diffuse", m);
+  });
   for (int extra = 0; extra <= 3; extra++) {  // Uber(albedo, roughness[, metallic[, transmission[, ior]]])
     std::vector<std::string> pt{"Node3f", "Nodef"};
     for (int k = 0; k < extra; k++) pt.push_back(k < 2 ? "Nodef" : "f32");
-    r.def("Uber", pt, "Uber", [material, extra](Interp&, std::vector<Cell>& a) {
-      auto m = material("Uber", a[0]->f);
-      m->roughness = a[1]->f[0];
-      if (extra >= 1) m->metallic = a[2]->f[0];
-      if (extra >= 2) m->transmission = a[3]->f[0];
+    r.def("Uber", pt, "Uber", [=](Interp&, std::vector<Cell>& a) {
+      auto m = material("Uber");
+      m->albedo = nobj(a[0]);
+      m->roughness = nobj(a[1]);
+      m->metallic = extra >= 1 ? nobj(a[2]) : constf(0.0f);
+      m->transmission = extra >= 2 ? nobj(a[3]) : constf(0.0f);
       if (extra >= 3) m->ior = a[4]->f[0];
       return mk_obj("Uber", m);
     });
   }
-  r.def("Subsurface", {"Node3f", "Nodef", "vec3"}, "Subsurface", [material](Interp&, std::vector<Cell>& a) {
-    auto m = material("Subsurface", a[0]->f);
-    m->roughness = a[1]->f[0];
+  r.def("Subsurface", {"Node3f", "Nodef", "vec3"}, "Subsurface", [=](Interp&, std::vector<Cell>& a) {
+    auto m = material("Subsurface");
+    m->albedo = nobj(a[0]);
+    m->roughness = nobj(a[1]);
+    if (!m->albedo->constant() || !m->roughness->constant()) fail("Subsurface: only constant parameters are supported by this front-end");
     memcpy(m->sigma_s, a[2]->f, 12);
     return mk_obj("Subsurface", m);
   });
-  for (const char* k : {"Emissive", "Diffuse", "Uber", "Subsurface"}) r.convert(k, "Material", [](const Value& v) { return retype(v, "Material"); });
+  r.def("Metal", {"Node3f", "Nodef"}, "Metal", [=](Interp&, std::vector<Cell>& a) {
+    auto m = material("Metal");
+    m->albedo = nobj(a[0]);
+    m->roughness = nobj(a[1]);
+    return mk_obj("Metal", m);
+  });
+  for (const char* kind : {"Glossy", "Glass"})
+    for (int with_ior = 0; with_ior < 2; with_ior++) {
+      std::vector<std::string> pt{"Node3f", "Nodef"};
+      if (with_ior) pt.push_back("Nodef");
+      r.def(kind, pt, kind, [=](Interp&, std::vector<Cell>& a) {
+        auto m = material(kind);
+        m->albedo = nobj(a[0]);
+        m->roughness = nobj(a[1]);
+        m->ior_node = with_ior ? nobj(a[2]) : constf(1.4f);  // material.h:53,67
+        return mk_obj(kind, m);
+      });
+    }
+  for (const char* k : {"Emissive", "Diffuse", "Uber", "Subsurface", "Metal", "Glossy", "Glass"})
+    r.convert(k, "Material", [](const Value& v) { return retype(v, "Material"); });
 
   // ---- shapes (geometry.cpp:901-946) ----
   auto shape = [](const char* kind, std::vector<float> p, bool flag = false) {
@@ -1395,10 +1577,34 @@ Interp::Interp() {
   });
   auto add_material = [](SceneObj& s, const std::string& name, const MaterialObj& m) {
     int id = -1;
-    if (m.kind == "Emissive") id = pine_gpu_scene_add_material_emissive(s.h, name.c_str(), m.color);
-    else if (m.kind == "Diffuse") id = pine_gpu_scene_add_material_diffuse(s.h, name.c_str(), m.color);
-    else if (m.kind == "Uber") id = pine_gpu_scene_add_material_uber(s.h, name.c_str(), m.color, m.roughness, m.metallic, m.transmission, m.ior);
-    else if (m.kind == "Subsurface") id = pine_gpu_scene_add_material_subsurface(s.h, name.c_str(), m.color, m.roughness, m.sigma_s);
+    std::map<const NodeObj*, int> memo;
+    auto N = [&](const NodeP3& n) { return instantiate_node(s, n, memo); };
+    auto all_const = [&](std::initializer_list<NodeP3> ns) {
+      for (auto& n : ns)
+        if (n && !n->constant()) return false;
+      return true;
+    };
+    if (m.kind == "Emissive") id = pine_gpu_scene_add_material_emissive(s.h, name.c_str(), m.albedo->v);
+    else if (m.kind == "Diffuse") {
+      if (m.albedo->constant()) id = pine_gpu_scene_add_material_diffuse(s.h, name.c_str(), m.albedo->v);
+      else id = pine_gpu_scene_add_material_diffuse_n(s.h, name.c_str(), N(m.albedo));
+    } else if (m.kind == "Uber") {
+      if (all_const({m.albedo, m.roughness, m.metallic, m.transmission}))
+        id = pine_gpu_scene_add_material_uber(s.h, name.c_str(), m.albedo->v, m.roughness->f, m.metallic->f, m.transmission->f, m.ior);
+      else {
+        const int a = N(m.albedo), ro = N(m.roughness), me = N(m.metallic), tr = N(m.transmission);
+        id = pine_gpu_scene_add_material_uber_n(s.h, name.c_str(), a, ro, me, tr, m.ior);
+      }
+    } else if (m.kind == "Subsurface")
+      id = pine_gpu_scene_add_material_subsurface(s.h, name.c_str(), m.albedo->v, m.roughness->f, m.sigma_s);
+    else if (m.kind == "Metal") {
+      const int a = N(m.albedo), ro = N(m.roughness);
+      id = pine_gpu_scene_add_material_metal(s.h, name.c_str(), a, ro);
+    } else if (m.kind == "Glossy" || m.kind == "Glass") {
+      const int a = N(m.albedo), ro = N(m.roughness), io = N(m.ior_node);
+      id = m.kind == "Glossy" ? pine_gpu_scene_add_material_glossy(s.h, name.c_str(), a, ro, io)
+                              : pine_gpu_scene_add_material_glass(s.h, name.c_str(), a, ro, io);
+    }
     gpu_check(id, "scene.add(material)");
     return id;
   };
@@ -1487,13 +1693,19 @@ static std::string value_text(const Value& v) {
     return std::string(buf);
   };
   if (v.type == "i32" || v.type == "BlueSampler") s += std::to_string(v.i[0]);
-  else if (v.type == "f32" || v.type == "Nodef") s += hexf(v.f[0]);
+  else if (v.type == "f32") s += hexf(v.f[0]);
+  else if (v.type == "Nodef" || v.type == "Node3f") {
+    auto n = std::dynamic_pointer_cast<NodeObj>(v.o);
+    if (n && n->kind == "constf") s += "const " + hexf(n->f);
+    else if (n && n->kind == "const3") s += "const " + hexf(n->v[0]) + " " + hexf(n->v[1]) + " " + hexf(n->v[2]);
+    else if (n) s += n->kind + (n->op ? std::string(" ") + n->op : std::string());
+  }
   else if (v.type == "bool") s += v.b ? "true" : "false";
   else if (v.type == "str") s += v.s;
   else if (v.type == "mat4") {
     for (int k = 0; k < 16; k++) s += (k ? " " : "") + hexf(v.f[k]);
-  } else if (v.type.rfind("vec", 0) == 0 || v.type == "Node3f") {
-    const int n = v.type == "Node3f" ? 3 : v.type[3] - '0';
+  } else if (v.type.rfind("vec", 0) == 0) {
+    const int n = v.type[3] - '0';
     const bool is_int = v.type.back() == 'i';
     for (int k = 0; k < n; k++) s += (k ? " " : "") + (is_int ? std::to_string(v.i[k]) : hexf(v.f[k]));
   }

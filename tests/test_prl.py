@@ -156,6 +156,52 @@ def test_script_builds_the_scene_the_api_builds_from_the_same_values():
     assert ps == s.describe()
 
 
+def test_node_expressions_resolve_like_the_reference():
+    """node.cpp:29-116: operators over Nodef / Node3f with the one-step conversions from numbers and vectors."""
+    from pine_amd import prl
+    ev = prl.evaluate
+    assert ev("Position() * 2.0") == "Node3f bin *"              # *(Node3f, Nodef): two conversions, unique
+    assert ev("2 * Position()") == "Node3f bin *" and ev("UV()[1]") == "Nodef comp"
+    assert ev("[0.9, 0.25, 0.2] * abs(Normal())[1] + [0.05, 0.05, 0.05]") == "Node3f bin +"
+    assert ev("lerp(Checkerboard(UV(), 0.95), 0.0, 0.4)") == "Nodef bin +"       # lerp(Nodef, Nodef, Nodef)
+    assert ev("lerp(Checkerboard(UV()), [1, 0, 0], [0, 0, 1])") == "Node3f bin +"  # lerp(Nodef, Node3f, Node3f)
+    assert ev("lerp(0.25, 2.0, 4.0)") == "f32 0x1.4p+1"                           # psl::lerp
+    assert ev("-fract(Position())") == "Node3f un -" and ev("Vec3(UV()[0], 0.5, 1)") == "Node3f tovec3"
+    assert ev("Glossy([1, 1, 1], 0.2)") == "Glossy " and ev("Metal(Normal(), 0.1)") == "Metal "
+    for bad, msg in [("UV()[3]", "0, 1, or 2"), ("Emissive(Position())", "constant colour"), ("Position() + 1.0", "is not found"),
+                     ("Checkerboard(0.5)", "is not found"), ("Metal([1,1,1])", "is not found")]:
+        with pytest.raises(prl.PrlError, match=msg):
+            ev(bad)
+
+
+def _classic(n, size, spp):
+    src = open(os.path.join(ROOT, "examples", "classic.pine")).read()
+    return src.replace("n := 100;", f"n := {n};").replace("size := [720, 360];", f"size := [{size[0]}, {size[1]}];").replace(
+        "BlueSampler(64)", f"BlueSampler({spp})").replace('scene.camera.film().save("classic.png");', "")
+
+
+def test_classic_script_with_loops_and_node_graphs_builds_a_valid_scene(oracle):
+    """examples/classic.pine: PRL for-loops place the cones, the floor is a node graph; the scene description
+    the front-end produces is accepted and rendered by the (reference-pinned) oracle."""
+    from pine_amd import prl
+    ps, spp, depth = prl.scene_of_dry_run(prl.interpret(_classic(6, (48, 24), 4), dry_run=True))
+    assert ps.count("shape cone ") == 36 and ps.count("\nnode ") == 20 and "material floor uber_n" in ps and (spp, depth) == (4, 6)
+    film, st = oracle.render(ps, (48, 24), spp, depth)
+    assert np.isfinite(film).all() and film[..., :3].mean() > 0.1
+    full = prl.scene_of_dry_run(prl.interpret(_classic(100, (720, 360), 64), dry_run=True))[0]
+    assert full.count("shape cone ") == 10000
+
+
+@pytest.mark.gpu
+def test_classic_script_render_equals_oracle(oracle):
+    from pine_amd import prl
+    src = _classic(10, (90, 45), 16)
+    ps, spp, depth = prl.scene_of_dry_run(prl.interpret(src, dry_run=True))
+    prl.interpret(src)
+    ref, _ = oracle.render(ps, (90, 45), spp, depth)
+    assert_bit_equal(prl.last_film(), ref, "classic.pine through the front-end vs oracle")
+
+
 def test_save_extension_rule_and_png_writer(tmp_path):
     """fileio.cpp:55-76: the extension is what follows the FIRST dot; unknown -> warning + '.png'."""
     from pine_amd import prl
