@@ -212,6 +212,8 @@ int pine_gpu_plan_read_samples(pine_gpu_plan*, float* out_host, int64_t capacity
 int pine_gpu_test_sampler(int device, int spp, float* out_host, int64_t capacity);  /* layout of oracle_sampler_stream */
 int pine_gpu_test_rng(int device, uint64_t* out_host, int64_t capacity);            /* layout of oracle_rng_stream */
 int pine_gpu_test_sincos(int device, const float* x_host, int64_t n, float* sin_out, float* cos_out);
+int pine_gpu_test_powlog(int device, const float* x_host, const float* y_host, int64_t n, float* pow_out,
+                         float* log_out);                                           /* powf(x, y), logf(x) */
 int pine_gpu_test_shapes(pine_gpu_scene*, int device, const float* rays_host, int64_t nrays,
                          float* out_host, int64_t capacity);                        /* layout of oracle_shapes */
 

@@ -715,7 +715,7 @@ PINE_HD float FrDielectric(float cosThetaI, float eta) {  // scattering.h:79-94
   return (sqr(rParl) + sqr(rPerp)) / 2.0f;
 }
 PINE_HD f3 FrSchlick(f3 F0, float cosTheta) {  // scattering.h:96-98 (powf: device libm, tolerance)
-  return F0 + (mk3(1.0f) - F0) * powf(1.0f - cosTheta, 5.0f);
+  return F0 + (mk3(1.0f) - F0) * ppow(1.0f - cosTheta, 5.0f);
 }
 struct TRDist {  // TrowbridgeReitzDistribution scattering.h:100-150
   float ax, ay;
@@ -792,7 +792,7 @@ PINE_HD f3 node_program_eval(const DNodeOp* ops, int start, f3 p, f3 n, f2 uv) {
       case N_POW: {
         sp--;
         const f3 a = st[sp - 1], b = st[sp];
-        st[sp - 1] = f3{powf(a.x, b.x), powf(a.y, b.y), powf(a.z, b.z)};
+        st[sp - 1] = f3{ppow(a.x, b.x), ppow(a.y, b.y), ppow(a.z, b.z)};
         break;
       }
       case N_NEG: st[sp - 1] = -st[sp - 1]; break;

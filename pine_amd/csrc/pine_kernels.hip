@@ -713,7 +713,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               h = shape_intersect<F>(shape, wr);
             }
             if (!h) break;  // sample_p returns nullopt: nothing changes
-            const float t = -logf(1 - sampler_get1d<true>(T, sampler)) * sigma_t_inv;
+            const float t = -plog(1 - sampler_get1d<true>(T, sampler)) * sigma_t_inv;
             if (wr.tmax < t) {
               beta_channel = channel + 1;
               it.p = sit.p;
@@ -963,6 +963,13 @@ __global__ void test_sincos_kernel(const float* x, long long n, float* s, float*
   if (i < n) {
     s[i] = psin(x[i]);
     c[i] = pcos(x[i]);
+  }
+}
+__global__ void test_powlog_kernel(const float* x, const float* y, long long n, float* p, float* l) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) {
+    p[i] = ppow(x[i], y[i]);
+    l[i] = plog(x[i]);
   }
 }
 __constant__ int kTestPixels[6][2] = {{0, 0}, {1, 0}, {3, 5}, {127, 127}, {128, 5}, {639, 639}};
@@ -1669,6 +1676,24 @@ int pine_gpu_test_sincos(int device, const float* x, int64_t n, float* s, float*
   hipFree(dx);
   hipFree(ds);
   hipFree(dc);
+  return 0;
+}
+int pine_gpu_test_powlog(int device, const float* x, const float* y, int64_t n, float* pw, float* lg) {
+  if (need_device(device)) return -1;
+  float *dx, *dy, *dp, *dl;
+  HIP_OK(hipMalloc((void**)&dx, n * 4));
+  HIP_OK(hipMalloc((void**)&dy, n * 4));
+  HIP_OK(hipMalloc((void**)&dp, n * 4));
+  HIP_OK(hipMalloc((void**)&dl, n * 4));
+  HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(test_powlog_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, 0, dx, dy, (long long)n, dp, dl);
+  HIP_OK(hipMemcpy(pw, dp, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(lg, dl, n * 4, hipMemcpyDeviceToHost));
+  hipFree(dx);
+  hipFree(dy);
+  hipFree(dp);
+  hipFree(dl);
   return 0;
 }
 int pine_gpu_test_sampler(int device, int spp_req, float* out, int64_t capacity) {

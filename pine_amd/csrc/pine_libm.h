@@ -152,4 +152,224 @@ PINE_HD void sincosf_glibc(float y, float& sn, float& cs) {
   cs = sin_poly(xs, x2, n ^ 1, csign);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// powf / logf exactly as the host libm computes them (glibc 2.35 e_powf.c / e_logf.c = the ARM
+// "optimized routines" algorithms: a 16-entry table of (1/c, log c) per mantissa interval, a short
+// polynomial in binary64, exp2 through a 32-entry table, ONE rounding to binary32 at the end).
+// Needed because FrSchlick (scattering.h:91-93) and NodeBinary '^' go through psl::pow = std::pow and
+// the BSSRDF free flight through log (bxdf.cpp:343): with the device's own powf / logf (within 1 ulp
+// of glibc, not identical) films with microfacet lobes differ from the reference in a few pixels.
+// Algorithm restated; the numeric tables are the published ones (sysdeps/ieee754/flt-32/e_powf_log2_data.c,
+// e_logf_data.c, e_exp2f_data.c), checked against the copy inside the container's libm.so.6.  As for
+// sinf/cosf, every a*b+c is a fused multiply-add because x86-64 glibc runs its -mfma build.
+// tools/check_libm.cpp: 0 mismatches against the container's libm over every float x in [0, 1] with
+// y = 5 (Schlick), 2^31 positive floats for logf and 10^9 random (x, y) pairs.
+// The tables are switch statements (immediates), not arrays: no memory traffic, no static data on the device.
+PINE_HD uint64_t asuint64(double d) {
+  uint64_t u;
+  memcpy(&u, &d, 8);
+  return u;
+}
+PINE_HD double asdouble(uint64_t u) {
+  double d;
+  memcpy(&d, &u, 8);
+  return d;
+}
+PINE_HD float asfloat(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+PINE_HD uint64_t exp2f_tab(unsigned i) {
+  switch (i) {
+    case 0: return 0x3ff0000000000000ull;
+    case 1: return 0x3fefd9b0d3158574ull;
+    case 2: return 0x3fefb5586cf9890full;
+    case 3: return 0x3fef9301d0125b51ull;
+    case 4: return 0x3fef72b83c7d517bull;
+    case 5: return 0x3fef54873168b9aaull;
+    case 6: return 0x3fef387a6e756238ull;
+    case 7: return 0x3fef1e9df51fdee1ull;
+    case 8: return 0x3fef06fe0a31b715ull;
+    case 9: return 0x3feef1a7373aa9cbull;
+    case 10: return 0x3feedea64c123422ull;
+    case 11: return 0x3feece086061892dull;
+    case 12: return 0x3feebfdad5362a27ull;
+    case 13: return 0x3feeb42b569d4f82ull;
+    case 14: return 0x3feeab07dd485429ull;
+    case 15: return 0x3feea47eb03a5585ull;
+    case 16: return 0x3feea09e667f3bcdull;
+    case 17: return 0x3fee9f75e8ec5f74ull;
+    case 18: return 0x3feea11473eb0187ull;
+    case 19: return 0x3feea589994cce13ull;
+    case 20: return 0x3feeace5422aa0dbull;
+    case 21: return 0x3feeb737b0cdc5e5ull;
+    case 22: return 0x3feec49182a3f090ull;
+    case 23: return 0x3feed503b23e255dull;
+    case 24: return 0x3feee89f995ad3adull;
+    case 25: return 0x3feeff76f2fb5e47ull;
+    case 26: return 0x3fef199bdd85529cull;
+    case 27: return 0x3fef3720dcef9069ull;
+    case 28: return 0x3fef5818dcfba487ull;
+    case 29: return 0x3fef7c97337b9b5full;
+    case 30: return 0x3fefa4afa2a490daull;
+    default: return 0x3fefd0765b6e4540ull;
+  }
+}
+PINE_HD void powf_log2_tab(unsigned i, double& invc, double& logc) {
+  switch (i) {
+    case 0: invc = 0x1.661ec79f8f3bep+0; logc = -0x1.efec65b963019p-2; break;
+    case 1: invc = 0x1.571ed4aaf883dp+0; logc = -0x1.b0b6832d4fca4p-2; break;
+    case 2: invc = 0x1.49539f0f010b0p+0; logc = -0x1.7418b0a1fb77bp-2; break;
+    case 3: invc = 0x1.3c995b0b80385p+0; logc = -0x1.39de91a6dcf7bp-2; break;
+    case 4: invc = 0x1.30d190c8864a5p+0; logc = -0x1.01d9bf3f2b631p-2; break;
+    case 5: invc = 0x1.25e227b0b8ea0p+0; logc = -0x1.97c1d1b3b7af0p-3; break;
+    case 6: invc = 0x1.1bb4a4a1a343fp+0; logc = -0x1.2f9e393af3c9fp-3; break;
+    case 7: invc = 0x1.12358f08ae5bap+0; logc = -0x1.960cbbf788d5cp-4; break;
+    case 8: invc = 0x1.0953f419900a7p+0; logc = -0x1.a6f9db6475fcep-5; break;
+    case 9: invc = 0x1.0000000000000p+0; logc = 0x0p+0; break;
+    case 10: invc = 0x1.e608cfd9a47acp-1; logc = 0x1.338ca9f24f53dp-4; break;
+    case 11: invc = 0x1.ca4b31f026aa0p-1; logc = 0x1.476a9543891bap-3; break;
+    case 12: invc = 0x1.b2036576afce6p-1; logc = 0x1.e840b4ac4e4d2p-3; break;
+    case 13: invc = 0x1.9c2d163a1aa2dp-1; logc = 0x1.40645f0c6651cp-2; break;
+    case 14: invc = 0x1.886e6037841edp-1; logc = 0x1.88e9c2c1b9ff8p-2; break;
+    default: invc = 0x1.767dcf5534862p-1; logc = 0x1.ce0a44eb17bccp-2; break;
+  }
+}
+PINE_HD void logf_tab(unsigned i, double& invc, double& logc) {
+  switch (i) {
+    case 0: invc = 0x1.661ec79f8f3bep+0; logc = -0x1.57bf7808caadep-2; break;
+    case 1: invc = 0x1.571ed4aaf883dp+0; logc = -0x1.2bef0a7c06ddbp-2; break;
+    case 2: invc = 0x1.49539f0f010b0p+0; logc = -0x1.01eae7f513a67p-2; break;
+    case 3: invc = 0x1.3c995b0b80385p+0; logc = -0x1.b31d8a68224e9p-3; break;
+    case 4: invc = 0x1.30d190c8864a5p+0; logc = -0x1.6574f0ac07758p-3; break;
+    case 5: invc = 0x1.25e227b0b8ea0p+0; logc = -0x1.1aa2bc79c8100p-3; break;
+    case 6: invc = 0x1.1bb4a4a1a343fp+0; logc = -0x1.a4e76ce8c0e5ep-4; break;
+    case 7: invc = 0x1.12358f08ae5bap+0; logc = -0x1.1973c5a611cccp-4; break;
+    case 8: invc = 0x1.0953f419900a7p+0; logc = -0x1.252f438e10c1ep-5; break;
+    case 9: invc = 0x1.0000000000000p+0; logc = 0x0p+0; break;
+    case 10: invc = 0x1.e608cfd9a47acp-1; logc = 0x1.aa5aa5df25984p-5; break;
+    case 11: invc = 0x1.ca4b31f026aa0p-1; logc = 0x1.c5e53aa362eb4p-4; break;
+    case 12: invc = 0x1.b2036576afce6p-1; logc = 0x1.526e57720db08p-3; break;
+    case 13: invc = 0x1.9c2d163a1aa2dp-1; logc = 0x1.bc2860d224770p-3; break;
+    case 14: invc = 0x1.886e6037841edp-1; logc = 0x1.1058bc8a07ee1p-2; break;
+    default: invc = 0x1.767dcf5534862p-1; logc = 0x1.4043057b6ee09p-2; break;
+  }
+}
+PINE_HD double powf_log2_inline(uint32_t ix) {  // e_powf.c log2_inline; |relative error| < 2^-68
+  const uint32_t tmp = ix - 0x3f330000u;
+  const unsigned i = (tmp >> (23 - 4)) % 16;
+  const uint32_t top = tmp & 0xff800000u;
+  const uint32_t iz = ix - top;
+  const int k = int32_t(top) >> 23;  // arithmetic shift
+  double invc, logc;
+  powf_log2_tab(i, invc, logc);
+  const double z = double(asfloat(iz));
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double y0 = logc + double(k);
+  const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2, A3 = -0x1.7154748bef6c8p-1,
+               A4 = 0x1.71547652ab82bp0;
+  const double r2 = r * r;
+  double y = __builtin_fma(A0, r, A1);
+  const double p = __builtin_fma(A2, r, A3);
+  const double r4 = r2 * r2;
+  double q = __builtin_fma(A4, r, y0);
+  q = __builtin_fma(p, r2, q);
+  y = __builtin_fma(y, r4, q);
+  return y;
+}
+PINE_HD float powf_exp2_inline(double xd, uint32_t sign_bias) {  // e_powf.c exp2_inline (no TOINT intrinsics)
+  const double shift = 0x1.8p+47;  // 0x1.8p52 / 32
+  double kd = xd + shift;
+  const uint64_t ki = asuint64(kd);
+  kd -= shift;
+  const double r = xd - kd;
+  uint64_t t = exp2f_tab(unsigned(ki % 32));
+  const uint64_t ski = ki + sign_bias;
+  t += ski << (52 - 5);
+  const double s = asdouble(t);
+  const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+  const double z = __builtin_fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = __builtin_fma(C2, r, 1.0);
+  y = __builtin_fma(z, r2, y);
+  y = y * s;
+  return float(y);
+}
+PINE_HD int powf_checkint(uint32_t iy) {  // 0: not an integer, 1: odd, 2: even
+  const int e = int(iy >> 23 & 0xff);
+  if (e < 0x7f) return 0;
+  if (e > 0x7f + 23) return 2;
+  if (iy & ((1u << (0x7f + 23 - e)) - 1)) return 0;
+  if (iy & (1u << (0x7f + 23 - e))) return 1;
+  return 2;
+}
+PINE_HD bool powf_zeroinfnan(uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000u - 1; }
+PINE_HD float powf_glibc(float x, float y) {
+  uint32_t sign_bias = 0;
+  uint32_t ix = asuint(x);
+  const uint32_t iy = asuint(y);
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) {
+    // x < 0x1p-126 or inf or nan, or y is 0 or inf or nan
+    if (powf_zeroinfnan(iy)) {
+      if (2 * iy == 0) return 1.0f;
+      if (ix == 0x3f800000u) return 1.0f;
+      if (2 * ix > 2u * 0x7f800000u || 2 * iy > 2u * 0x7f800000u) return x + y;
+      if (2 * ix == 2 * 0x3f800000u) return 1.0f;
+      if ((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;  // |x|<1 && y==inf or |x|>1 && y==-inf
+      return y * y;
+    }
+    if (powf_zeroinfnan(ix)) {
+      float x2 = x * x;
+      if ((ix & 0x80000000u) && powf_checkint(iy) == 1) x2 = -x2;
+      return (iy & 0x80000000u) ? 1 / x2 : x2;
+    }
+    if (ix & 0x80000000u) {  // finite x < 0
+      const int yint = powf_checkint(iy);
+      if (yint == 0) return (x - x) / (x - x);  // NaN (__math_invalidf)
+      if (yint == 1) sign_bias = 1u << (5 + 11);
+      ix &= 0x7fffffffu;
+    }
+    if (ix < 0x00800000u) {  // subnormal x: normalise
+      ix = asuint(x * 0x1p23f);
+      ix &= 0x7fffffffu;
+      ix -= 23u << 23;
+    }
+  }
+  const double logx = powf_log2_inline(ix);
+  const double ylogx = double(y) * logx;  // cannot overflow
+  if ((asuint64(ylogx) >> 47 & 0xffff) >= asuint64(126.0) >> 47) {  // |y*log2(x)| >= 126
+    if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -__builtin_inff() : __builtin_inff();
+    if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;
+  }
+  return powf_exp2_inline(ylogx, sign_bias);
+}
+PINE_HD float logf_glibc(float x) {  // e_logf.c
+  uint32_t ix = asuint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2 == 0) return -__builtin_inff();          // log(+-0) = -inf
+    if (ix == 0x7f800000u) return x;                    // log(inf) = inf
+    if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return (x - x) / (x - x);  // negative or nan
+    ix = asuint(x * 0x1p23f);  // subnormal: normalise
+    ix -= 23u << 23;
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const unsigned i = (tmp >> (23 - 4)) % 16;
+  const int k = int32_t(tmp) >> 23;
+  const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+  double invc, logc;
+  logf_tab(i, invc, logc);
+  const double z = double(asfloat(iz));
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double y0 = __builtin_fma(double(k), 0x1.62e42fefa39efp-1, logc);
+  const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  const double r2 = r * r;
+  double y = __builtin_fma(A1, r, A2);
+  y = __builtin_fma(A0, r2, y);
+  y = __builtin_fma(y, r2, y0 + r);
+  return float(y);
+}
+
 }  // namespace pine_libm

@@ -64,6 +64,9 @@ PINE_HD float pcos(float v) { return __cosf(v); }
 PINE_HD float psin(float v) { return pine_libm::sinf_glibc(v); }
 PINE_HD float pcos(float v) { return pine_libm::cosf_glibc(v); }
 #endif
+// libm-exact pow / log (pine_libm.h): psl::pow == std::pow (src/psl/math.h:201-202), psl::log == std::log
+PINE_HD float ppow(float a, float b) { return pine_libm::powf_glibc(a, b); }
+PINE_HD float plog(float v) { return pine_libm::logf_glibc(v); }
 PINE_HD void psincos(float v, float& sn, float& cs) {
 #ifdef PINE_ABL_SINCOS
   sn = psin(v);

@@ -398,7 +398,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                 hh = shape_intersect<F>(shape, wr);
               }
               if (!hh) break;
-              const float t = -logf(1 - sampler_get1d<true>(T, sampler)) * sigma_t_inv;
+              const float t = -plog(1 - sampler_get1d<true>(T, sampler)) * sigma_t_inv;
               if (wr.tmax < t) {
                 beta_channel = channel + 1;
                 it.p = sit.p;

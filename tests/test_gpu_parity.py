@@ -59,6 +59,27 @@ def test_device_sincos_equals_host_libm():
     assert_bit_equal(c, hc, "device cosf vs libm")
 
 
+def test_device_powf_logf_equal_host_libm():
+    """FrSchlick's pow, the node '^' and the BSSRDF free flight's log on the device == glibc's, bit for bit."""
+    from pine_amd import _lib
+    libm = C.CDLL("libm.so.6")
+    libm.powf.restype = libm.logf.restype = C.c_float
+    libm.powf.argtypes = [C.c_float, C.c_float]
+    libm.logf.argtypes = [C.c_float]
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0, 1, 150000), rng.uniform(0, 50, 50000), 10.0 ** rng.uniform(-30, 30, 50000),
+                        np.float32([0.0, 1.0, 0.5, 2.0, 1e-40, 3.0])]).astype(np.float32)
+    y = np.concatenate([np.full(100000, 5.0), rng.uniform(-8, 8, 150000), np.float32([0.0, 5.0, 5.0, 0.5, 2.0, -1.5])]).astype(np.float32)
+    p = np.zeros_like(x)
+    lg = np.zeros_like(x)
+    _lib.check(_lib.lib.pine_gpu_test_powlog(0, x.ctypes.data_as(_lib.c_f_p), y.ctypes.data_as(_lib.c_f_p), x.size,
+                                             p.ctypes.data_as(_lib.c_f_p), lg.ctypes.data_as(_lib.c_f_p)))
+    hp = np.float32([libm.powf(float(a), float(b)) for a, b in zip(x, y)])
+    hl = np.float32([libm.logf(float(a)) for a in x])
+    assert_bit_equal(p, hp, "device powf vs libm")
+    assert_bit_equal(lg, hl, "device logf vs libm")
+
+
 @pytest.mark.parametrize("spp", [1, 16, 256])
 def test_device_sampler_stream(spp):
     from pine_amd import _lib
@@ -107,7 +128,7 @@ def _render(scene, spp, depth, **kw):
     return out, st
 
 
-LIBM_TOLERANCE_FILMS = {"mats_zoo_64_s32_d6"}
+LIBM_TOLERANCE_FILMS = set()  # (was {"mats_zoo_64_s32_d6"} until powf/logf became glibc-exact on the device)
 
 
 def _scene_for(name):

@@ -13,3 +13,15 @@ def test_sincos_match_host_libm(tmp_path):
     out = subprocess.run([str(exe), "61"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert '"sin_mismatch": 0' in out.stdout and '"cos_mismatch": 0' in out.stdout
+
+
+def test_powf_logf_match_host_libm(tmp_path):
+    """powf over every float in [0, 1] x {5, 2.5, 0.5} (Schlick), logf over all 2^31 positive floats, special
+    values, and a few million random pairs (tools/check_libm_pow.cpp runs 10^9 of them)."""
+    exe = tmp_path / "check_libm_pow"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-pthread",
+                           os.path.join(ROOT, "tools", "check_libm_pow.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "20000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    for k in ("schlick_mismatch", "logf_mismatch", "pair_mismatch", "special_mismatch"):
+        assert f'"{k}": 0' in out.stdout
