@@ -261,27 +261,30 @@ PINE_HD bool box_hit_oct(const float* lo, const float* hi, const DRayOct& r, flo
   return tmin <= tmax;
 }
 // AABB::intersect(o, d, tmin&, tmax&) bbox.cpp:94-111 (also the body of AABB::hit(Ray) :75-93)
+// Straight-line form (selects instead of the reference's early returns): in a wave some lane almost
+// always needs every step, so the early exits only added exec-mask bookkeeping and branch latency.
+// The decisions are the same comparisons on the same values; after a failed axis tmin / tmax are
+// dead in every caller (they return false at once).
 PINE_HD bool box_slabs(f3 lo, f3 hi, f3 o, f3 d, float& tmin, float& tmax) {
+  bool ok = true;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const float di = get(d, i), oi = get(o, i), l = get(lo, i), h = get(hi, i);
-    if (pabs(di) < 1e-6f) {
-      if (oi < l || oi > h) return false;
-      continue;
-    }
-    const float inv_d = prcp(di);
+    const bool parallel = pabs(di) < 1e-6f;
+    const float inv_d = prcp(di);  // (unused when parallel)
     float t_near = (l - oi) * inv_d;
     float t_far = (h - oi) * inv_d;
-    if (inv_d < 0.0f) {
-      const float t = t_far;
-      t_far = t_near;
-      t_near = t;
-    }
-    tmin = pmax(t_near, tmin);
-    tmax = pmin(t_far, tmax);
-    if (tmin > tmax) return false;
+    const bool neg = inv_d < 0.0f;
+    const float tn = neg ? t_far : t_near;
+    const float tf = neg ? t_near : t_far;
+    const float ntmin = pmax(tn, tmin);
+    const float ntmax = pmin(tf, tmax);
+    const bool axis_ok = parallel ? !(oi < l || oi > h) : !(ntmin > ntmax);
+    ok = ok & axis_ok;
+    tmin = parallel ? tmin : ntmin;
+    tmax = parallel ? tmax : ntmax;
   }
-  return true;
+  return ok;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -316,27 +319,22 @@ PINE_HD float sphere_compute_t(f3 ro, f3 rd, float tmin, f3 p, float r) {  // ge
 
 // Rect::hit / Rect::intersect share the plane + extent test (geometry.cpp:275-299)
 PINE_HD bool rect_test(const float* f, const DRay& ray, float& t_out) {
+  // Straight-line form of the reference's chain of early returns (same comparisons, same values,
+  // combined with & instead of branches): with 64 rays per wave some lane needs every step, so the
+  // exits only cost exec-mask bookkeeping and seven dependent branch points per test.
   const f3 position = ld3(f), n = ld3(f + 9);
   const float denom = dot(ray.d, n);
-  if (denom == 0.0f) return false;
   const float num = dot(position - ray.o, n);
-  // Exact shortcuts that spare the 11-instruction IEEE division for planes that cannot be hit:
-  //  * every ray on this path has tmin == 0, so a quotient that is negative or zero fails
-  //    `t <= tmin`: decided by the operands' signs alone (NaNs fall through to the division);
-  //  * |num| > |denom| * tmax * (1 + 2^-20) implies the rounded quotient is >= tmax.
-  if (ray.tmin == 0.0f) {
-    if (num == 0.0f || (num < 0.0f && denom > 0.0f) || (num > 0.0f && denom < 0.0f)) return false;
-    if (pabs(num) > pabs(denom) * ray.tmax * 1.00000095367431640625f) return false;
-  }
+  bool ok = !(denom == 0.0f);
   const float t = num / denom;
-  if (t <= ray.tmin || t >= ray.tmax) return false;
+  ok = ok & !(t <= ray.tmin || t >= ray.tmax);
   const f3 p = ray_at(ray, t) - position;
   const float u = dot(p, ld3(f + 14));
-  if (u < -0.5f || u > 0.5f) return false;
+  ok = ok & !(u < -0.5f || u > 0.5f);
   const float v = dot(p, ld3(f + 17));
-  if (v < -0.5f || v > 0.5f) return false;
+  ok = ok & !(v < -0.5f || v > 0.5f);
   t_out = t;
-  return true;
+  return ok;
 }
 // OBB: ray into object space with a re-normalised direction but WORLD tmin/tmax (bbox.cpp:145-163)
 PINE_HD void obb_local_ray(const float* f, f3 o, f3 d, f3& lo_o, f3& lo_d) {
