@@ -167,14 +167,11 @@ PINE_HD f2 sample_disk_polar(f2 u) {
 }
 PINE_HD f2 sample_disk_concentric(f2 u) {
   u = f2{u.x * 2 - 1.0f, u.y * 2 - 1.0f};
-  float theta, r;
-  if (pabs(u.x) > pabs(u.y)) {
-    r = u.x;
-    theta = kPi / 4.0f * u.y / u.x;
-  } else {
-    r = u.y;
-    theta = kPi / 2.0f - kPi / 4.0f * (u.x / u.y);
-  }
+  // (one division for both branches of sampling.h:30-36: (Pi/4 * u.y) / u.x  or  Pi/2 - Pi/4 * (u.x / u.y))
+  const bool wide = pabs(u.x) > pabs(u.y);
+  const float r = wide ? u.x : u.y;
+  const float q = (wide ? kPi / 4.0f * u.y : u.x) / (wide ? u.x : u.y);
+  const float theta = wide ? q : kPi / 2.0f - kPi / 4.0f * q;
   float sn, cs;
   psincos(theta, sn, cs);
   return r * f2{cs, sn};

@@ -194,10 +194,9 @@ PINE_HD m3 transpose(const m3& m) {
   return {f3{m.x.x, m.y.x, m.z.x}, f3{m.x.y, m.y.y, m.z.y}, f3{m.x.z, m.y.z, m.z.z}};
 }
 PINE_HD void coordinate_system(f3 n, f3& t, f3& b) {  // vecmath.h:1182-1188
-  if (pabs(n.x) > pabs(n.y))
-    t = normalize(cross(n, mk3(0, 1, 0)));
-  else
-    t = normalize(cross(n, mk3(1, 0, 0)));
+  // (the axis is selected first, so that the cross product + normalize run once: same operations on the same values)
+  const bool along_y = pabs(n.x) > pabs(n.y);
+  t = normalize(cross(n, f3{along_y ? 0.0f : 1.0f, along_y ? 1.0f : 0.0f, 0.0f}));
   b = cross(n, t);
 }
 PINE_HD m3 coordinate_system(f3 n) {  // :1190-1195
