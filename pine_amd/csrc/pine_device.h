@@ -425,9 +425,11 @@ PINE_HD bool shape_intersect(int kind, const DShape* S, DRay& ray) {
       const m34 m = ld34(f + 6);
       const f3 ps = o + tmin * d;
       const f3 pe = o + tmax * d;
-      tmin = distance(mul_point(m, ps), ray.o);
-      tmax = distance(mul_point(m, pe), ray.o);
-      ray.tmax = tmin > ray.tmin ? tmin : tmax;
+      // bbox.cpp:166-171 maps both endpoints back; the far one is only read when the near distance is not
+      // beyond tmin (origin on or inside the box): compute it on demand, the values are the same
+      float tw = distance(mul_point(m, ps), ray.o);
+      if (__builtin_expect(!(tw > ray.tmin), 0)) tw = distance(mul_point(m, pe), ray.o);
+      ray.tmax = tw;
       return true;
     }
     case SHAPE_SPHERE: if constexpr (!(F & F_SPHERE)) __builtin_unreachable(); else {  // geometry.cpp:88-93
