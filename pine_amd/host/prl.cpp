@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -666,6 +667,10 @@ struct Interp {
   std::string out;
   int flags = 0, device = 0;
   std::shared_ptr<struct FilmObj> last_film;
+  // A tree-walking interpreter is ~1000x slower than the reference's JIT on arithmetic loops
+  // (scenes/benchmark.pine would run for hours): scripts get a budget of evaluated nodes
+  // (PINE_PRL_MAX_STEPS, default 4e8 ~ half a minute) instead of hanging the host.
+  unsigned long long steps = 0, max_steps = 400000000ull;
 
   Interp();
   [[noreturn]] void error(const Node& n, const std::string& m) const { fail(std::to_string(n.line) + ":" + std::to_string(n.col) + ": " + m); }
@@ -751,6 +756,7 @@ struct Interp {
   }
 
   Cell eval(const NodeP& n) {
+    if (++steps > max_steps) error(*n, "script exceeded the interpreter's step budget (PINE_PRL_MAX_STEPS)");
     switch (n->kind) {
       case Node::Num:
         if (n->text.find('.') != std::string::npos) return cell(mk_f32(psl_stof(n->text)));
@@ -1736,6 +1742,7 @@ int pine_prl_interpret(const char* source, int flags, int device) {
     prl::Interp in;
     in.flags = flags;
     in.device = device;
+    if (const char* ms = getenv("PINE_PRL_MAX_STEPS")) in.max_steps = strtoull(ms, nullptr, 10);
     try {
       for (auto& k : program->kids) in.exec(k);  // top level: no new scope (the program IS the outermost block)
     } catch (prl::BreakSignal&) {

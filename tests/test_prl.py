@@ -202,6 +202,13 @@ def test_classic_script_render_equals_oracle(oracle):
     assert_bit_equal(prl.last_film(), ref, "classic.pine through the front-end vs oracle")
 
 
+def test_runaway_scripts_hit_the_step_budget(monkeypatch):
+    from pine_amd import prl
+    monkeypatch.setenv("PINE_PRL_MAX_STEPS", "200000")
+    with pytest.raises(prl.PrlError, match="step budget"):
+        prl.interpret("x := 0; while true { x += 1; }", dry_run=True)
+
+
 def test_save_extension_rule_and_png_writer(tmp_path):
     """fileio.cpp:55-76: the extension is what follows the FIRST dot; unknown -> warning + '.png'."""
     from pine_amd import prl
