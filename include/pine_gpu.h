@@ -67,6 +67,18 @@ int pine_gpu_scene_add_material_subsurface(pine_gpu_scene*, const char* name, co
 int pine_gpu_scene_find_material(pine_gpu_scene*, const char* name);
                                          /* Scene::find_material src/pine/core/scene.cpp:49-54 */
 
+/* scene.add(Light) / scene.set(EnvironmentLight): Scene::add_light, set_env_light src/pine/core/scene.cpp:29-46.
+ * PointLight / SpotLight / DirectionalLight (delta lights: sampled without MIS, path.cpp:104-106) and
+ * the Sky environment light (added to radiance on a miss, path.cpp:75-81; sampled uniformly over the
+ * sphere): src/pine/core/light.h:21-67, light.cpp:11-84.  Lights enter the light sampler's list in
+ * add order together with the area lights of emissive geometry; the environment light comes last
+ * (lightsampler.cpp:6-10).  Atmosphere and ImageSky are not supported. */
+int pine_gpu_scene_add_light_point(pine_gpu_scene*, const float position[3], const float color[3]);
+int pine_gpu_scene_add_light_spot(pine_gpu_scene*, const float position[3], const float direction[3],
+                                  const float color[3], float falloff_radian, float cutoff_additional_radian);
+int pine_gpu_scene_add_light_directional(pine_gpu_scene*, const float direction[3], const float color[3]);
+int pine_gpu_scene_set_env_sky(pine_gpu_scene*, const float sun_color[3]);
+
 /* Shading nodes (Nodef / Node3f: src/pine/core/node.h:13-297, registered node.cpp:29-116).  A node
  * lives in the scene's node table; each call returns its id (or < 0).  Supported: constants, the
  * surface inputs Position / Normal / UV, NodeBinary (+ - * / ^), NodeUnary (- abs sqr sqrt fract),

@@ -1747,7 +1747,17 @@ struct Scene {
   std::vector<Material> materials;
   std::vector<std::string> material_names;
   std::vector<Geometry> geometries;
-  std::vector<int> lights;  // geometry indices of emissive geometry, in add order (scene.cpp:16-22)
+  // Scene::lights in add order (scene.cpp:16-33): an AreaLight per emissive geometry, explicit Point /
+  // Spot / Directional lights; UniformLightSampler::build appends the environment light (lightsampler.cpp:6-10)
+  struct Light {
+    enum Kind { Area, Point, Spot, Directional, Sky } kind = Area;
+    int geom = -1;
+    vec3 position, direction, color;
+    float falloff_cos = 0, cutoff_cos = 0;
+    bool is_delta() const { return kind == Point || kind == Spot || kind == Directional; }  // light.h:111-113
+  };
+  std::vector<Light> lights;
+  bool has_env = false;  // the LAST entry of `lights` is the environment light
   Camera camera;
   // accel (BVH::build bvh.cpp:453-495)
   std::vector<std::shared_ptr<BVHImpl>> lbvh;
@@ -1890,17 +1900,55 @@ struct Integrator {
     if (N == 0) return false;
     u1 *= N;
     int index = int(u1);
-    const Geometry& g = scene->geometries[scene->lights[index]];
-    ShapeSample gs;
-    if (!g.sample(p, u2, u1 - index, gs)) return false;
-    ls.wo = gs.w;
-    ls.pdf = gs.pdf;
-    ls.distance = gs.distance;
-    ls.le = material_le(scene->materials[g.material], gs.n, -ls.wo);
-    if (ls.le.is_zero()) return false;
+    const Scene::Light& L = scene->lights[index];
+    switch (L.kind) {
+      case Scene::Light::Area: {
+        const Geometry& g = scene->geometries[L.geom];
+        ShapeSample gs;
+        if (!g.sample(p, u2, u1 - index, gs)) return false;
+        ls.wo = gs.w;
+        ls.pdf = gs.pdf;
+        ls.distance = gs.distance;
+        ls.le = material_le(scene->materials[g.material], gs.n, -ls.wo);
+        if (ls.le.is_zero()) return false;
+        break;
+      }
+      case Scene::Light::Point:  // light.cpp:11-17
+        ls.wo = normalize(L.position - p, ls.distance);
+        ls.pdf = ls.distance * ls.distance;
+        ls.le = L.color;
+        break;
+      case Scene::Light::Spot: {  // light.cpp:35-47
+        ls.wo = normalize(L.position - p, ls.distance);
+        const float cs = -dot(ls.wo, L.direction);
+        if (cs > L.falloff_cos) ls.le = L.color;
+        else if (cs > L.cutoff_cos) ls.le = L.color * (cs - L.cutoff_cos) / (L.falloff_cos - L.cutoff_cos);
+        else return false;
+        ls.pdf = ls.distance * ls.distance;
+        break;
+      }
+      case Scene::Light::Directional:  // light.cpp:48-54
+        ls.distance = 1e+10f;
+        ls.wo = L.direction;
+        ls.pdf = 1.0f;
+        ls.le = L.color;
+        break;
+      case Scene::Light::Sky:  // light.cpp:71-84
+        ls.wo = uniform_sphere(u2);
+        ls.pdf = 1 / (4 * Pi);
+        ls.distance = kFloatMax;
+        ls.le = sky_color_of(L.color, ls.wo);
+        break;
+    }
     ls.pdf = ls.pdf / N;
-    ls.is_delta = false;
+    ls.is_delta = L.is_delta();
     return true;
+  }
+  static vec3 sky_color_of(vec3 sun_color, vec3 wo) {  // Sky::color light.cpp:71-73, sky_color color.cpp:100-103
+    const float t = wo.y / 2 + 0.7f;
+    const vec3 a(1.0f, 0.8f, 0.6f), b(0.6f, 0.8f, 1.0f);
+    const vec3 l = a * (1 - t) + b * t;  // psl::lerp(t, a, b) math.h
+    return sun_color * (l * l);
   }
 
   // BSSRDF::sample_p (bxdf.cpp:329-353) + BXDF::sample_p (:375-382)
@@ -1946,7 +1994,17 @@ struct Integrator {
     bool hit = scene->intersect(ray, it);
     if (hit) it.compute_transformation();  // integrator.cpp:36-41
     // medium block (path.cpp:50-72) is dead: no mediums.  Tr == vec3(1) (integrator.cpp:75-81)
-    if (!hit) return result;  // no env light (path.cpp:75-81)
+    if (!hit) {  // path.cpp:75-81
+      if (scene->has_env) {
+        const Scene::Light& env = scene->lights.back();
+        Lo += vec3(1.0f) * sky_color_of(env.color, ray.d);
+        if (!pv.is_delta) {
+          result.has_light_pdf = true;
+          result.light_pdf = 1 / (4 * Pi);  // Sky::pdf, NOT divided by the light count
+        }
+      }
+      return result;
+    }
 
     const Geometry& g = scene->geometries[it.geom];
     const Material& mat = scene->materials[g.material];
@@ -2044,8 +2102,12 @@ struct Integrator {
           vec3 tr(1.0f);
           vec3 wo = it.to_local(ls.wo);
           vec3 f = bxdf.f(wo);
-          float mis = balance_heuristic(ls.pdf, bxdf.pdf(wo));
-          lo += ls.le * tr * cosine * f / ls.pdf * mis;
+          if (ls.is_delta) {  // path.cpp:104-106
+            lo += ls.le * tr * cosine * f / ls.pdf;
+          } else {
+            float mis = balance_heuristic(ls.pdf, bxdf.pdf(wo));
+            lo += ls.le * tr * cosine * f / ls.pdf * mis;
+          }
         }
       }
     }
@@ -2218,8 +2280,52 @@ bool parse_pscene(const char* text, Scene& scene) {
         return false;
       }
       scene.geometries.push_back(g);
-      if (scene.materials[g.material].kind == M_EMISSIVE)
-        scene.lights.push_back(int(scene.geometries.size()) - 1);
+      if (scene.materials[g.material].kind == M_EMISSIVE) {
+        Scene::Light L;
+        L.kind = Scene::Light::Area;
+        L.geom = int(scene.geometries.size()) - 1;
+        if (scene.has_env) scene.lights.insert(scene.lights.end() - 1, L);
+        else scene.lights.push_back(L);
+      }
+    } else if (kw == "light") {  // light point|spot|directional ... (user-level ctor arguments)
+      std::string kind;
+      in >> kind;
+      Scene::Light L;
+      if (kind == "point") {
+        L.kind = Scene::Light::Point;
+        L.position = rd3(in);
+        L.color = rd3(in);
+      } else if (kind == "spot") {  // SpotLight ctor light.cpp:18-34
+        L.kind = Scene::Light::Spot;
+        L.position = rd3(in);
+        L.direction = normalize(rd3(in));
+        L.color = rd3(in);
+        const float falloff = rdf(in), extra = rdf(in);
+        L.falloff_cos = std::cos(falloff);
+        L.cutoff_cos = std::cos(falloff + extra);
+      } else if (kind == "directional") {
+        L.kind = Scene::Light::Directional;
+        L.direction = normalize(rd3(in));
+        L.color = rd3(in);
+      } else {
+        g_error = "unknown light kind " + kind;
+        return false;
+      }
+      if (scene.has_env) scene.lights.insert(scene.lights.end() - 1, L);
+      else scene.lights.push_back(L);
+    } else if (kw == "envlight") {  // envlight sky <sun colour>
+      std::string kind;
+      in >> kind;
+      if (kind != "sky") {
+        g_error = "unknown environment light " + kind;
+        return false;
+      }
+      Scene::Light L;
+      L.kind = Scene::Light::Sky;
+      L.color = rd3(in);
+      if (scene.has_env) scene.lights.back() = L;
+      else scene.lights.push_back(L);
+      scene.has_env = true;
     } else if (kw == "camera") {
       std::string kind;
       int W, H;

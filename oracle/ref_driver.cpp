@@ -215,6 +215,31 @@ static void load_pscene(const char* path, Loaded& out) {
         fprintf(stderr, "unknown shape kind %s\n", kind.c_str());
         exit(2);
       }
+    } else if (kw == "light") {
+      std::string kind;
+      in >> kind;
+      if (kind == "point") {
+        auto p = rd3(in), c = rd3(in);
+        scene.add_light(Light(PointLight(p, c)));
+      } else if (kind == "spot") {
+        auto p = rd3(in), d = rd3(in), c = rd3(in);
+        float falloff = rdf(in), extra = rdf(in);
+        scene.add_light(Light(SpotLight(p, d, c, falloff, extra)));
+      } else if (kind == "directional") {
+        auto d = rd3(in), c = rd3(in);
+        scene.add_light(Light(DirectionalLight(d, c)));
+      } else {
+        fprintf(stderr, "unknown light kind %s\n", kind.c_str());
+        exit(2);
+      }
+    } else if (kw == "envlight") {
+      std::string kind;
+      in >> kind;
+      if (kind != "sky") {
+        fprintf(stderr, "unknown environment light %s\n", kind.c_str());
+        exit(2);
+      }
+      scene.set_env_light(EnvironmentLight(Sky(rd3(in))));
     } else if (kw == "camera") {
       std::string kind;
       in >> kind;

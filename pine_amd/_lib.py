@@ -75,6 +75,10 @@ SIGNATURES = {
     "pine_gpu_scene_add_material_uber": (C.c_int, [C.c_void_p, C.c_char_p, f3, C.c_float, C.c_float, C.c_float, C.c_float]),
     "pine_gpu_scene_add_material_subsurface": (C.c_int, [C.c_void_p, C.c_char_p, f3, C.c_float, f3]),
     "pine_gpu_scene_find_material": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "pine_gpu_scene_add_light_point": (C.c_int, [C.c_void_p, f3, f3]),
+    "pine_gpu_scene_add_light_spot": (C.c_int, [C.c_void_p, f3, f3, f3, C.c_float, C.c_float]),
+    "pine_gpu_scene_add_light_directional": (C.c_int, [C.c_void_p, f3, f3]),
+    "pine_gpu_scene_set_env_sky": (C.c_int, [C.c_void_p, f3]),
     "pine_gpu_scene_node_constf": (C.c_int, [C.c_void_p, C.c_float]),
     "pine_gpu_scene_node_const3": (C.c_int, [C.c_void_p, f3]),
     "pine_gpu_scene_node_input": (C.c_int, [C.c_void_p, C.c_int]),

@@ -230,6 +230,33 @@ class Glass(Material):       # material.h:66-78
         self.albedo, self.roughness, self.ior = albedo, roughness, ior
 
 
+# ---- lights other than emissive geometry (src/pine/core/light.h:21-67, light.cpp:173-186) ---------
+class Light:
+    pass
+
+
+class PointLight(Light):
+    def __init__(self, position, color):
+        self.position, self.color = position, color
+
+
+class SpotLight(Light):
+    def __init__(self, position, direction, color, falloff_radian, cutoff_additional_radian=0.0):
+        self.position, self.direction, self.color = position, direction, color
+        self.falloff, self.cutoff_additional = falloff_radian, cutoff_additional_radian
+
+
+class DirectionalLight(Light):
+    def __init__(self, direction, color):
+        self.direction, self.color = direction, color
+
+
+class Sky:
+    """EnvironmentLight Sky(sun_color): scene.set(Sky(...))."""
+    def __init__(self, sun_color):
+        self.sun_color = sun_color
+
+
 # ---- shapes (src/pine/core/geometry.cpp:901-946) ------------------------------------------------
 class Shape:
     pass
@@ -361,9 +388,17 @@ class Scene:
             pass
 
     # scene.add(name, material) | scene.add(shape, material | name)
-    def add(self, a, b):
+    def add(self, a, b=None):
         if isinstance(a, str) and isinstance(b, Material):
             return self._add_material(a, b)
+        if isinstance(a, Light) and b is None:
+            h = self._h
+            if isinstance(a, PointLight):
+                return check(lib.pine_gpu_scene_add_light_point(h, _v3(a.position), _v3(a.color)), "PointLight")
+            if isinstance(a, SpotLight):
+                return check(lib.pine_gpu_scene_add_light_spot(h, _v3(a.position), _v3(a.direction), _v3(a.color),
+                                                               float(a.falloff), float(a.cutoff_additional)), "SpotLight")
+            return check(lib.pine_gpu_scene_add_light_directional(h, _v3(a.direction), _v3(a.color)), "DirectionalLight")
         if isinstance(a, Shape):
             if isinstance(b, str):
                 mid = check(lib.pine_gpu_scene_find_material(self._h, b.encode()), "scene.add")
@@ -375,6 +410,9 @@ class Scene:
         raise PineError("scene.add: no matching overload")
 
     def set(self, camera):
+        if isinstance(camera, Sky):
+            check(lib.pine_gpu_scene_set_env_sky(self._h, _v3(camera.sun_color)), "scene.set")
+            return camera
         if not isinstance(camera, ThinLenCamera):
             raise PineError("scene.set: expected a camera")
         f = camera.film()

@@ -25,7 +25,8 @@ enum : unsigned {
   F_SSS = 1u << 7,
   F_LDS_SCENE = 1u << 8,  // scene records staged in LDS
   F_NODES = 1u << 9,      // material parameters may be shading-node programs (node.h)
-  F_ALL = 0xffu | F_NODES,
+  F_LIGHTS = 1u << 10,    // Point / Spot / Directional lights or an environment light are present
+  F_ALL = 0xffu | F_NODES | F_LIGHTS,
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -823,6 +824,45 @@ PINE_HD f3 node_program_eval(const DNodeOp* ops, int start, f3 p, f3 n, f2 uv) {
   }
   return st[0];
 }
+// Lights other than emissive geometry (light.cpp:11-84).  Returns false when the light does not reach p.
+PINE_HD f3 sky_color_of(f3 sun_color, f3 wo) {  // Sky::color light.cpp:71-73, sky_color color.cpp:100-103
+  const float t = wo.y / 2 + 0.7f;
+  const f3 a{1.0f, 0.8f, 0.6f}, b{0.6f, 0.8f, 1.0f};
+  const f3 l = a * (1 - t) + b * t;  // psl::lerp(t, a, b) math.h:118-121
+  return sun_color * (l * l);
+}
+PINE_HD bool light_sample_other(const DLight* L, f3 p, f2 u2, f3& w, float& distance, float& pdf, f3& le) {
+  switch (L->kind) {
+    case LIGHT_POINT:  // light.cpp:11-17
+      w = normalize(ld3(L->position) - p, distance);
+      pdf = sqr(distance);
+      le = ld3(L->color);
+      return true;
+    case LIGHT_SPOT: {  // light.cpp:35-47
+      w = normalize(ld3(L->position) - p, distance);
+      const float cs = -dot(w, ld3(L->direction));
+      if (cs > L->falloff_cos) le = ld3(L->color);
+      else if (cs > L->cutoff_cos) le = ld3(L->color) * (cs - L->cutoff_cos) / (L->falloff_cos - L->cutoff_cos);
+      else return false;
+      pdf = sqr(distance);
+      return true;
+    }
+    case LIGHT_DIRECTIONAL:  // light.cpp:48-54
+      distance = 1e+10f;
+      w = ld3(L->direction);
+      pdf = 1.0f;
+      le = ld3(L->color);
+      return true;
+    case LIGHT_SKY:  // light.cpp:74-81
+      w = uniform_sphere(u2);
+      pdf = 1 / (4 * kPi);
+      distance = kFloatMax;
+      le = sky_color_of(ld3(L->color), w);
+      return true;
+    default: return false;
+  }
+}
+
 // A material's parameters at a surface point: the literals of the record, or (F_NODES variants) the
 // values of its node programs there -- BxdfSampleCtx -> NodeEvalCtx(it) (bxdf.h:10-21, node.h:13-20).
 struct MatParams {

@@ -354,7 +354,14 @@ int SceneHost::add_geometry(HostGeometry g) {
   geometries.push_back(std::move(g));
   int id = int(geometries.size()) - 1;
   // Scene::add_geometry (scene.cpp:19-20): emissive geometry becomes an AreaLight
-  if (materials[geometries[id].shape.material].kind == MAT_EMISSIVE) lights.push_back(id);
+  item_order.push_back({0, id});
+  if (materials[geometries[id].shape.material].kind == MAT_EMISSIVE) {
+    DLight L{};
+    L.kind = LIGHT_AREA;
+    L.geom = id;
+    lights.push_back(L);
+    light_describe.push_back("");
+  }
   accel.built = false;
   return id;
 }
@@ -609,7 +616,9 @@ std::string SceneHost::describe() const {
     s += l + "\n";
   }
   for (auto& d : material_describe) s += d + "\n";
-  for (auto& g : geometries) s += g.describe + "\n";
+  for (auto& it : item_order)
+    s += (it.first == 0 ? geometries[size_t(it.second)].describe : light_describe[size_t(it.second)]) + "\n";
+  if (has_env) s += env_describe + "\n";
   if (has_camera) s += camera_describe + "\n";
   return s;
 }
@@ -705,6 +714,60 @@ int pine_gpu_scene_add_material_subsurface(pine_gpu_scene* s, const char* name, 
   return s->host.add_material(
       n.c_str(), m, "material " + n + " subsurface " + hex3(c) + fmt(" %a ", roughness) + hex3(sigma_s));
 }
+// ---- lights other than emissive geometry (light.h:21-67, light.cpp:11-84, scene.cpp:29-46) ----
+static int add_light(pine_gpu_scene* s, const DLight& L, const std::string& desc) {
+  s->host.lights.push_back(L);
+  s->host.light_describe.push_back(desc);
+  s->host.item_order.push_back({1, int(s->host.lights.size()) - 1});
+  return int(s->host.lights.size()) - 1;
+}
+int pine_gpu_scene_add_light_point(pine_gpu_scene* s, const float position[3], const float color[3]) {
+  if (!check(s, position) || !check(s, color)) return -1;
+  DLight L{};
+  L.kind = LIGHT_POINT;
+  memcpy(L.position, position, 12);
+  memcpy(L.color, color, 12);
+  return add_light(s, L, "light point " + hex3(position) + " " + hex3(color));
+}
+int pine_gpu_scene_add_light_spot(pine_gpu_scene* s, const float position[3], const float direction[3], const float color[3],
+                                  float falloff_radian, float cutoff_additional_radian) {
+  if (!check(s, position) || !check(s, direction) || !check(s, color)) return -1;
+  const float pi2 = kPi * 2;  // Pi2 (math.h)
+  if (falloff_radian <= 0.0f) return set_error("`SpotLight` invalid falloff angle"), -1;  // light.cpp:25-32
+  if (falloff_radian > pi2) return set_error("`SpotLight` invalid falloff angle(please use radian, not degree)"), -1;
+  if (cutoff_additional_radian < 0.0f) return set_error("`SpotLight` invalid cutoff angle"), -1;
+  if (falloff_radian + cutoff_additional_radian > pi2) return set_error("`SpotLight` invalid cutoff angle(please use radian, not degree)"), -1;
+  DLight L{};
+  L.kind = LIGHT_SPOT;
+  memcpy(L.position, position, 12);
+  const f3 d = normalize(ld3(direction));
+  L.direction[0] = d.x, L.direction[1] = d.y, L.direction[2] = d.z;
+  memcpy(L.color, color, 12);
+  L.falloff_cos = cosf(falloff_radian);
+  L.cutoff_cos = cosf(falloff_radian + cutoff_additional_radian);
+  return add_light(s, L, "light spot " + hex3(position) + " " + hex3(direction) + " " + hex3(color) +
+                            fmt(" %a %a", falloff_radian, cutoff_additional_radian));
+}
+int pine_gpu_scene_add_light_directional(pine_gpu_scene* s, const float direction[3], const float color[3]) {
+  if (!check(s, direction) || !check(s, color)) return -1;
+  DLight L{};
+  L.kind = LIGHT_DIRECTIONAL;
+  const f3 d = normalize(ld3(direction));
+  L.direction[0] = d.x, L.direction[1] = d.y, L.direction[2] = d.z;
+  memcpy(L.color, color, 12);
+  return add_light(s, L, "light directional " + hex3(direction) + " " + hex3(color));
+}
+int pine_gpu_scene_set_env_sky(pine_gpu_scene* s, const float sun_color[3]) {
+  if (!check(s, sun_color)) return -1;
+  DLight L{};
+  L.kind = LIGHT_SKY;
+  memcpy(L.color, sun_color, 12);
+  s->host.env = L;
+  s->host.has_env = true;
+  s->host.env_describe = "envlight sky " + hex3(sun_color);
+  return 0;
+}
+
 // ---- shading nodes + node-parameterised materials ----
 static int add_node(pine_gpu_scene* s, HostNode n) {
   if (!check(s)) return -1;

@@ -97,7 +97,13 @@ struct SceneHost {
   std::vector<std::string> material_describe;
   std::vector<HostGeometry> geometries;
   std::vector<HostMesh> meshes;
-  std::vector<int> lights;  // geometry indices, in add order
+  std::vector<DLight> lights;  // Scene::lights in add order (area lights of emissive geometry + explicit lights)
+  bool has_env = false;
+  DLight env{};                // environment light (appended to the sampler's list at plan build)
+  std::vector<std::string> light_describe;
+  std::string env_describe;
+  // what describe() prints after the materials, in add order: (0, geometry index) or (1, light index)
+  std::vector<std::pair<int, int>> item_order;
   DCamera camera{};
   bool has_camera = false;
   int tonemapper = 0;

@@ -90,9 +90,10 @@ struct DeviceScene {
   const int* prims;
   const DBvh* bvhs;
   const float* tri_verts;
-  const int* lights;
+  const DLight* lights;
   const DNodeOp* node_ops;  // shading-node programs (F_NODES variants)
-  int num_lights;
+  int num_lights;           // entries of `lights` (the light sampler's N)
+  int env_light;            // index of the environment light in `lights`, or -1
   int num_shapes;
   DCamera cam;
   DTables tables;
@@ -115,7 +116,7 @@ struct SceneView {
   const DNode* nodes;
   const int* prims;
   const DBvh* bvhs;
-  const int* lights;
+  const DLight* lights;
   const float* tri_verts;
   const DNodeOp* node_ops;
   int stack_top;
@@ -410,7 +411,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.materials = reinterpret_cast<const DMaterial*>(base + S.off_materials);
     V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
     V.prims = reinterpret_cast<const int*>(base + S.off_prims);
-    V.lights = reinterpret_cast<const int*>(base + S.off_lights);
+    V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
   } else {
     __syncthreads();  // Sobol rows staged above
@@ -608,7 +609,15 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     const DShape* shape = nullptr;
     const DMaterial* mat = nullptr;
     if (!hit) {
-      terminal = true;  // no environment light (path.cpp:75-81)
+      terminal = true;  // path.cpp:75-81
+      if constexpr (F & F_LIGHTS)
+        if (S.env_light >= 0) {
+          Lo = mk3(1.0f) * sky_color_of(ld3(V.lights[S.env_light].color), ray_d);
+          if (!st.is_delta()) {
+            has_light_pdf = true;
+            light_pdf = 1 / (4 * kPi);  // Sky::pdf -- not divided by the light count
+          }
+        }
     } else {
       REGION(3);  // surface info
       shape = &V.shapes[geom];
@@ -739,35 +748,50 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         if (S.num_lights > 0) {  // UniformLightSampler::sample lightsampler.cpp:12-26
           if (S.num_lights != 1) u1 *= float(S.num_lights);  // x * 1.0f == x exactly
           const int index = int(u1);
-          const DShape* lshape = &V.shapes[V.lights[index]];
-          DShapeSample gs;
-          if (shape_sample<F>(lshape, V.tri_verts, it.p, u2, u1 - float(index), gs)) {
-            // AreaLight::sample light.cpp:55-69
-            const DMaterial* lmat = &V.materials[lshape->material];
-            if (!is_zero(material_le(lmat, gs.n, -gs.w))) {
-              const float ls_pdf = S.num_lights != 1 ? gs.pdf / float(S.num_lights) : gs.pdf;
-              REGION(7);  // shadow ray cast
-              shadow_count++;
-              DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
-              int g2, p2;
-              SEC_MARK(5);  // light sampling
+          const DLight* L = &V.lights[index];
+          int lkind = LIGHT_AREA;
+          if constexpr (F & F_LIGHTS) lkind = L->kind;
+          bool lvalid = false;
+          f3 lw = mk3(0.0f), lle = mk3(0.0f);
+          float ldist = 0.0f, lpdf = 0.0f;
+          if (lkind == LIGHT_AREA) {  // AreaLight::sample light.cpp:55-69
+            const DShape* lshape = &V.shapes[L->geom];
+            DShapeSample gs;
+            if (shape_sample<F>(lshape, V.tri_verts, it.p, u2, u1 - float(index), gs)) {
+              lle = material_le(&V.materials[lshape->material], gs.n, -gs.w);
+              lvalid = !is_zero(lle);
+              lw = gs.w;
+              ldist = gs.distance;
+              lpdf = gs.pdf;
+            }
+          } else {
+            if constexpr (F & F_LIGHTS) lvalid = light_sample_other(L, it.p, u2, lw, ldist, lpdf, lle);
+          }
+          const bool ldelta = lkind == LIGHT_POINT || lkind == LIGHT_SPOT || lkind == LIGHT_DIRECTIONAL;  // light.h:111-113
+          if (lvalid) {
+            const float ls_pdf = S.num_lights != 1 ? lpdf / float(S.num_lights) : lpdf;
+            REGION(7);  // shadow ray cast
+            shadow_count++;
+            DRay sr = spawn_ray(it.p, it.n, lw, ldist);
+            int g2, p2;
+            SEC_MARK(5);  // light sampling
 #ifdef PINE_ABL_NOSHADOW
-              const bool occluded = sr.tmax < 0;
+            const bool occluded = sr.tmax < 0;
 #else
-              const bool occluded = scene_traverse<true, F>(V, sr, stack, g2, p2);
+            const bool occluded = scene_traverse<true, F>(V, sr, stack, g2, p2);
 #endif
-              SEC_MARK(6);  // shadow traversal
-              if (!occluded) {
-                // the material records are re-read here instead of being kept in registers across
-                // the traversal (le is the emitter's colour: the one-sided test passed above)
-                const f3 le = ld3(lmat->color);
-                bx.albedo = mp.albedo;
-                bx.albedo_over_pi = mp.albedo_over_pi;
-                const float cosine = absdot(gs.w, it.n);
-                const f3 wo = mul(w2l, gs.w);
-                const f3 f = bxdf_f<F>(bx, wo);
+            SEC_MARK(6);  // shadow traversal
+            if (!occluded) {
+              bx.albedo = mp.albedo;
+              bx.albedo_over_pi = mp.albedo_over_pi;
+              const float cosine = absdot(lw, it.n);
+              const f3 wo = mul(w2l, lw);
+              const f3 f = bxdf_f<F>(bx, wo);
+              if (ldelta) {  // path.cpp:104-106: no MIS against a delta light
+                nee = mk3(0.0f) + lle * mk3(1.0f) * cosine * f / ls_pdf;
+              } else {
                 const float mis = balance_heuristic(ls_pdf, bxdf_pdf<F>(bx, wo));
-                nee = mk3(0.0f) + le * mk3(1.0f) * cosine * f / ls_pdf * mis;
+                nee = mk3(0.0f) + lle * mk3(1.0f) * cosine * f / ls_pdf * mis;
               }
             }
           }
@@ -1246,7 +1270,9 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     packed_prims[i] = g | (H.materials[size_t(sh.material)].kind == MAT_EMISSIVE ? kPrimEmissiveBit : 0) | (sh.kind << kPrimKindShift);
   }
   S.off_prims = put(packed_prims.data(), packed_prims.size() * sizeof(int));
-  S.off_lights = put(H.lights.data(), H.lights.size() * sizeof(int));
+  std::vector<DLight> light_list = H.lights;  // + the environment light last (lightsampler.cpp:6-10)
+  if (H.has_env) light_list.push_back(H.env);
+  S.off_lights = put(light_list.data(), light_list.size() * sizeof(DLight));
   blob.resize((blob.size() + 15) & ~size_t(15));
   S.blob_bytes = int(blob.size());
   HIP_OK(hipMalloc((void**)&p->d_blob, blob.size()));
@@ -1272,10 +1298,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.materials = reinterpret_cast<const DMaterial*>(p->d_blob + S.off_materials);
   S.bvhs = reinterpret_cast<const DBvh*>(p->d_blob + S.off_bvhs);
   S.prims = reinterpret_cast<const int*>(p->d_blob + S.off_prims);
-  S.lights = reinterpret_cast<const int*>(p->d_blob + S.off_lights);
+  S.lights = reinterpret_cast<const DLight*>(p->d_blob + S.off_lights);
   S.node_ops = reinterpret_cast<const DNodeOp*>(p->d_blob + S.off_node_ops);
   S.tri_verts = p->d_tri;
-  S.num_lights = int(H.lights.size());
+  S.num_lights = int(light_list.size());
+  S.env_light = H.has_env ? int(light_list.size()) - 1 : -1;
   S.num_shapes = int(shapes.size());
   S.cam = H.camera;
   S.tables.sobol = p->d_tables;
@@ -1321,6 +1348,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     if (m.kind == MAT_SUBSURFACE) need |= F_SSS;
   }
   if (!node_ops.empty()) need |= F_NODES;
+  for (auto& L : light_list)
+    if (L.kind != LIGHT_AREA) need |= F_LIGHTS;
   const bool lds_ok = size_t(S.blob_bytes) <= 32 * 1024 && getenv("PINE_GPU_NO_LDS_SCENE") == nullptr;
   p->variant = -1;
   for (int v = 0; v < kNumVariants; v++) {

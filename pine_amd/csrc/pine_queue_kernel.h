@@ -93,7 +93,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.materials = reinterpret_cast<const DMaterial*>(base + S.off_materials);
     V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
     V.prims = reinterpret_cast<const int*>(base + S.off_prims);
-    V.lights = reinterpret_cast<const int*>(base + S.off_lights);
+    V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
   } else {
     V.nodes = S.nodes;
@@ -422,7 +422,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           if (S.num_lights > 0) {
             if (S.num_lights != 1) u1 *= float(S.num_lights);
             const int index = int(u1);
-            const DShape* lshape = &V.shapes[V.lights[index]];
+            const DShape* lshape = &V.shapes[V.lights[index].geom];  // (no F_LIGHTS variants of this kernel: area lights only)
             DShapeSample gs;
             if (shape_sample<F>(lshape, V.tri_verts, it.p, u2, u1 - float(index), gs)) {
               const DMaterial* lmat = &V.materials[lshape->material];

@@ -113,6 +113,22 @@ struct DCamera {
   int W, H;
 };
 
+// One entry of the light sampler's list (UniformLightSampler::build lightsampler.cpp:6-10): Scene::lights
+// in add order -- an area light per emissive geometry, Point / Spot / Directional lights -- then the
+// environment light, if any, last.  light.h:21-67.
+enum LightKind : int { LIGHT_AREA = 0, LIGHT_POINT = 1, LIGHT_SPOT = 2, LIGHT_DIRECTIONAL = 3, LIGHT_SKY = 4 };
+struct alignas(16) DLight {
+  float position[3];
+  int kind;
+  float direction[3];  // normalised (Spot, Directional)
+  int geom;            // LIGHT_AREA: geometry index
+  float color[3];      // Point / Spot / Directional: colour; Sky: sun_color
+  float falloff_cos;
+  float cutoff_cos;
+  int pad[3];
+};
+static_assert(sizeof(DLight) == 64, "DLight must be 64 bytes");
+
 // Fold-stack entry (SURVEY.md 8(d) "FoldEntry 32 B"): what a non-terminal path vertex must keep
 // until its child subtree has resolved, for the backward per-level clamp (path.cpp:114-121).
 struct FoldEntry {

@@ -14,7 +14,7 @@ CAMERAS = {
 }
 
 
-def cbox(size=(640, 640), camera="committed", boxes=True):
+def cbox(size=(640, 640), camera="committed", boxes=True, lamp=True):
     """scenes/cbox.pine; boxes=False gives the Rect-only variant (no order-dependent OBBs)."""
     scene = Scene()
     scene.add("floor", Diffuse([0.9, 0.9, 0.9]))
@@ -34,7 +34,8 @@ def cbox(size=(640, 640), camera="committed", boxes=True):
                       translate([-0.6, 0.0, 1.0]) * rotate_y(-0.4) * scale([0.6, 1.3, 0.6])), "floor")
     # 600 * [1.0, 0.64, 0.185] in PRL is float32 arithmetic
     le = (np.float32(600) * np.array([1.0, 0.64, 0.185], dtype=np.float32)).tolist()
-    scene.add(Rect([0.0, 1.9, 1], [0.1, 0, 0], [0, 0, 0.1]), Emissive(le))
+    if lamp:
+        scene.add(Rect([0.0, 1.9, 1], [0.1, 0, 0], [0, 0, 0.1]), Emissive(le))
     frm, to, fov = CAMERAS[camera]
     scene.set(ThinLenCamera(Film(list(size), Uncharted2()), frm, to, fov))
     return scene
@@ -169,4 +170,19 @@ def materials_zoo(size=(64, 64)):
     scene.add(Sphere([-0.1, 0.9, 1.5], 0.3), "uber")
     scene.add(Rect([0.0, 1.9, 1], [0.5, 0, 0], [0, 0, 0.5]), Emissive([20.0, 18.0, 15.0]))
     scene.set(ThinLenCamera(Film(list(size)), [0, 1, -4], [0, 1, 0], 0.25))
+    return scene
+
+
+def lights_zoo(size=(64, 64), with_sky=True):
+    """cbox geometry (README camera) lit by every light kind of light.h: the emissive Rect (area light), a
+    PointLight added BEFORE it, a SpotLight and a DirectionalLight after, and the Sky environment light --
+    the light sampler's list order is the add order, the environment light last (lightsampler.cpp:6-10)."""
+    from .api import PointLight, SpotLight, DirectionalLight, Sky
+    scene = cbox(size, "readme", lamp=False)
+    scene.add(PointLight([0.5, 1.5, 0.5], [2.5, 2.0, 1.5]))
+    scene.add(Rect([0.0, 1.9, 1], [0.1, 0, 0], [0, 0, 0.1]), Emissive((np.array([1.0, 0.64, 0.185], dtype=np.float32) * np.float32(600)).tolist()))
+    scene.add(SpotLight([-0.5, 1.75, 1.0], [0.25, -1.0, 0.125], [5.0, 5.0, 4.0], 0.4, 0.2))
+    scene.add(DirectionalLight([0.5, 1.0, -1.0], [0.4, 0.4, 0.6]))
+    if with_sky:
+        scene.set(Sky([0.9, 0.9, 1.0]))
     return scene

@@ -52,6 +52,7 @@ FILM_NAMES = [
     "cbox_rect_readme_64_s64_d5", "cbox_committed_ragged_45x37_s8_d3", "cbox_readme_64_s1_d1",
     "zoo_48_s16_d5", "classic_cones12_90x45_s32_d6", "sss_48_s32_d8",
     "mats_zoo_64_s32_d6", "classic_checker_cones8_90x45_s32_d6",   # node-graph materials, Metal / Glossy / Glass
+    "lights_zoo_64_s32_d6", "lights_nosky_48_s16_d4",               # delta lights, Sky environment light
 ]
 
 

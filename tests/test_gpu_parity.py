@@ -145,6 +145,8 @@ def _scene_for(name):
         "sss_48_s32_d8": lambda: scenes.sss((48, 48), 1),
         "mats_zoo_64_s32_d6": lambda: scenes.materials_zoo((64, 64)),
         "classic_checker_cones8_90x45_s32_d6": lambda: scenes.classic_cones((90, 45), 8, checker_floor=True),
+        "lights_zoo_64_s32_d6": lambda: scenes.lights_zoo((64, 64)),
+        "lights_nosky_48_s16_d4": lambda: scenes.lights_zoo((48, 48), with_sky=False),
     }[name]()
 
 

@@ -50,6 +50,9 @@ FILMS = {
     # node-graph materials + Metal / Glossy / Glass (node.h, material.h:39-78)
     "mats_zoo_64_s32_d6": (lambda: scenes.materials_zoo((64, 64)), 32, 6),
     "classic_checker_cones8_90x45_s32_d6": (lambda: scenes.classic_cones((90, 45), 8, checker_floor=True), 32, 6),
+    # Point / Spot / Directional lights + Sky environment light (light.h, path.cpp:75-81,104-106)
+    "lights_zoo_64_s32_d6": (lambda: scenes.lights_zoo((64, 64)), 32, 6),
+    "lights_nosky_48_s16_d4": (lambda: scenes.lights_zoo((48, 48), with_sky=False), 16, 4),
 }
 
 
