@@ -145,6 +145,11 @@ struct SceneObj : Object {
   SceneObj() : h(pine_gpu_scene_create()) {}
   ~SceneObj() override { pine_gpu_scene_destroy(h); }
 };
+struct LightObj : Object {
+  std::string kind;  // PointLight | SpotLight | DirectionalLight | Sky
+  float a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, c[3] = {0, 0, 0};
+  float falloff = 0, extra = 0;
+};
 struct IntegratorObj : Object {
   int spp = 0, depth = 0;
 };
@@ -1654,6 +1659,59 @@ Interp::Interp() {
     return *s->camera;
   });
 
+  // ---- lights (light.cpp:173-186) ----
+  auto light = [](const char* kind) {
+    auto l = std::make_shared<LightObj>();
+    l->kind = kind;
+    return l;
+  };
+  r.def("PointLight", {"vec3", "vec3"}, "PointLight", [=](Interp&, std::vector<Cell>& a) {
+    auto l = light("PointLight");
+    memcpy(l->a, a[0]->f, 12);
+    memcpy(l->c, a[1]->f, 12);
+    return mk_obj("PointLight", l);
+  });
+  for (int with_cutoff = 0; with_cutoff < 2; with_cutoff++) {
+    std::vector<std::string> pt{"vec3", "vec3", "vec3", "f32"};
+    if (with_cutoff) pt.push_back("f32");
+    r.def("SpotLight", pt, "SpotLight", [=](Interp&, std::vector<Cell>& a) {
+      auto l = light("SpotLight");
+      memcpy(l->a, a[0]->f, 12);
+      memcpy(l->b, a[1]->f, 12);
+      memcpy(l->c, a[2]->f, 12);
+      l->falloff = a[3]->f[0];
+      l->extra = with_cutoff ? a[4]->f[0] : 0.0f;
+      return mk_obj("SpotLight", l);
+    });
+  }
+  r.def("DirectionalLight", {"vec3", "vec3"}, "DirectionalLight", [=](Interp&, std::vector<Cell>& a) {
+    auto l = light("DirectionalLight");
+    memcpy(l->b, a[0]->f, 12);
+    memcpy(l->c, a[1]->f, 12);
+    return mk_obj("DirectionalLight", l);
+  });
+  for (const char* k : {"PointLight", "SpotLight", "DirectionalLight"}) r.convert(k, "Light", [](const Value& v) { return retype(v, "Light"); });
+  r.def("Sky", {"vec3"}, "Sky", [=](Interp&, std::vector<Cell>& a) {
+    auto l = light("Sky");
+    memcpy(l->c, a[0]->f, 12);
+    return mk_obj("Sky", l);
+  });
+  r.convert("Sky", "EnvironmentLight", [](const Value& v) { return retype(v, "EnvironmentLight"); });
+  r.def("add", {"Scene&", "Light"}, "void", [](Interp&, std::vector<Cell>& a) {  // Scene::add_light scene.cpp:29-34
+    auto s = obj<SceneObj>(a[0]);
+    auto l = obj<LightObj>(a[1]);
+    int rc = -1;
+    if (l->kind == "PointLight") rc = pine_gpu_scene_add_light_point(s->h, l->a, l->c);
+    else if (l->kind == "SpotLight") rc = pine_gpu_scene_add_light_spot(s->h, l->a, l->b, l->c, l->falloff, l->extra);
+    else rc = pine_gpu_scene_add_light_directional(s->h, l->b, l->c);
+    gpu_check(rc, "scene.add(light)");
+    return Value();
+  });
+  r.def("set", {"Scene&", "EnvironmentLight"}, "void", [](Interp&, std::vector<Cell>& a) {  // Scene::set_env_light scene.cpp:44-46
+    gpu_check(pine_gpu_scene_set_env_sky(obj<SceneObj>(a[0])->h, obj<LightObj>(a[1])->c), "scene.set(environment light)");
+    return Value();
+  });
+
   // ---- sampler + integrator (sampler.cpp:189-198, program_context.cpp:76-81, path.cpp:7-41) ----
   r.def("BlueSampler", {"i32"}, "BlueSampler", [](Interp&, std::vector<Cell>& a) {
     if (a[0]->i[0] <= 0) fail("`BlueSampler` should have positive samples per pixel");
@@ -1687,6 +1745,20 @@ Interp::Interp() {
     f->pixels.assign(size_t(f->w) * f->h * 4, 0.0f);
     gpu_check(pine_gpu_path_render(s->h, &prm, f->pixels.data()), "PathIntegrator.render");
     in.last_film = f;
+    return Value();
+  });
+  // quick_render(scene, from, to, filename): 640x480, ThinLenCamera fov 0.5, BlueSampler(4), depth 4, save
+  // (program_context.cpp:120-124) -- composed from the functions above
+  r.def("quick_render", {"Scene&", "vec3", "vec3", "str"}, "void", [](Interp& in, std::vector<Cell>& a) {
+    Node at;
+    at.kind = Node::Call;
+    const int size[2] = {640, 480};
+    Cell film = in.call(at, "Film", {cell(mk_veci(2, size))});
+    Cell cam = in.call(at, "ThinLenCamera", {film, a[1], a[2], cell(mk_f32(0.5f))});
+    in.call(at, "set", {a[0], cam});
+    Cell integ = in.call(at, "PathIntegrator", {in.call(at, "BlueSampler", {cell(mk_i32(4))}), cell(mk_i32(4))});
+    in.call(at, "render", {integ, a[0]});
+    in.call(at, "save", {film, a[3]});
     return Value();
   });
 }

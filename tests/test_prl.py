@@ -202,6 +202,37 @@ def test_classic_script_render_equals_oracle(oracle):
     assert_bit_equal(prl.last_film(), ref, "classic.pine through the front-end vs oracle")
 
 
+def _lights_script(size_note=""):
+    return open(os.path.join(ROOT, "examples", "minimal_lights.pine")).read()
+
+
+def test_lights_and_quick_render(oracle):
+    """scene.add(Light), scene.set(Sky), quick_render (program_context.cpp:120-124): list order = add order,
+    the environment light last; the oracle (pinned to the reference on light scenes) accepts the description."""
+    from pine_amd import prl
+    out = prl.interpret(_lights_script(), dry_run=True)
+    ps, spp, depth = prl.scene_of_dry_run(out)
+    assert (spp, depth) == (4, 4) and "camera thinlens 640 480" in ps and out.rstrip().endswith("@save minimal_lights.png 640x480")
+    kinds = [l.split()[1] for l in ps.splitlines() if l.startswith("light ")]
+    assert kinds == ["directional", "point", "spot"] and "envlight sky" in ps
+    with pytest.raises(prl.PrlError, match="invalid falloff angle"):
+        prl.interpret('s := Scene(); s.add(SpotLight([0,1,0], [0,-1,0], [1,1,1], 30.0));', dry_run=True)  # degrees, not radians
+    small = ps.replace("camera thinlens 640 480", "camera thinlens 40 30")
+    film, _ = oracle.render(small, (40, 30), 4, 4)
+    assert film[..., :3].mean() > 0.05
+
+
+@pytest.mark.gpu
+def test_lights_script_render_equals_oracle(oracle):
+    from pine_amd import prl
+    src = _lights_script().replace('world.quick_render([0, 0.5, -5], [0, 0, 0], "minimal_lights.png");',
+                                   'world.set(ThinLenCamera(Film([80, 60]), [0, 0.5, -5], [0, 0, 0], 0.5)); PathIntegrator(BlueSampler(16), 5).render(world);')
+    ps, spp, depth = prl.scene_of_dry_run(prl.interpret(src, dry_run=True))
+    prl.interpret(src)
+    ref, _ = oracle.render(ps, (80, 60), spp, depth)
+    assert_bit_equal(prl.last_film(), ref, "lights script through the front-end vs oracle")
+
+
 def test_runaway_scripts_hit_the_step_budget(monkeypatch):
     from pine_amd import prl
     monkeypatch.setenv("PINE_PRL_MAX_STEPS", "200000")
