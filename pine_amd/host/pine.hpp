@@ -59,6 +59,16 @@ struct Emissive { vec3 color; };
 struct Diffuse { vec3 albedo; };
 struct Uber { vec3 albedo; float roughness; float metallic = 0.0f; float transmission = 0.0f; float ior = 1.45f; };
 struct Subsurface { vec3 albedo; float roughness; vec3 sigma_s; };
+// constant-parameter forms of material.h:39-78 (node-graph parameters: use the C ABI's node calls)
+struct Metal { vec3 albedo; float roughness; };
+struct Glossy { vec3 albedo; float roughness; float ior = 1.4f; };
+struct Glass { vec3 albedo; float roughness; float ior = 1.4f; };
+
+// ---- lights other than emissive geometry (light.h:21-67) ----
+struct PointLight { vec3 position, color; };
+struct SpotLight { vec3 position, direction, color; float falloff_radian, cutoff_additional_radian = 0.0f; };
+struct DirectionalLight { vec3 direction, color; };
+struct Sky { vec3 sun_color; };
 
 // ---- shapes ----
 struct Rect { vec3 position, ex, ey; bool flip_normal = false; };
@@ -132,6 +142,22 @@ class Scene {
   int add(const std::string& name, Subsurface m) {
     return check(pine_gpu_scene_add_material_subsurface(h_, name.c_str(), m.albedo.data(), m.roughness, m.sigma_s.data()), "Subsurface");
   }
+  int add(const std::string& name, Metal m) {
+    return check(pine_gpu_scene_add_material_metal(h_, name.c_str(), node(m.albedo), node(m.roughness)), "Metal");
+  }
+  int add(const std::string& name, Glossy m) {
+    return check(pine_gpu_scene_add_material_glossy(h_, name.c_str(), node(m.albedo), node(m.roughness), node(m.ior)), "Glossy");
+  }
+  int add(const std::string& name, Glass m) {
+    return check(pine_gpu_scene_add_material_glass(h_, name.c_str(), node(m.albedo), node(m.roughness), node(m.ior)), "Glass");
+  }
+  int add(PointLight l) { return check(pine_gpu_scene_add_light_point(h_, l.position.data(), l.color.data()), "PointLight"); }
+  int add(SpotLight l) {
+    return check(pine_gpu_scene_add_light_spot(h_, l.position.data(), l.direction.data(), l.color.data(), l.falloff_radian,
+                                               l.cutoff_additional_radian), "SpotLight");
+  }
+  int add(DirectionalLight l) { return check(pine_gpu_scene_add_light_directional(h_, l.direction.data(), l.color.data()), "DirectionalLight"); }
+  void set(Sky sky) { check(pine_gpu_scene_set_env_sky(h_, sky.sun_color.data()), "scene.set(Sky)"); }
   // scene.add(shape, "material name") and scene.add(shape, Material)
   template <class S, class = std::enable_if_t<is_shape<S>::value>>
   int add(const S& shape, const std::string& material) {
@@ -161,6 +187,8 @@ class Scene {
   int add_shape(const Mesh& s, int m) {
     return check(pine_gpu_scene_add_mesh(h_, &s.vertices[0].x, int(s.vertices.size()), &s.indices[0][0], int(s.indices.size()), m), "Mesh");
   }
+  int node(vec3 v) { return check(pine_gpu_scene_node_const3(h_, v.data()), "node"); }
+  int node(float v) { return check(pine_gpu_scene_node_constf(h_, v), "node"); }
   pine_gpu_scene* h_;
 };
 
