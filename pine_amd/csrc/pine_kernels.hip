@@ -911,14 +911,19 @@ constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 using QueueKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, uint32_t*, Counters*);
 struct QueueVariant {
   unsigned features;
+  int ctx;             // path contexts per workgroup
+  size_t fixed_lds;    // LDS bytes before the traversal stack
   QueueKernelFn fn;
   const char* name;
 };
+#define PINE_QV(F, CTX, NAME) {F, CTX, QLayout<CTX>::fixed_bytes, path_queue_kernel<F, CTX>, NAME}
 static const QueueVariant kQueueVariants[] = {
-    {kFBoxes | F_LDS_SCENE, path_queue_kernel<kFBoxes | F_LDS_SCENE>, "queue: rect+box/diffuse, scene in LDS"},
+    PINE_QV(kFBoxes | F_LDS_SCENE, PINE_QCTX, "queue: rect+box/diffuse, scene in LDS"),
 #ifndef PINE_ONLY_CBOX_VARIANT
-    {kFAnalytic | F_LDS_SCENE, path_queue_kernel<kFAnalytic | F_LDS_SCENE>, "queue: analytic shapes/uber, scene in LDS"},
-    {kFAnalytic, path_queue_kernel<kFAnalytic>, "queue: analytic shapes/uber"},
+    PINE_QV(kFAnalytic | F_LDS_SCENE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS"),
+    PINE_QV(kFAnalytic, PINE_QCTX, "queue: analytic shapes/uber"),
+    // big scenes: node-graph materials allowed, 1024 contexts so that a deep traversal stack fits the LDS
+    PINE_QV(kFAnalytic | F_NODES, 1024, "queue: analytic shapes/uber/nodes, 1024 contexts (deep BVH)"),
 #endif
 };
 constexpr int kNumQueueVariants = int(sizeof(kQueueVariants) / sizeof(kQueueVariants[0]));
@@ -1377,7 +1382,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
         if ((F & F_LDS_SCENE) && !lds_ok) continue;  // (a scene-in-global variant later in the table is the fallback when LDS is short)
-        const size_t lds = kQLdsFixedBytes + size_t(S.stack_total) * kQBlock * sizeof(int) +
+        const size_t lds = kQueueVariants[v].fixed_lds + size_t(S.stack_total) * kQBlock * sizeof(int) +
                            ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0);
         if (lds > 160 * 1024) continue;
         p->queue_variant = v;
@@ -1438,16 +1443,17 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   const char* env_bpc = getenv("PINE_GPU_BLOCKS_PER_CU");
   if (env_bpc && atoi(env_bpc) > 0) blocks_per_cu = atoi(env_bpc);
   unsigned long long want = (W.total_items + kBlock - 1) / kBlock;
-  if (p->queue_variant >= 0) want = (W.total_items + kQCtx - 1) / kQCtx;
+  const int qctx = p->queue_variant >= 0 ? kQueueVariants[p->queue_variant].ctx : 0;
+  if (p->queue_variant >= 0) want = (W.total_items + qctx - 1) / qctx;
   p->grid = int(std::min<unsigned long long>(want, (unsigned long long)prop.multiProcessorCount * blocks_per_cu));
   if (p->grid < 1) p->grid = 1;
 
   if (W.items_per_pixel > 1) HIP_OK(hipMalloc((void**)&p->d_ckpt, W.total_items * sizeof(ulonglong2)));
   HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
-  const size_t fold_slots = p->queue_variant >= 0 ? size_t(p->grid) * kQCtx : size_t(p->grid) * kBlock;
+  const size_t fold_slots = p->queue_variant >= 0 ? size_t(p->grid) * qctx : size_t(p->grid) * kBlock;
   HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * fold_slots * sizeof(float)));
   if (p->queue_variant >= 0)
-    HIP_OK(hipMalloc((void**)&p->d_ctxg, size_t(p->grid) * kQCtx * kQCtxGlobalDwords * sizeof(uint32_t)));
+    HIP_OK(hipMalloc((void**)&p->d_ctxg, size_t(p->grid) * qctx * kQCtxGlobalDwords * sizeof(uint32_t)));
   HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
   p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
   if (p->timed)

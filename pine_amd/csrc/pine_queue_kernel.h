@@ -32,8 +32,6 @@ constexpr int kQBlock = PINE_QBLOCK;  // threads per workgroup (one workgroup pe
 #ifndef PINE_QCTX
 #define PINE_QCTX 1536
 #endif
-constexpr int kQCtx = PINE_QCTX;  // path contexts per workgroup (1.5x the threads by default)
-constexpr int kQRing = 2048;   // ring capacity (power of two >= kQCtx)
 constexpr int kQFields = 12;   // dwords of context state
 constexpr int kQPoolItems = 512;
 enum : int { QS_S = 0, QS_T = 1, QS_COUNT = 2 };
@@ -43,16 +41,22 @@ constexpr unsigned kStFresh = 0xffffffffu;  // context has no path yet
 // control words
 enum : int { QC_HEAD = 0, QC_TAIL = 2, QC_BUSY = 6, /* heads at 0..1, tails at 2..3 (one u64) */ QC_LOCK = 7, QC_PNEXT = 8, QC_PEND = 10, QC_EXHAUSTED = 12, QC_ABORT = 13, QC_WORDS = 16 };
 constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a protocol bug must end the kernel, not hang the GPU
-
-// LDS layout (dword offsets)
-constexpr int kQOffCtl = 0;
-constexpr int kQOffRing = kQOffCtl + QC_WORDS;                 // 3 rings of kQRing dwords (id + 1, 0 = empty)
-constexpr int kQOffState = kQOffRing + QS_COUNT * kQRing;
-constexpr int kQOffSobol = kQOffState + kQFields * kQCtx;
 constexpr int kQWinDwords = 5;  // per-thread sampler window: 3 dwords of ranking bytes (12 dimensions) + 2 of scrambling bytes
-constexpr int kQOffWin = kQOffSobol + kLdsSamplerDims * 256 / 4;
-constexpr int kQOffStack = kQOffWin + kQWinDwords * kQBlock;
-constexpr size_t kQLdsFixedBytes = size_t(kQOffStack) * 4;
+
+// LDS layout (dword offsets) for CTX path contexts per workgroup: the default is 1.5 contexts per thread;
+// scenes whose BVH needs a deep traversal stack (4 KB of LDS per stack slot) use the 1024-context layout.
+template <int CTX>
+struct QLayout {
+  static constexpr int ctx = CTX;
+  static constexpr int ring = CTX <= 1024 ? 1024 : 2048;  // ring capacity (power of two >= CTX)
+  static constexpr int off_ctl = 0;
+  static constexpr int off_ring = off_ctl + QC_WORDS;  // QS_COUNT rings of `ring` dwords (id + 1, 0 = empty)
+  static constexpr int off_state = off_ring + QS_COUNT * ring;
+  static constexpr int off_sobol = off_state + kQFields * CTX;
+  static constexpr int off_win = off_sobol + kLdsSamplerDims * 256 / 4;
+  static constexpr int off_stack = off_win + kQWinDwords * kQBlock;
+  static constexpr size_t fixed_bytes = size_t(off_stack) * 4;
+};
 
 // per-context global record: the pixel's RNG state (2 x u64).  The sampler's per-pixel ranking and
 // scrambling bytes are read straight from the 256 KB tables (L2-resident, shared by every context).
@@ -60,10 +64,13 @@ constexpr int kQCtxGlobalDwords = 4;
 
 // Not instantiated with F_SSS: the BSSRDF beta channel per pending level is not carried by the
 // contexts (scenes with Subsurface materials run path_trace_kernel).
-template <unsigned F>
+template <unsigned F, int CTX = PINE_QCTX>
 __global__ void __launch_bounds__(kQBlock, kQBlock / 256)
 path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
+  using L = QLayout<CTX>;
+  constexpr int kQCtx = L::ctx, kQRing = L::ring, kQOffCtl = L::off_ctl, kQOffRing = L::off_ring, kQOffState = L::off_state,
+                kQOffSobol = L::off_sobol, kQOffWin = L::off_win, kQOffStack = L::off_stack;
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63;
