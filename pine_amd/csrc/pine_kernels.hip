@@ -128,7 +128,9 @@ struct WorkParams {
   int num_local_tiles;   // tiles owned by this shard
   int shard_rank, shard_world;
   int samples_per_item;  // k
-  int items_per_pixel;   // spp / k
+  int items_per_pixel;   // spp / k (a power of two)
+  int log2_items_per_pixel;
+  unsigned tiles_x_magic;  // ceil(2^32 / tiles_x): see decode_item
   unsigned long long total_items;  // num_local_tiles * items_per_pixel * 64
 };
 
@@ -289,10 +291,16 @@ __device__ __forceinline__ ItemInfo decode_item(const WorkParams& W, int film_w,
   ItemInfo it;
   const int p = int(item & 63);
   const unsigned long long tc = item >> 6;
-  const int chunk = int(tc % (unsigned)W.items_per_pixel);
-  const int ltile = int(tc / (unsigned)W.items_per_pixel);
+  // spp and k are powers of two: shifts instead of 64-bit divisions (this runs once per camera sample)
+  const int chunk = int(tc & (unsigned long long)(W.items_per_pixel - 1));
+  const int ltile = int(tc >> W.log2_items_per_pixel);
   const int tile = ltile * W.shard_world + W.shard_rank;
-  const int tx = tile % W.tiles_x, ty = tile / W.tiles_x;
+  // tile / tiles_x by multiplication with the rounded-up reciprocal + one fix-up step (exact for any
+  // 32-bit tile: the estimate is never more than one too large)
+  unsigned ty = unsigned((uint64_t(unsigned(tile)) * W.tiles_x_magic) >> 32);
+  if (ty * unsigned(W.tiles_x) > unsigned(tile)) ty--;
+  if (W.tiles_x == 1) ty = unsigned(tile);  // (2^32 / 1 does not fit the 32-bit magic)
+  const int tx = tile - int(ty) * W.tiles_x;
   it.px = tx * kTile + (p & 7);
   it.py = ty * kTile + (p >> 3);
   it.chunk = chunk;
@@ -1426,6 +1434,9 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   W.num_local_tiles = (total_tiles - prm->shard_rank + prm->shard_world - 1) / prm->shard_world;
   W.samples_per_item = kspi;
   W.items_per_pixel = spp / kspi;
+  W.log2_items_per_pixel = 0;
+  while ((1 << W.log2_items_per_pixel) < W.items_per_pixel) W.log2_items_per_pixel++;
+  W.tiles_x_magic = unsigned(((1ull << 32) + unsigned(W.tiles_x) - 1) / unsigned(W.tiles_x));  // tiles_x >= 1
   W.total_items = (unsigned long long)W.num_local_tiles * W.items_per_pixel * 64ull;
 
   hipDeviceProp_t prop;
