@@ -930,8 +930,9 @@ static const QueueVariant kQueueVariants[] = {
 #ifndef PINE_ONLY_CBOX_VARIANT
     PINE_QV(kFAnalytic | F_LDS_SCENE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS"),
     PINE_QV(kFAnalytic, PINE_QCTX, "queue: analytic shapes/uber"),
-    // big scenes: node-graph materials allowed, 1024 contexts so that a deep traversal stack fits the LDS
-    PINE_QV(kFAnalytic | F_NODES, 1024, "queue: analytic shapes/uber/nodes, 1024 contexts (deep BVH)"),
+    // everything except Subsurface (meshes, node-graph materials, every light kind); 1024 contexts so that
+    // a deep traversal stack (4 KB of LDS per slot, two BVH levels for meshes) fits
+    PINE_QV((F_ALL & ~F_SSS), 1024, "queue: all but SSS, 1024 contexts (deep BVH)"),
 #endif
 };
 constexpr int kNumQueueVariants = int(sizeof(kQueueVariants) / sizeof(kQueueVariants[0]));
@@ -1385,7 +1386,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   {
     const char* ksel = getenv("PINE_GPU_KERNEL");
     const bool want_queue = !(ksel && std::string(ksel) == "mega");
-    if (want_queue && !(need & (F_SSS | F_MESH))) {
+    if (want_queue && !(need & F_SSS)) {
       for (int v = 0; v < kNumQueueVariants; v++) {
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;

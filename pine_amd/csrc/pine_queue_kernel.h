@@ -63,7 +63,8 @@ struct QLayout {
 constexpr int kQCtxGlobalDwords = 4;
 
 // Not instantiated with F_SSS: the BSSRDF beta channel per pending level is not carried by the
-// contexts (scenes with Subsurface materials run path_trace_kernel).
+// contexts (scenes with Subsurface materials run path_trace_kernel).  Everything else -- meshes, node
+// graphs, delta lights, the environment light -- is covered by the "all but SSS" variant.
 template <unsigned F, int CTX = PINE_QCTX>
 __global__ void __launch_bounds__(kQBlock, kQBlock / 256)
 path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
@@ -426,10 +427,54 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         if (!bxdf_is_delta<F>(bx)) {
           const f2 u2 = sampler_get2d<true>(T, sampler);  // g++ order: get2d first (lightsampler.h:27)
           float u1 = sampler_get1d<true>(T, sampler);
-          if (S.num_lights > 0) {
+          if constexpr (F & F_LIGHTS) {
+            // general light list (light.cpp:11-84): area lights, delta lights (no MIS, path.cpp:104-106), Sky
+            if (S.num_lights > 0) {
+              if (S.num_lights != 1) u1 *= float(S.num_lights);
+              const int index = int(u1);
+              const DLight* L = &V.lights[index];
+              const int lkind = L->kind;
+              bool lvalid = false;
+              f3 lw = mk3(0.0f), lle = mk3(0.0f);
+              float ldist = 0.0f, lpdf = 0.0f;
+              if (lkind == LIGHT_AREA) {
+                const DShape* lshape = &V.shapes[L->geom];
+                DShapeSample gs;
+                if (shape_sample<F>(lshape, V.tri_verts, it.p, u2, u1 - float(index), gs)) {
+                  lle = material_le(&V.materials[lshape->material], gs.n, -gs.w);
+                  lvalid = !is_zero(lle);
+                  lw = gs.w;
+                  ldist = gs.distance;
+                  lpdf = gs.pdf;
+                }
+              } else {
+                lvalid = light_sample_other(L, it.p, u2, lw, ldist, lpdf, lle);
+              }
+              const bool ldelta = lkind == LIGHT_POINT || lkind == LIGHT_SPOT || lkind == LIGHT_DIRECTIONAL;
+              if (lvalid) {
+                const float ls_pdf = S.num_lights != 1 ? lpdf / float(S.num_lights) : lpdf;
+                shadow_count++;
+                DRay sr = spawn_ray(it.p, it.n, lw, ldist);
+                int g2, p2;
+                if (!scene_traverse<true, F, kQBlock>(V, sr, stack, g2, p2)) {
+                  bx.albedo = mp.albedo;
+                  bx.albedo_over_pi = mp.albedo_over_pi;
+                  const float cosine = absdot(lw, it.n);
+                  const f3 wo = mul(w2l, lw);
+                  const f3 f = bxdf_f<F>(bx, wo);
+                  if (ldelta) {
+                    nee = mk3(0.0f) + lle * mk3(1.0f) * cosine * f / ls_pdf;
+                  } else {
+                    const float mis = balance_heuristic(ls_pdf, bxdf_pdf<F>(bx, wo));
+                    nee = mk3(0.0f) + lle * mk3(1.0f) * cosine * f / ls_pdf * mis;
+                  }
+                }
+              }
+            }
+          } else if (S.num_lights > 0) {
             if (S.num_lights != 1) u1 *= float(S.num_lights);
             const int index = int(u1);
-            const DShape* lshape = &V.shapes[V.lights[index].geom];  // (no F_LIGHTS variants of this kernel: area lights only)
+            const DShape* lshape = &V.shapes[V.lights[index].geom];  // (no other light kinds in this variant)
             DShapeSample gs;
             if (shape_sample<F>(lshape, V.tri_verts, it.p, u2, u1 - float(index), gs)) {
               const DMaterial* lmat = &V.materials[lshape->material];
@@ -512,6 +557,16 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           float lp = 0.0f;
           if (geom == -2) {
             Lo = f3{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
+          } else if (geom == -1) {  // miss: the environment light, if any (path.cpp:75-81)
+            if constexpr (F & F_LIGHTS)
+              if (S.env_light >= 0) {
+                const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
+                Lo = mk3(1.0f) * sky_color_of(ld3(V.lights[S.env_light].color), ray_d);
+                if (!st.is_delta()) {
+                  lp_valid = true;
+                  lp = 1 / (4 * kPi);  // Sky::pdf -- not divided by the light count
+                }
+              }
           } else if (geom >= 0 && (geom & kPrimEmissiveBit) != 0) {
             const DShape* shape = &V.shapes[geom & kPrimIndexMask];
             const DMaterial* mat = &V.materials[shape->material];

@@ -100,7 +100,7 @@ def icosphere(subdiv=3, radius=0.4, center=(0.0, 0.5, 1.0)):
     return verts, np.array(f, dtype=np.uint32)
 
 
-def sss(size=(640, 640), subdiv=3, camera="readme"):
+def sss(size=(640, 640), subdiv=3, camera="readme", skin=None, emissive_mesh=False):
     """Config C5: Rect-only cbox room + one closed icosphere mesh (1280 triangles at
     subdiv=3) with Subsurface([1,1,1], 0.0, [40,40,40]) + the cbox emissive Rect."""
     scene = Scene()
@@ -108,7 +108,7 @@ def sss(size=(640, 640), subdiv=3, camera="readme"):
     scene.add("blue", Diffuse([0.2, 0.5, 0.9]))
     scene.add("red", Diffuse([0.9, 0.1, 0.05]))
     scene.add("green", Diffuse([0.2, 0.9, 0.05]))
-    scene.add("skin", Subsurface([1, 1, 1], 0.0, [40, 40, 40]))
+    scene.add("skin", skin if skin is not None else Subsurface([1, 1, 1], 0.0, [40, 40, 40]))
     scene.add(Rect([0, 0, 1], [2, 0, 0], [0, 0, 2], True), "floor")
     scene.add(Rect([0, 2, 1], [2, 0, 0], [0, 0, 2]), "floor")
     scene.add(Rect([-1, 1, 1], [0, 0, 2], [0, 2, 0], True), "red")
@@ -116,6 +116,9 @@ def sss(size=(640, 640), subdiv=3, camera="readme"):
     scene.add(Rect([0, 1, 2], [2, 0, 0], [0, 2, 0], True), "blue")
     verts, faces = icosphere(subdiv)
     scene.add(Mesh(verts, faces), "skin")
+    if emissive_mesh:  # a second, small mesh as an area light (Mesh::sample picks a triangle, geometry.h:170-178)
+        v2, f2 = icosphere(1, 0.12, (-0.5, 1.5, 0.6))
+        scene.add(Mesh(v2, f2), Emissive([30.0, 24.0, 12.0]))
     le = (np.float32(600) * np.array([1.0, 0.64, 0.185], dtype=np.float32)).tolist()
     scene.add(Rect([0.0, 1.9, 1], [0.1, 0, 0], [0, 0, 0.1]), Emissive(le))
     frm, to, fov = CAMERAS[camera]

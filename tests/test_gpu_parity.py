@@ -132,6 +132,7 @@ LIBM_TOLERANCE_FILMS = set()  # (was {"mats_zoo_64_s32_d6"} until powf/logf beca
 
 
 def _scene_for(name):
+    import pine_amd as pa
     from pine_amd import scenes
     return {
         "cbox_committed_64_s16_d4": lambda: scenes.cbox((64, 64), "committed"),
@@ -147,6 +148,7 @@ def _scene_for(name):
         "classic_checker_cones8_90x45_s32_d6": lambda: scenes.classic_cones((90, 45), 8, checker_floor=True),
         "lights_zoo_64_s32_d6": lambda: scenes.lights_zoo((64, 64)),
         "lights_nosky_48_s16_d4": lambda: scenes.lights_zoo((48, 48), with_sky=False),
+        "mesh_glossy_48_s32_d6": lambda: scenes.sss((48, 48), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True),
     }[name]()
 
 

@@ -17,6 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import pine_amd as pa  # noqa: E402
 from pine_amd import scenes  # noqa: E402  (scene construction only: host code, no GPU)
 
 REF = os.path.join(ROOT, "oracle", "_ref", "pine_ref")
@@ -53,6 +54,8 @@ FILMS = {
     # Point / Spot / Directional lights + Sky environment light (light.h, path.cpp:75-81,104-106)
     "lights_zoo_64_s32_d6": (lambda: scenes.lights_zoo((64, 64)), 32, 6),
     "lights_nosky_48_s16_d4": (lambda: scenes.lights_zoo((48, 48), with_sky=False), 16, 4),
+    # triangle meshes without Subsurface (two-level BVH, mesh area light): the stage-queued kernel's mesh path
+    "mesh_glossy_48_s32_d6": (lambda: scenes.sss((48, 48), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True), 32, 6),
 }
 
 
