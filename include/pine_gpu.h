@@ -126,6 +126,18 @@ int pine_gpu_scene_add_disk(pine_gpu_scene*, const float position[3], const floa
 int pine_gpu_scene_add_cone(pine_gpu_scene*, const float position[3], const float normal[3],
                             float radius, float height, int material);
                                          /* Cone(vec3,vec3,float,float) geometry.cpp:409-414 */
+int pine_gpu_scene_add_plane(pine_gpu_scene*, const float position[3], const float normal[3], int material);
+                                         /* Plane(vec3,vec3)          geometry.cpp:31-34   */
+int pine_gpu_scene_add_line(pine_gpu_scene*, const float p0[3], const float p1[3], float thickness,
+                            int material);
+                                         /* Line(vec3,vec3,float)     geometry.cpp:171-179 */
+int pine_gpu_scene_add_cylinder(pine_gpu_scene*, const float p0[3], const float p1[3], float radius,
+                                int material);
+                                         /* Cylinder(vec3,vec3,float) geometry.h:140-141 (side surface only;
+                                            not usable as a light, as in the reference)    */
+int pine_gpu_scene_add_triangle(pine_gpu_scene*, const float v0[3], const float v1[3], const float v2[3],
+                                int material);
+                                         /* Triangle(vec3,vec3,vec3)  geometry.cpp:528-531 */
 int pine_gpu_scene_add_mesh(pine_gpu_scene*, const float* vertices, int num_vertices,
                             const uint32_t* indices, int num_triangles, int material);
                                          /* Mesh(vertices, indices)   geometry.cpp:601-609 */

@@ -893,6 +893,164 @@ struct Cone {  // geometry.cpp:409-464, geometry.h:122-142
   AABB get_aabb() const { return bottom.get_aabb().extend(p); }  // geometry.h:129
 };
 
+vec3 uniform_hemisphere(vec2 u) {  // sampling.h:56-62
+  const float phi = u.x * Pi * 2;
+  const float cos_theta = u.y;
+  const float sin_theta = std::sqrt(1.0f - sqr(cos_theta));
+  return vec3(sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta);
+}
+
+struct Plane {  // geometry.cpp:31-70
+  vec3 position, n, u, v;
+  Plane(vec3 p, vec3 normal) : position(p), n(normalize(normal)) { coordinate_system(n, u, v); }
+  bool hit(const Ray& ray) const {  // :35-39
+    float t = (dot(position, n) - dot(ray.o, n)) / dot(ray.d, n);
+    if (t <= ray.tmin) return false;
+    return t < ray.tmax;
+  }
+  bool intersect(Ray& ray) const {  // :40-45
+    float t = (dot(position, n) - dot(ray.o, n)) / dot(ray.d, n);
+    if (t < ray.tmin || t > ray.tmax) return false;
+    ray.tmax = t;
+    return true;
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {  // :46-51
+    it.n = n;
+    vec3 dp = p - position;
+    it.uv = vec2(dot(dp, u), dot(dp, v));
+    it.p = position + it.uv.x * u + it.uv.y * v;
+  }
+  AABB get_aabb() const { return {position + vec3(-100.0f), position + vec3(100.0f)}; }  // :52
+  ShapeSample sample(vec3 p, vec2 u2) const {  // :57-69
+    ShapeSample ss;
+    vec3 p_sphere = uniform_hemisphere(u2);
+    float l = absdot(p - position, n);
+    float ex = l * p_sphere.x / p_sphere.z;
+    float ey = l * p_sphere.y / p_sphere.z;
+    vec3 dp = p - position;  // project_to_plane :53-56
+    ss.p = (position + u * dot(u, dp) + v * dot(v, dp)) + u * ex + v * ey;
+    ss.n = n;
+    ss.uv = {ex, ey};
+    ss.w = normalize(ss.p - p, ss.distance);
+    ss.pdf = 1.0f / (2 * Pi);
+    return ss;
+  }
+  float pdf() const { return 1.0f / (2 * Pi); }  // :70
+};
+
+struct Line {  // geometry.cpp:171-244
+  vec3 p0, p1;
+  mat3 tbn;
+  float thickness, len;
+  Line(vec3 a, vec3 b, float th)
+      : p0(a), p1(b), tbn(coordinate_system(normalize(b - a))), thickness(th), len(length(b - a)) {}
+  float area() const { return thickness * 2 * Pi * len; }  // geometry.h:70
+  // the closest approach of the segment to the ray axis, in the ray's look_at frame (:181-192, :197-208)
+  bool closest(const Ray& ray, float& z) const {
+    mat4 r2o = look_at(ray.o, ray.o + ray.d);
+    mat4 o2r = inverse(r2o);
+    vec3 q0 = o2r * p0;  // mat4 * vec3 and vec3{mat4 * vec4(p,1)} are the same arithmetic (vecmath.h:700-707)
+    vec3 q1 = o2r * p1;
+    vec3 o = q0;
+    vec3 d = q1 - q0;
+    // inverse(mat2(dot(d,d), -d.z, -d.z, 1)) * vec2(-dot(o,d), o.z)   (vecmath.h:1079-1087): only .x is used
+    float m00 = dot(d, d), m01 = -d.z, m10 = -d.z, m11 = 1.0f;  // m[c][r]
+    float det = m00 * m11 - m10 * m01;
+    float ix0 = m11 / det, iy0 = -m10 / det;  // row 0 of the inverse: x[0], y[0]
+    float b0 = -dot(o, d), b1 = o.z;
+    float tzx = ix0 * b0 + iy0 * b1;
+    float t = clampf(tzx, 0.0f, 1.0f);
+    z = clampf(o.z + t * d.z, ray.tmin + thickness, ray.tmax);
+    float D = length(o + t * d - vec3(0.0f, 0.0f, z));
+    return D <= thickness;
+  }
+  bool hit(const Ray& ray) const {
+    float z;
+    return closest(ray, z);
+  }
+  bool intersect(Ray& ray) const {
+    float z;
+    if (!closest(ray, z)) return false;
+    ray.tmax = z;
+    return true;
+  }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {  // :215-222
+    float lt = dot(p - p0, tbn.z);
+    vec3 lp = lt * p1 + (1.0f - lt) * p0;  // lerp(lt, p0, p1) vecmath.h:877-880
+    it.p = p;
+    it.n = normalize(p - lp);
+    it.uv = {lt, 0.0f};
+  }
+  ShapeSample sample(vec3 p, vec2 u2) const {  // :223-233
+    ShapeSample ss;
+    float phi = u2[1] * 2 * Pi;
+    ss.p = (u2[0] * p1 + (1.0f - u2[0]) * p0) + thickness * std::cos(phi) * tbn.x +
+           thickness * std::sin(phi) * tbn.y;
+    ss.n = std::cos(phi) * tbn.x + std::sin(phi) * tbn.y;
+    ss.uv = u2;
+    ss.w = normalize(ss.p - p, ss.distance);
+    ss.pdf = sqr(ss.distance) / (absdot(ss.w, ss.n) * area());
+    return ss;
+  }
+  float pdf(const Ray& ray, vec3 ns) const {  // :234-236
+    return sqr(ray.tmax) / (area() * absdot(ns, ray.d));
+  }
+  AABB get_aabb() const {  // :237-244
+    AABB aabb;
+    aabb.extend(p0 - vec3(thickness));
+    aabb.extend(p1 - vec3(thickness));
+    aabb.extend(p0 + vec3(thickness));
+    aabb.extend(p1 + vec3(thickness));
+    return aabb;
+  }
+};
+
+struct Cylinder {  // geometry.h:139-157, geometry.cpp:466-523: lateral surface only, no caps
+  vec3 p0, p1, n;
+  float r;
+  Cylinder(vec3 a, vec3 b, float r) : p0(a), p1(b), n(normalize(b - a)), r(r) {}
+  bool solve(const Ray& ray, float& t, vec3& hit_point, vec3& projection) const {  // :467-488 == :491-511
+    vec3 m = ray.o - p0;
+    vec3 v = ray.d - dot(ray.d, n) * n;
+    vec3 w = m - dot(m, n) * n;
+    float a = dot(v, v);
+    float b = 2 * dot(v, w);
+    float c = dot(w, w) - r * r;
+    float discriminant = b * b - 4 * a * c;
+    if (discriminant < 0) return false;
+    float sqrtDisc = std::sqrt(discriminant);
+    t = (-b - sqrtDisc) / (2 * a);
+    if (t < ray.tmin) t = (-b + sqrtDisc) / (2 * a);
+    if (t > ray.tmax) return false;
+    hit_point = ray(t);
+    projection = p0 + dot(hit_point - p0, n) * n;
+    if (dot(projection - p0, n) < 0 || dot(projection - p1, n) > 0) return false;
+    return true;
+  }
+  bool hit(const Ray& ray) const {
+    float t;
+    vec3 hp, pr;
+    return solve(ray, t, hp, pr);
+  }
+  // Cylinder::intersect writes it.n / it.p itself and compute_surface_info is empty (:512-523); the
+  // winning shape's intersect is always the last one that succeeded, so the values it left are the
+  // ones recomputed here from the final ray (same t, same ray -> same bits)
+  bool intersect(Ray& ray) const {
+    float t;
+    vec3 hp, pr;
+    if (!solve(ray, t, hp, pr)) return false;
+    ray.tmax = t;
+    return true;
+  }
+  void compute_surface_info(vec3 hit_point, SurfaceInteraction& it) const {
+    vec3 projection = p0 + dot(hit_point - p0, n) * n;
+    it.n = normalize(hit_point - projection);
+    it.p = hit_point;
+  }
+  // bottom(p0,-n,r), top(p0,n,r): both cap disks sit at p0 (geometry.h:141), so the box ignores p1
+  AABB get_aabb() const { return union_(Disk(p0, -n, r).get_aabb(), Disk(p0, n, r).get_aabb()); }
+};
+
 struct Tri {  // geometry.cpp:525-599 (static helpers)
   static bool hit(const Ray& ray, vec3 v0, vec3 v1, vec3 v2) {  // :532-547
     vec3 E1 = v1 - v0, E2 = v2 - v0, T = ray.o - v0;
@@ -921,6 +1079,43 @@ struct Tri {  // geometry.cpp:525-599 (static helpers)
     if (u + v > 1.0f) return false;
     ray.tmax = t;
     return true;
+  }
+};
+
+struct Triangle {  // the stand-alone shape, geometry.cpp:525-595
+  vec3 v0, v1, v2, n;
+  Triangle(vec3 a, vec3 b, vec3 c) : v0(a), v1(b), v2(c), n(normalize(cross(a - b, a - c))) {
+    if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f) n = vec3(0, 0, 1);
+  }
+  float area() const { return length(cross(v1 - v0, v2 - v0)) / 2; }  // geometry.h:113
+  bool hit(const Ray& ray) const { return Tri::hit(ray, v0, v1, v2); }
+  bool intersect(Ray& ray) const { return Tri::intersect(ray, v0, v1, v2); }
+  void compute_surface_info(vec3 p, SurfaceInteraction& it) const {  // :568-574 (uv are plain dot products)
+    float u = dot(p - v0, v1 - v0);
+    float v = dot(p - v0, v2 - v0);
+    it.uv = vec2(u, v);
+    it.p = lerp3(it.uv[0], it.uv[1], v0, v1, v2);
+    it.n = n;
+  }
+  ShapeSample sample(vec3 p, vec2 u) const {  // :575-584
+    ShapeSample ss;
+    if (u.x + u.y > 1.0f) u = vec2(1.0f, 1.0f) - u;
+    ss.p = lerp3(u.x, u.y, v0, v1, v2);
+    ss.n = n;
+    ss.uv = u;
+    ss.w = normalize(ss.p - p, ss.distance);
+    ss.pdf = sqr(ss.distance) / fmax_(absdot(ss.w, ss.n) * area(), kEpsilon);
+    return ss;
+  }
+  float pdf(const Ray& ray, vec3 ns) const {  // :585-587
+    return sqr(ray.tmax) / (area() * absdot(ns, ray.d));
+  }
+  AABB get_aabb() const {  // :588-594
+    AABB aabb;
+    aabb.extend(v0);
+    aabb.extend(v1);
+    aabb.extend(v2);
+    return aabb;
   }
 };
 
@@ -1443,7 +1638,7 @@ struct Material {
 // ------------------------------------------------------------------------------------------------
 // Geometry variant + Scene
 // ------------------------------------------------------------------------------------------------
-enum ShapeKind { S_RECT, S_AABB, S_OBB, S_SPHERE, S_DISK, S_CONE, S_MESH };
+enum ShapeKind { S_RECT, S_AABB, S_OBB, S_SPHERE, S_DISK, S_CONE, S_MESH, S_PLANE, S_LINE, S_CYLINDER, S_TRIANGLE };
 struct Geometry {
   ShapeKind kind;
   std::shared_ptr<void> impl;
@@ -1457,6 +1652,10 @@ struct Geometry {
       case S_SPHERE: return as<Sphere>().hit(r);
       case S_DISK: return as<Disk>().hit(r);
       case S_CONE: return as<Cone>().hit(r);
+      case S_PLANE: return as<Plane>().hit(r);
+      case S_LINE: return as<Line>().hit(r);
+      case S_CYLINDER: return as<Cylinder>().hit(r);
+      case S_TRIANGLE: return as<Triangle>().hit(r);
       default: return false;
     }
   }
@@ -1468,6 +1667,10 @@ struct Geometry {
       case S_SPHERE: return as<Sphere>().intersect(r);
       case S_DISK: return as<Disk>().intersect(r);
       case S_CONE: return as<Cone>().intersect(r);
+      case S_PLANE: return as<Plane>().intersect(r);
+      case S_LINE: return as<Line>().intersect(r);
+      case S_CYLINDER: return as<Cylinder>().intersect(r);
+      case S_TRIANGLE: return as<Triangle>().intersect(r);
       default: return false;
     }
   }
@@ -1479,6 +1682,10 @@ struct Geometry {
       case S_SPHERE: as<Sphere>().compute_surface_info(p, it); break;
       case S_DISK: as<Disk>().compute_surface_info(p, it); break;
       case S_CONE: as<Cone>().compute_surface_info(p, it); break;
+      case S_PLANE: as<Plane>().compute_surface_info(p, it); break;
+      case S_LINE: as<Line>().compute_surface_info(p, it); break;
+      case S_CYLINDER: as<Cylinder>().compute_surface_info(p, it); break;
+      case S_TRIANGLE: as<Triangle>().compute_surface_info(p, it); break;
       default: break;
     }
   }
@@ -1490,6 +1697,10 @@ struct Geometry {
       case S_SPHERE: return as<Sphere>().get_aabb();
       case S_DISK: return as<Disk>().get_aabb();
       case S_CONE: return as<Cone>().get_aabb();
+      case S_PLANE: return as<Plane>().get_aabb();
+      case S_LINE: return as<Line>().get_aabb();
+      case S_CYLINDER: return as<Cylinder>().get_aabb();
+      case S_TRIANGLE: return as<Triangle>().get_aabb();
       default: return AABB();
     }
   }
@@ -1499,6 +1710,9 @@ struct Geometry {
       case S_RECT: ss = as<Rect>().sample(p, u); break;
       case S_SPHERE: ss = as<Sphere>().sample(p, u); break;
       case S_DISK: ss = as<Disk>().sample(p, u); break;
+      case S_PLANE: ss = as<Plane>().sample(p, u); break;
+      case S_LINE: ss = as<Line>().sample(p, u); break;
+      case S_TRIANGLE: ss = as<Triangle>().sample(p, u); break;
       case S_MESH: {  // geometry.h:170-178
         const Mesh& m = as<Mesh>();
         if (m.num_triangles() == 0) return false;
@@ -1517,6 +1731,9 @@ struct Geometry {
       case S_SPHERE: return as<Sphere>().pdf(ray);
       case S_DISK: return as<Disk>().pdf(ray, ns);
       case S_CONE: return as<Cone>().pdf(ray, ns);
+      case S_PLANE: return as<Plane>().pdf();
+      case S_LINE: return as<Line>().pdf(ray, ns);
+      case S_TRIANGLE: return as<Triangle>().pdf(ray, ns);
       case S_MESH: return as<Mesh>().pdf(ray, ns);
       default: return 0.0f;
     }
@@ -2263,6 +2480,24 @@ bool parse_pscene(const char* text, Scene& scene) {
         float r = rdf(in), h = rdf(in);
         g.kind = S_CONE;
         g.impl = std::make_shared<Cone>(p, n, r, h);
+      } else if (kind == "plane") {
+        vec3 p = rd3(in), n = rd3(in);
+        g.kind = S_PLANE;
+        g.impl = std::make_shared<Plane>(p, n);
+      } else if (kind == "line") {
+        vec3 a = rd3(in), b = rd3(in);
+        float th = rdf(in);
+        g.kind = S_LINE;
+        g.impl = std::make_shared<Line>(a, b, th);
+      } else if (kind == "cylinder") {
+        vec3 a = rd3(in), b = rd3(in);
+        float r = rdf(in);
+        g.kind = S_CYLINDER;
+        g.impl = std::make_shared<Cylinder>(a, b, r);
+      } else if (kind == "triangle") {
+        vec3 a = rd3(in), b = rd3(in), c = rd3(in);
+        g.kind = S_TRIANGLE;
+        g.impl = std::make_shared<Triangle>(a, b, c);
       } else if (kind == "mesh") {
         int nv, nt;
         in >> nv >> nt;

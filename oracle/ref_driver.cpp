@@ -199,6 +199,20 @@ static void load_pscene(const char* path, Loaded& out) {
         auto p = rd3(in), n = rd3(in);
         float r = rdf(in), h = rdf(in);
         scene.add_geometry(Cone(p, n, r, h), psl::string(mat.c_str()));
+      } else if (kind == "plane") {
+        auto p = rd3(in), n = rd3(in);
+        scene.add_geometry(Plane(p, n), psl::string(mat.c_str()));
+      } else if (kind == "line") {
+        auto a = rd3(in), b = rd3(in);
+        float th = rdf(in);
+        scene.add_geometry(Line(a, b, th), psl::string(mat.c_str()));
+      } else if (kind == "cylinder") {
+        auto a = rd3(in), b = rd3(in);
+        float r = rdf(in);
+        scene.add_geometry(Cylinder(a, b, r), psl::string(mat.c_str()));
+      } else if (kind == "triangle") {
+        auto a = rd3(in), b = rd3(in), c = rd3(in);
+        scene.add_geometry(Triangle(a, b, c), psl::string(mat.c_str()));
       } else if (kind == "mesh") {
         int nv, nt;
         in >> nv >> nt;

@@ -100,6 +100,10 @@ SIGNATURES = {
     "pine_gpu_scene_add_sphere": (C.c_int, [C.c_void_p, f3, C.c_float, C.c_int]),
     "pine_gpu_scene_add_disk": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_int]),
     "pine_gpu_scene_add_cone": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_float, C.c_int]),
+    "pine_gpu_scene_add_plane": (C.c_int, [C.c_void_p, f3, f3, C.c_int]),
+    "pine_gpu_scene_add_line": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_int]),
+    "pine_gpu_scene_add_cylinder": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_int]),
+    "pine_gpu_scene_add_triangle": (C.c_int, [C.c_void_p, f3, f3, f3, C.c_int]),
     "pine_gpu_scene_add_mesh": (C.c_int, [C.c_void_p, c_f_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int]),
     "pine_gpu_scene_set_camera_thinlens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f3, f3, C.c_float, C.c_float, C.c_float]),
     "pine_gpu_scene_describe": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),

@@ -303,6 +303,30 @@ class Cone(Shape):
         self.position, self.normal, self.radius, self.height = position, normal, radius, height
 
 
+class Plane(Shape):
+    """Plane(position, normal) geometry.cpp:31-34 (its bounding box is position +-100, geometry.cpp:52)"""
+    def __init__(self, position, normal):
+        self.position, self.normal = position, normal
+
+
+class Line(Shape):
+    """Line(p0, p1, thickness) geometry.cpp:171-179"""
+    def __init__(self, p0, p1, thickness):
+        self.p0, self.p1, self.thickness = p0, p1, thickness
+
+
+class Cylinder(Shape):
+    """Cylinder(p0, p1, r) geometry.h:139-157: side surface only, never a light"""
+    def __init__(self, p0, p1, radius):
+        self.p0, self.p1, self.radius = p0, p1, radius
+
+
+class Triangle(Shape):
+    """Triangle(v0, v1, v2) geometry.cpp:528-531"""
+    def __init__(self, v0, v1, v2):
+        self.v0, self.v1, self.v2 = v0, v1, v2
+
+
 class Mesh(Shape):
     def __init__(self, vertices, indices):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
@@ -466,6 +490,14 @@ class Scene:
             return check(lib.pine_gpu_scene_add_disk(h, _v3(s.position), _v3(s.normal), float(s.radius), mid), "Disk")
         if isinstance(s, Cone):
             return check(lib.pine_gpu_scene_add_cone(h, _v3(s.position), _v3(s.normal), float(s.radius), float(s.height), mid), "Cone")
+        if isinstance(s, Plane):
+            return check(lib.pine_gpu_scene_add_plane(h, _v3(s.position), _v3(s.normal), mid), "Plane")
+        if isinstance(s, Line):
+            return check(lib.pine_gpu_scene_add_line(h, _v3(s.p0), _v3(s.p1), float(s.thickness), mid), "Line")
+        if isinstance(s, Cylinder):
+            return check(lib.pine_gpu_scene_add_cylinder(h, _v3(s.p0), _v3(s.p1), float(s.radius), mid), "Cylinder")
+        if isinstance(s, Triangle):
+            return check(lib.pine_gpu_scene_add_triangle(h, _v3(s.v0), _v3(s.v1), _v3(s.v2), mid), "Triangle")
         if isinstance(s, Mesh):
             return check(lib.pine_gpu_scene_add_mesh(h, s.vertices.ctypes.data_as(_lib.c_f_p), len(s.vertices),
                                                      s.indices.ctypes.data_as(C.POINTER(C.c_uint32)), len(s.indices), mid), "Mesh")

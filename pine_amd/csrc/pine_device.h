@@ -26,7 +26,8 @@ enum : unsigned {
   F_LDS_SCENE = 1u << 8,  // scene records staged in LDS
   F_NODES = 1u << 9,      // material parameters may be shading-node programs (node.h)
   F_LIGHTS = 1u << 10,    // Point / Spot / Directional lights or an environment light are present
-  F_ALL = 0xffu | F_NODES | F_LIGHTS,
+  F_XSHAPES = 1u << 11,   // Plane / Line / Cylinder / stand-alone Triangle
+  F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES,
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -354,6 +355,90 @@ PINE_HD bool cone_quadratic(const float* f, const DRay& ray, float& tmax, float&
   return true;
 }
 
+
+PINE_HD bool tri_hit(const float* v, const DRay& ray);
+PINE_HD bool tri_intersect(const float* v, DRay& ray);
+// ---- Plane / Line / Cylinder (geometry.cpp:31-70, 171-244, 466-523) ---------------------------
+// inverse(mat4) vecmath.cpp:103-132 on column-major m[c][r]; only rows 0..2 of the result are produced
+// (the callers transform points).  Same expression order as the reference, nothing simplified.
+PINE_HD bool mat4_inverse_rows3(const float (&m)[4][4], float (&r)[4][3]) {
+  float det = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    det += (m[(1 + i) % 4][0] * (m[(2 + i) % 4][1] * m[(3 + i) % 4][2] - m[(3 + i) % 4][1] * m[(2 + i) % 4][2]) +
+            m[(2 + i) % 4][0] * (m[(3 + i) % 4][1] * m[(1 + i) % 4][2] - m[(1 + i) % 4][1] * m[(3 + i) % 4][2]) +
+            m[(3 + i) % 4][0] * (m[(1 + i) % 4][1] * m[(2 + i) % 4][2] - m[(2 + i) % 4][1] * m[(1 + i) % 4][2])) *
+           m[i % 4][3] * float(i % 2 ? -1 : 1);
+  if (det == 0) return false;
+#pragma unroll
+  for (int v = 0; v < 4; v++)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      r[v][i] = (m[(1 + i) % 4][(1 + v) % 4] * (m[(2 + i) % 4][(2 + v) % 4] * m[(3 + i) % 4][(3 + v) % 4] -
+                                                 m[(3 + i) % 4][(2 + v) % 4] * m[(2 + i) % 4][(3 + v) % 4]) +
+                 m[(2 + i) % 4][(1 + v) % 4] * (m[(3 + i) % 4][(2 + v) % 4] * m[(1 + i) % 4][(3 + v) % 4] -
+                                                 m[(1 + i) % 4][(2 + v) % 4] * m[(3 + i) % 4][(3 + v) % 4]) +
+                 m[(3 + i) % 4][(1 + v) % 4] * (m[(1 + i) % 4][(2 + v) % 4] * m[(2 + i) % 4][(3 + v) % 4] -
+                                                 m[(2 + i) % 4][(2 + v) % 4] * m[(1 + i) % 4][(3 + v) % 4])) *
+                float((v + i) % 2 ? 1 : -1) / det;
+  return true;
+}
+// Line::hit / intersect share everything up to the acceptance test (geometry.cpp:181-192, 197-208):
+// the segment in the ray's look_at frame, its closest approach to the z axis, clamped to the ray span
+PINE_HD bool line_closest(const float* f, const DRay& ray, float& z) {
+  const f3 up = mk3(0.0f, 1.0f, 0.0f);
+  f3 zz = normalize((ray.o + ray.d) - ray.o);  // look_at(ray.o, ray.o + ray.d) vecmath.h:1172-1180
+  if (pabs(dot(zz, up)) > 0.999f) zz = normalize(zz + mk3(0.0f, 0.0f, 1e-5f));
+  const f3 xx = normalize(cross(up, zz));
+  const f3 yy = cross(zz, xx);
+  const float m[4][4] = {{xx.x, xx.y, xx.z, 0.0f}, {yy.x, yy.y, yy.z, 0.0f}, {zz.x, zz.y, zz.z, 0.0f},
+                         {ray.o.x, ray.o.y, ray.o.z, 1.0f}};
+  float r[4][3];
+  if (!mat4_inverse_rows3(m, r)) {  // inverse() returns the identity for a singular matrix
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) r[c][k] = c == k ? 1.0f : 0.0f;
+  }
+  const f3 cx = mk3(r[0][0], r[0][1], r[0][2]), cy = mk3(r[1][0], r[1][1], r[1][2]),
+           cz = mk3(r[2][0], r[2][1], r[2][2]), cw = mk3(r[3][0], r[3][1], r[3][2]);
+  const f3 a = ld3(f), b = ld3(f + 3);
+  const f3 o = cx * a.x + cy * a.y + cz * a.z + cw;  // mat4 * vec3 vecmath.h:705
+  const f3 q1 = cx * b.x + cy * b.y + cz * b.z + cw;
+  const f3 d = q1 - o;
+  // inverse(mat2(dot(d,d), -d.z, -d.z, 1)) * vec2(-dot(o,d), o.z): only .x is read
+  const float m00 = dot(d, d), m01 = -d.z, m10 = -d.z, m11 = 1.0f;
+  const float det2 = m00 * m11 - m10 * m01;
+  const float ix0 = m11 / det2, iy0 = -m10 / det2;
+  const float b0 = -dot(o, d), b1 = o.z;
+  const float t = pclamp(ix0 * b0 + iy0 * b1, 0.0f, 1.0f);
+  const float th = f[15];
+  z = pclamp(o.z + t * d.z, ray.tmin + th, ray.tmax);
+  const float D = length(o + t * d - mk3(0.0f, 0.0f, z));
+  return D <= th;
+}
+// Cylinder::hit == the acceptance part of Cylinder::intersect (geometry.cpp:466-511): side surface only
+PINE_HD bool cylinder_solve(const float* f, const DRay& ray, float& t) {
+  const f3 p0 = ld3(f), p1 = ld3(f + 3), n = ld3(f + 6);
+  const float r = f[9];
+  const f3 m = ray.o - p0;
+  const f3 v = ray.d - dot(ray.d, n) * n;
+  const f3 w = m - dot(m, n) * n;
+  const float a = dot(v, v);
+  const float b = 2 * dot(v, w);
+  const float c = dot(w, w) - r * r;
+  const float discriminant = b * b - 4 * a * c;
+  if (discriminant < 0) return false;
+  const float sqrtDisc = psqrt(discriminant);
+  t = (-b - sqrtDisc) / (2 * a);
+  if (t < ray.tmin) t = (-b + sqrtDisc) / (2 * a);
+  if (t > ray.tmax) return false;
+  const f3 hit_point = ray_at(ray, t);
+  const f3 projection = p0 + dot(hit_point - p0, n) * n;
+  if (dot(projection - p0, n) < 0 || dot(projection - p1, n) > 0) return false;
+  return true;
+}
+
 template <unsigned F = F_ALL>
 PINE_HD bool shape_hit(int kind, const DShape* S, const DRay& ray) {
   const float* f = S->f;
@@ -393,6 +478,21 @@ PINE_HD bool shape_hit(int kind, const DShape* S, const DRay& ray) {
       float tmax, side;
       return cone_quadratic(f, ray, tmax, side) && side <= 0;
     }
+    case SHAPE_PLANE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:35-39
+      const f3 position = ld3(f), n = ld3(f + 3);
+      const float t = (dot(position, n) - dot(ray.o, n)) / dot(ray.d, n);
+      if (t <= ray.tmin) return false;
+      return t < ray.tmax;
+    }
+    case SHAPE_LINE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:180-195
+      float z;
+      return line_closest(f, ray, z);
+    }
+    case SHAPE_CYLINDER: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:466-489
+      float t;
+      return cylinder_solve(f, ray, t);
+    }
+    case SHAPE_TRIANGLE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else { return tri_hit(f, ray); }  // :566
     default: return false;
   }
 }
@@ -458,6 +558,26 @@ PINE_HD bool shape_intersect(int kind, const DShape* S, DRay& ray) {
       }
       return false;
     }
+    case SHAPE_PLANE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:40-45
+      const f3 position = ld3(f), n = ld3(f + 3);
+      const float t = (dot(position, n) - dot(ray.o, n)) / dot(ray.d, n);
+      if (t < ray.tmin || t > ray.tmax) return false;
+      ray.tmax = t;
+      return true;
+    }
+    case SHAPE_LINE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:196-214
+      float z;
+      if (!line_closest(f, ray, z)) return false;
+      ray.tmax = z;
+      return true;
+    }
+    case SHAPE_CYLINDER: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:490-517
+      float t;
+      if (!cylinder_solve(f, ray, t)) return false;
+      ray.tmax = t;
+      return true;
+    }
+    case SHAPE_TRIANGLE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else { return tri_intersect(f, ray); }  // :567
     default: return false;
   }
 }
@@ -526,6 +646,41 @@ PINE_HD void shape_surface_info(const DShape* S, f3 p, DSurface& it) {
       const f3 x = apex - n * l;
       it.n = normalize(p - x);
       it.p = x + it.n * l * f[10];
+      break;
+    }
+    case SHAPE_PLANE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:46-51
+      const f3 position = ld3(f), u = ld3(f + 6), v = ld3(f + 9);
+      it.n = ld3(f + 3);
+      const f3 dp = p - position;
+      it.uv = f2{dot(dp, u), dot(dp, v)};
+      it.p = position + it.uv.x * u + it.uv.y * v;
+      break;
+    }
+    case SHAPE_LINE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:215-222
+      const f3 p0 = ld3(f), p1 = ld3(f + 3);
+      const float lt = dot(p - p0, ld3(f + 12));
+      const f3 lp = lt * p1 + (1.0f - lt) * p0;  // lerp(lt, p0, p1) vecmath.h:877-880
+      it.p = p;
+      it.n = normalize(p - lp);
+      it.uv = f2{lt, 0.0f};
+      break;
+    }
+    case SHAPE_CYLINDER: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {
+      // Cylinder::intersect itself leaves it.n / it.p (geometry.cpp:512-515; compute_surface_info is empty):
+      // the winner's intersect is the last that succeeded, so recomputing from the final ray gives its values
+      const f3 p0 = ld3(f), n = ld3(f + 6);
+      const f3 projection = p0 + dot(p - p0, n) * n;
+      it.n = normalize(p - projection);
+      it.p = p;
+      break;
+    }
+    case SHAPE_TRIANGLE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:568-574
+      const f3 v0 = ld3(f), v1 = ld3(f + 3), v2 = ld3(f + 6);
+      const float u = dot(p - v0, v1 - v0);
+      const float v = dot(p - v0, v2 - v0);
+      it.uv = f2{u, v};
+      it.p = lerp3(u, v, v0, v1, v2);
+      it.n = ld3(f + 9);
       break;
     }
     default: it.p = p; it.n = mk3(0.0f); break;
@@ -632,6 +787,33 @@ PINE_HD bool shape_sample(const DShape* S, const float* tri_verts, f3 o, f2 u, f
       ss.pdf = sqr(ss.distance) / pmax(absdot(ss.w, ss.n) * f[13], kEpsilon);
       break;
     }
+    case SHAPE_PLANE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:57-69
+      const f3 position = ld3(f), n = ld3(f + 3), pu = ld3(f + 6), pv = ld3(f + 9);
+      const float phi = u.x * kPi * 2;  // uniform_hemisphere sampling.h:56-62
+      const float cos_theta = u.y;
+      const float sin_theta = psqrt(1.0f - sqr(cos_theta));
+      const f3 ps = f3{sin_theta * pcos(phi), sin_theta * psin(phi), cos_theta};
+      const float l = absdot(o - position, n);
+      const float ex = l * ps.x / ps.z;
+      const float ey = l * ps.y / ps.z;
+      const f3 dp = o - position;
+      ss.p = (position + pu * dot(pu, dp) + pv * dot(pv, dp)) + pu * ex + pv * ey;
+      ss.n = n;
+      ss.w = normalize(ss.p - o, ss.distance);
+      ss.pdf = 1.0f / (2 * kPi);
+      break;
+    }
+    case SHAPE_LINE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else {  // geometry.cpp:223-233
+      const f3 p0 = ld3(f), p1 = ld3(f + 3), tx = ld3(f + 6), ty = ld3(f + 9);
+      const float th = f[15];
+      const float phi = u.y * 2 * kPi;
+      ss.p = (u.x * p1 + (1.0f - u.x) * p0) + th * pcos(phi) * tx + th * psin(phi) * ty;
+      ss.n = pcos(phi) * tx + psin(phi) * ty;
+      ss.w = normalize(ss.p - o, ss.distance);
+      ss.pdf = sqr(ss.distance) / (absdot(ss.w, ss.n) * f[16]);
+      break;
+    }
+    case SHAPE_TRIANGLE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else { tri_sample(f, o, u, ss); } break;  // :575-584
     case SHAPE_MESH: if constexpr (!(F & F_MESH)) __builtin_unreachable(); else {  // Mesh::sample geometry.h:170-178
       const int first = as_int(f[0]), nt = as_int(f[1]);
       if (nt == 0) return false;
@@ -659,6 +841,9 @@ PINE_HD float shape_pdf(const DShape* S, const DRay& ray, f3 ns) {
     case SHAPE_DISK: if constexpr (!(F & F_DISK)) __builtin_unreachable(); else { return sqr(ray.tmax) / (f[13] * absdot(ns, ray.d)); }  // :166-168
     case SHAPE_CONE: if constexpr (!(F & F_CONE)) __builtin_unreachable(); else { return sqr(ray.tmax) / f[11] * absdot(ns, ray.d); }  // :462-464
     case SHAPE_MESH: if constexpr (!(F & F_MESH)) __builtin_unreachable(); else { return sqr(ray.tmax) / (f[3] * absdot(ns, ray.d)); }  // geometry.h:180-182
+    case SHAPE_PLANE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else { return 1.0f / (2 * kPi); }  // geometry.cpp:70
+    case SHAPE_LINE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else { return sqr(ray.tmax) / (f[16] * absdot(ns, ray.d)); }  // :234-236
+    case SHAPE_TRIANGLE: if constexpr (!(F & F_XSHAPES)) __builtin_unreachable(); else { return sqr(ray.tmax) / (f[12] * absdot(ns, ray.d)); }  // :585-587
     default: return 0.0f;
   }
 }

@@ -411,6 +411,26 @@ HostAABB SceneHost::geometry_aabb(int gi) const {
       b.extend(ld3(f));
       break;
     }
+    case SHAPE_PLANE:  // geometry.cpp:52
+      b.lower = ld3(f) + mk3(-100.0f);
+      b.upper = ld3(f) + mk3(100.0f);
+      break;
+    case SHAPE_LINE: {  // geometry.cpp:237-244
+      const f3 p0 = ld3(f), p1 = ld3(f + 3), th = mk3(f[15]);
+      b.extend(p0 - th);
+      b.extend(p1 - th);
+      b.extend(p0 + th);
+      b.extend(p1 + th);
+      break;
+    }
+    case SHAPE_CYLINDER:  // geometry.h:141,147: both cap disks are built at p0, so the box is the one of Sphere(p0, r)
+      b = sphere_aabb(ld3(f), f[9]);
+      break;
+    case SHAPE_TRIANGLE:  // geometry.cpp:588-594
+      b.extend(ld3(f));
+      b.extend(ld3(f + 3));
+      b.extend(ld3(f + 6));
+      break;
     case SHAPE_MESH: {
       const HostMesh& m = meshes[geometries[gi].mesh];
       for (size_t i = 0; i < m.vertices.size() / 3; i++) b.extend(ld3(&m.vertices[3 * i]));
@@ -1041,6 +1061,101 @@ int pine_gpu_scene_add_cone(pine_gpu_scene* s, const float p_[3], const float n_
   f[6] = r, f[7] = h, f[8] = A, f[9] = A2, f[10] = S, f[11] = area;
   f[12] = p_[0], f[13] = p_[1], f[14] = p_[2];  // bottom disk centre (AABB only)
   g.describe = "shape cone " + matref(s, material) + " " + hex3(p_) + " " + hex3(n_) + fmt(" %a %a", r, h);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_plane(pine_gpu_scene* s, const float p_[3], const float n_[3], int material) {
+  if (!check(s, p_) || !check(s, n_)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_PLANE;
+  g.shape.material = material;
+  f3 n = normalize(ld3(n_));  // Plane::Plane geometry.cpp:31-34
+  if (length(n) == 0.0f) {
+    set_error("`Plane` can't have degenerated normal");
+    return -1;
+  }
+  f3 u, v;
+  coordinate_system(n, u, v);
+  float* f = g.shape.f;
+  memcpy(f, p_, 12);
+  f[3] = n.x, f[4] = n.y, f[5] = n.z;
+  f[6] = u.x, f[7] = u.y, f[8] = u.z;
+  f[9] = v.x, f[10] = v.y, f[11] = v.z;
+  g.describe = "shape plane " + matref(s, material) + " " + hex3(p_) + " " + hex3(n_);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_line(pine_gpu_scene* s, const float p0_[3], const float p1_[3], float thickness,
+                            int material) {
+  if (!check(s, p0_) || !check(s, p1_)) return -1;
+  if (thickness <= 0.0f) {  // Line::Line geometry.cpp:171-179
+    set_error("`Line` should have positive thickness");
+    return -1;
+  }
+  f3 p0 = ld3(p0_), p1 = ld3(p1_);
+  if (p0.x == p1.x && p0.y == p1.y && p0.z == p1.z) {
+    set_error("`Line` shouldn't have identical begin and end point");
+    return -1;
+  }
+  HostGeometry g{};
+  g.shape.kind = SHAPE_LINE;
+  g.shape.material = material;
+  m3 tbn = coordinate_system(normalize(p1 - p0));
+  float len = length(p1 - p0);
+  float* f = g.shape.f;
+  memcpy(f, p0_, 12);
+  memcpy(f + 3, p1_, 12);
+  f[6] = tbn.x.x, f[7] = tbn.x.y, f[8] = tbn.x.z;
+  f[9] = tbn.y.x, f[10] = tbn.y.y, f[11] = tbn.y.z;
+  f[12] = tbn.z.x, f[13] = tbn.z.y, f[14] = tbn.z.z;
+  f[15] = thickness;
+  f[16] = thickness * 2 * kPi * len;  // Line::area geometry.h:70
+  g.describe = "shape line " + matref(s, material) + " " + hex3(p0_) + " " + hex3(p1_) + fmt(" %a", thickness);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_cylinder(pine_gpu_scene* s, const float p0_[3], const float p1_[3], float r,
+                                int material) {
+  if (!check(s, p0_) || !check(s, p1_)) return -1;
+  if (material >= 0 && material < int(s->host.materials.size()) &&
+      s->host.materials[size_t(material)].kind == MAT_EMISSIVE) {
+    // Cylinder::sample / pdf / area are PINE_UNREACHABLE in the reference (geometry.h:148-150)
+    set_error("`Cylinder` can't be emissive: the reference has no sampling routine for it");
+    return -1;
+  }
+  if (r < 0.0f) {  // the two cap Disks of the constructor (geometry.h:141, geometry.cpp:125)
+    set_error("`Disk` can't have negative radius");
+    return -1;
+  }
+  HostGeometry g{};
+  g.shape.kind = SHAPE_CYLINDER;
+  g.shape.material = material;
+  f3 n = normalize(ld3(p1_) - ld3(p0_));  // geometry.h:140-141
+  if (length(n) == 0.0f) {
+    set_error("`Disk` can't have degenerated normal");
+    return -1;
+  }
+  float* f = g.shape.f;
+  memcpy(f, p0_, 12);
+  memcpy(f + 3, p1_, 12);
+  f[6] = n.x, f[7] = n.y, f[8] = n.z;
+  f[9] = r;
+  g.describe = "shape cylinder " + matref(s, material) + " " + hex3(p0_) + " " + hex3(p1_) + fmt(" %a", r);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_triangle(pine_gpu_scene* s, const float v0_[3], const float v1_[3], const float v2_[3],
+                                int material) {
+  if (!check(s, v0_) || !check(s, v1_) || !check(s, v2_)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_TRIANGLE;
+  g.shape.material = material;
+  f3 v0 = ld3(v0_), v1 = ld3(v1_), v2 = ld3(v2_);
+  f3 n = normalize(cross(v0 - v1, v0 - v2));  // Triangle(v0,v1,v2) geometry.cpp:528-531
+  if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f) n = mk3(0.0f, 0.0f, 1.0f);
+  float* f = g.shape.f;
+  memcpy(f, v0_, 12);
+  memcpy(f + 3, v1_, 12);
+  memcpy(f + 6, v2_, 12);
+  f[9] = n.x, f[10] = n.y, f[11] = n.z;
+  f[12] = length(cross(v1 - v0, v2 - v0)) / 2;  // Triangle::area geometry.h:112
+  g.describe = "shape triangle " + matref(s, material) + " " + hex3(v0_) + " " + hex3(v1_) + " " + hex3(v2_);
   return s->host.add_geometry(std::move(g));
 }
 int pine_gpu_scene_add_mesh(pine_gpu_scene* s, const float* vertices, int nv, const uint32_t* indices,

@@ -1354,6 +1354,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
       case SHAPE_DISK: need |= F_DISK; break;
       case SHAPE_CONE: need |= F_CONE; break;
       case SHAPE_MESH: need |= F_MESH; break;
+      case SHAPE_PLANE: case SHAPE_LINE: case SHAPE_CYLINDER: case SHAPE_TRIANGLE: need |= F_XSHAPES; break;
       default: break;
     }
   }

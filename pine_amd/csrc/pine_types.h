@@ -18,6 +18,10 @@ enum ShapeKind : int {
   SHAPE_DISK = 4,
   SHAPE_CONE = 5,
   SHAPE_MESH = 6,
+  SHAPE_PLANE = 7,
+  SHAPE_LINE = 8,
+  SHAPE_CYLINDER = 9,
+  SHAPE_TRIANGLE = 10,
 };
 
 // 128-byte shape record.  Field use per kind:
@@ -30,6 +34,10 @@ enum ShapeKind : int {
 //  DISK  : f[0..2] position, [3..5] n, [6..8] u, [9..11] v, [12] r, [13] area
 //  CONE  : f[0..2] apex p, [3..5] n, [6] r, [7] h, [8] A, [9] A2, [10] S, [11] area
 //  MESH  : i(0) first_tri, i(1) num_tri, i(2) bvh index, f[3] area (first triangle x count)
+//  PLANE : f[0..2] position, [3..5] n, [6..8] u, [9..11] v
+//  LINE  : f[0..2] p0, [3..5] p1, [6..8] tbn.x, [9..11] tbn.y, [12..14] tbn.z, [15] thickness, [16] area
+//  CYLINDER: f[0..2] p0, [3..5] p1, [6..8] n, [9] r
+//  TRIANGLE: f[0..8] v0 v1 v2, [9..11] n, [12] area
 struct alignas(16) DShape {
   float f[30];
   int kind;
@@ -92,9 +100,10 @@ static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
 // that the leaf loop knows which intersection routine to run (and the path kernel whether the hit is
 // a light) without first fetching the shape / material records -- one dependent LDS/L2 round trip
 // less per primitive.  (The host-side FlatAccel::prims and the accel dump keep plain indices.)
-constexpr int kPrimIndexMask = 0x07ffffff;
-constexpr int kPrimEmissiveBit = 1 << 27;
-constexpr int kPrimKindShift = 28;  // kinds 0..6 -> the packed word stays non-negative
+constexpr int kPrimIndexMask = 0x03ffffff;
+constexpr int kPrimEmissiveBit = 1 << 26;
+constexpr int kPrimKindShift = 27;  // kinds 0..15 in bits 27..30 -> the packed word stays non-negative (-1 = miss)
+static_assert(SHAPE_TRIANGLE < 16, "the shape kind must fit the 4 bits below the sign bit");
 
 // One BVH (top level or per mesh).  If root_count > 0 the root itself is a leaf
 // (bvh.cpp:331-334,396-399): test prim_index[root_start .. root_start+root_count) and stop.

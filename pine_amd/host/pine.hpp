@@ -79,6 +79,10 @@ inline OBB Box(AABB aabb, mat4 m) { return {aabb, m}; }
 struct Sphere { vec3 center; float radius; };
 struct Disk { vec3 position, normal; float radius; };
 struct Cone { vec3 position, normal; float radius, height; };
+struct Plane { vec3 position, normal; };
+struct Line { vec3 p0, p1; float thickness; };
+struct Cylinder { vec3 p0, p1; float radius; };
+struct Triangle { vec3 v0, v1, v2; };
 struct Mesh { std::vector<vec3> vertices; std::vector<std::array<uint32_t, 3>> indices; };
 
 template <class T> struct is_shape : std::false_type {};
@@ -88,6 +92,10 @@ template <> struct is_shape<OBB> : std::true_type {};
 template <> struct is_shape<Sphere> : std::true_type {};
 template <> struct is_shape<Disk> : std::true_type {};
 template <> struct is_shape<Cone> : std::true_type {};
+template <> struct is_shape<Plane> : std::true_type {};
+template <> struct is_shape<Line> : std::true_type {};
+template <> struct is_shape<Cylinder> : std::true_type {};
+template <> struct is_shape<Triangle> : std::true_type {};
 template <> struct is_shape<Mesh> : std::true_type {};
 
 struct Uncharted2 { static constexpr int code = 0; };
@@ -184,6 +192,10 @@ class Scene {
   int add_shape(const Sphere& s, int m) { return check(pine_gpu_scene_add_sphere(h_, s.center.data(), s.radius, m), "Sphere"); }
   int add_shape(const Disk& s, int m) { return check(pine_gpu_scene_add_disk(h_, s.position.data(), s.normal.data(), s.radius, m), "Disk"); }
   int add_shape(const Cone& s, int m) { return check(pine_gpu_scene_add_cone(h_, s.position.data(), s.normal.data(), s.radius, s.height, m), "Cone"); }
+  int add_shape(const Plane& s, int m) { return check(pine_gpu_scene_add_plane(h_, s.position.data(), s.normal.data(), m), "Plane"); }
+  int add_shape(const Line& s, int m) { return check(pine_gpu_scene_add_line(h_, s.p0.data(), s.p1.data(), s.thickness, m), "Line"); }
+  int add_shape(const Cylinder& s, int m) { return check(pine_gpu_scene_add_cylinder(h_, s.p0.data(), s.p1.data(), s.radius, m), "Cylinder"); }
+  int add_shape(const Triangle& s, int m) { return check(pine_gpu_scene_add_triangle(h_, s.v0.data(), s.v1.data(), s.v2.data(), m), "Triangle"); }
   int add_shape(const Mesh& s, int m) {
     return check(pine_gpu_scene_add_mesh(h_, &s.vertices[0].x, int(s.vertices.size()), &s.indices[0][0], int(s.indices.size()), m), "Mesh");
   }

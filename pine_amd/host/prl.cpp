@@ -1524,7 +1524,13 @@ Interp::Interp() {
   r.def("Disk", {"vec3", "vec3", "f32"}, "Disk", [shape, cat](Interp&, std::vector<Cell>& a) { return shape("Disk", cat({{a[0]->f, 3}, {a[1]->f, 3}, {a[2]->f, 1}})); });
   r.def("Cone", {"vec3", "vec3", "f32", "f32"}, "Cone",
         [shape, cat](Interp&, std::vector<Cell>& a) { return shape("Cone", cat({{a[0]->f, 3}, {a[1]->f, 3}, {a[2]->f, 1}, {a[3]->f, 1}})); });
-  for (const char* k : {"Rect", "AABB", "OBB", "Sphere", "Disk", "Cone"}) r.convert(k, "Shape", [](const Value& v) { return retype(v, "Shape"); });
+  r.def("Plane", {"vec3", "vec3"}, "Plane", [shape, cat](Interp&, std::vector<Cell>& a) { return shape("Plane", cat({{a[0]->f, 3}, {a[1]->f, 3}})); });
+  r.def("Line", {"vec3", "vec3", "f32"}, "Line", [shape, cat](Interp&, std::vector<Cell>& a) { return shape("Line", cat({{a[0]->f, 3}, {a[1]->f, 3}, {a[2]->f, 1}})); });
+  r.def("Cylinder", {"vec3", "vec3", "f32"}, "Cylinder",
+        [shape, cat](Interp&, std::vector<Cell>& a) { return shape("Cylinder", cat({{a[0]->f, 3}, {a[1]->f, 3}, {a[2]->f, 1}})); });
+  r.def("Triangle", {"vec3", "vec3", "vec3"}, "Triangle",
+        [shape, cat](Interp&, std::vector<Cell>& a) { return shape("Triangle", cat({{a[0]->f, 3}, {a[1]->f, 3}, {a[2]->f, 3}})); });
+  for (const char* k : {"Rect", "AABB", "OBB", "Sphere", "Disk", "Cone", "Plane", "Line", "Cylinder", "Triangle"}) r.convert(k, "Shape", [](const Value& v) { return retype(v, "Shape"); });
   r.def("@ma.AABB.lower", {"AABB"}, "vec3", [](Interp&, std::vector<Cell>& a) { return mk_vecf(3, obj<ShapeObj>(a[0])->p.data()); });
   r.def("@ma.AABB.upper", {"AABB"}, "vec3", [](Interp&, std::vector<Cell>& a) { return mk_vecf(3, obj<ShapeObj>(a[0])->p.data() + 3); });
 
@@ -1628,6 +1634,10 @@ Interp::Interp() {
     else if (g.kind == "Sphere") rc = pine_gpu_scene_add_sphere(s.h, p, p[3], mat);
     else if (g.kind == "Disk") rc = pine_gpu_scene_add_disk(s.h, p, p + 3, p[6], mat);
     else if (g.kind == "Cone") rc = pine_gpu_scene_add_cone(s.h, p, p + 3, p[6], p[7], mat);
+    else if (g.kind == "Plane") rc = pine_gpu_scene_add_plane(s.h, p, p + 3, mat);
+    else if (g.kind == "Line") rc = pine_gpu_scene_add_line(s.h, p, p + 3, p[6], mat);
+    else if (g.kind == "Cylinder") rc = pine_gpu_scene_add_cylinder(s.h, p, p + 3, p[6], mat);
+    else if (g.kind == "Triangle") rc = pine_gpu_scene_add_triangle(s.h, p, p + 3, p + 6, mat);
     gpu_check(rc, "scene.add(shape)");
   };
   r.def("add", {"Scene&", "str", "Material"}, "void", [add_material](Interp&, std::vector<Cell>& a) {

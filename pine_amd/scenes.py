@@ -189,3 +189,31 @@ def lights_zoo(size=(64, 64), with_sky=True):
     if with_sky:
         scene.set(Sky([0.9, 0.9, 1.0]))
     return scene
+
+
+def xshapes_zoo(size=(64, 64), extra_lights=True):
+    """The analytic shapes of geometry.h that no BASELINE scene uses: a Plane floor (UV checkerboard), a
+    Cylinder (side surface only; its bounding box is the reference's Sphere(p0, r) box, geometry.h:141), a
+    thick Line, a stand-alone Triangle -- lit by a Rect lamp and, with extra_lights, by an emissive Triangle,
+    an emissive Line and a dim emissive Plane above (Plane::sample / Line::sample / Triangle::sample)."""
+    from .api import Plane, Line, Cylinder, Triangle, Metal, Checkerboard, UV, lerp
+    scene = Scene()
+    scene.add("floor", Diffuse(lerp(Checkerboard(UV() * 2.0, 0.5), [0.8, 0.8, 0.8], [0.2, 0.3, 0.6])))
+    scene.add("white", Diffuse([0.85, 0.85, 0.85]))
+    scene.add("red", Diffuse([0.9, 0.15, 0.1]))
+    scene.add("metal", Metal([0.9, 0.8, 0.5], 0.15))
+    scene.add(Plane([0, 0, 0], [0, 1, 0]), "floor")
+    scene.add(Rect([0, 1, 2.2], [3, 0, 0], [0, 2, 0], True), "white")
+    scene.add(Cylinder([-0.6, 0.25, 1.2], [-0.6, 1.25, 1.2], 0.25), "red")
+    scene.add(Cylinder([0.75, 0.3, 0.6], [0.55, 0.3, 0.9], 0.3), "metal")
+    scene.add(Line([0.1, 0.1, 0.9], [0.8, 0.9, 1.5], 0.06), "metal")
+    scene.add(Line([-0.9, 0.05, 0.5], [0.9, 0.05, 0.4], 0.04), "white")
+    scene.add(Triangle([-0.3, 0.0, 1.8], [0.5, 0.0, 1.9], [0.1, 1.1, 1.7]), "red")
+    scene.add(Sphere([0.0, 0.2, 1.0], 0.2), "white")
+    scene.add(Rect([0.0, 1.9, 1], [0.5, 0, 0], [0, 0, 0.5]), Emissive([20.0, 18.0, 15.0]))
+    if extra_lights:
+        scene.add(Triangle([-1.0, 1.2, 1.0], [-1.0, 1.6, 1.4], [-1.0, 1.6, 0.8]), Emissive([12.0, 4.0, 2.0]))
+        scene.add(Line([0.9, 0.6, 1.9], [0.9, 1.4, 1.9], 0.03), Emissive([2.0, 8.0, 14.0]))
+        scene.add(Plane([0, 6, 0], [0, -1, 0]), Emissive([0.15, 0.2, 0.3]))
+    scene.set(ThinLenCamera(Film(list(size)), [0, 1, -4], [0, 1, 0], 0.25))
+    return scene

@@ -54,6 +54,7 @@ FILM_NAMES = [
     "mats_zoo_64_s32_d6", "classic_checker_cones8_90x45_s32_d6",   # node-graph materials, Metal / Glossy / Glass
     "lights_zoo_64_s32_d6", "lights_nosky_48_s16_d4",               # delta lights, Sky environment light
     "mesh_glossy_48_s32_d6",                                        # meshes (incl. a mesh area light) without Subsurface
+    "xshapes_48_s16_d5", "xshapes_nolights_40_s8_d3",               # Plane / Line / Cylinder / Triangle
 ]
 
 

@@ -48,6 +48,8 @@ def test_scene_describe_equals_golden_pscene():
     assert scenes.sss((48, 48), 1).describe() == ps
     _, ps, _, _ = load_film("classic_cones12_90x45_s32_d6")
     assert scenes.classic_cones((90, 45), 12).describe() == ps
+    _, ps, _, _ = load_film("xshapes_48_s16_d5")
+    assert scenes.xshapes_zoo((48, 48)).describe() == ps
 
 
 def test_error_behaviour_mirrors_reference():
@@ -58,6 +60,14 @@ def test_error_behaviour_mirrors_reference():
     with pytest.raises(pa.PineError, match="degenerated"):           # geometry.cpp:266
         s.add("m", pa.Diffuse([1, 1, 1]))
         s.add(pa.Rect([0, 0, 0], [1, 0, 0], [2, 0, 0]), "m")
+    with pytest.raises(pa.PineError, match="positive thickness"):    # geometry.cpp:177
+        s.add(pa.Line([0, 0, 0], [1, 0, 0], 0.0), "m")
+    with pytest.raises(pa.PineError, match="identical begin and end"):  # geometry.cpp:178
+        s.add(pa.Line([1, 2, 3], [1, 2, 3], 0.1), "m")
+    with pytest.raises(pa.PineError, match="degenerated normal"):    # geometry.cpp:32
+        s.add(pa.Plane([0, 0, 0], [0, 0, 0]), "m")
+    with pytest.raises(pa.PineError, match="Cylinder"):              # geometry.h:148-150: no sample/pdf/area
+        s.add(pa.Cylinder([0, 0, 0], [0, 1, 0], 0.1), pa.Emissive([1, 1, 1]))
     with pytest.raises(pa.PineError, match="max_path_length"):       # path.cpp:12-13
         pa.PathIntegrator(pa.BlueSampler(4), 0)
     with pytest.raises(pa.PineError):

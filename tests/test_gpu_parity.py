@@ -98,11 +98,12 @@ def test_device_rng_stream():
     assert np.array_equal(out, ref)
 
 
-def test_device_shape_records():
+@pytest.mark.parametrize("which", ["shapes_zoo", "shapes_xzoo"])
+def test_device_shape_records(which):
     from pine_amd import _lib, scenes
-    z = np.load(os.path.join(GOLDEN, "shapes_zoo.npz"))
+    z = np.load(os.path.join(GOLDEN, which + ".npz"))
     rec, rays = z["records"], np.ascontiguousarray(z["rays"])
-    sc = scenes.shapes_zoo((48, 48))
+    sc = scenes.shapes_zoo((48, 48)) if which == "shapes_zoo" else scenes.xshapes_zoo((48, 48))
     assert sc.describe() == str(z["pscene"])
     out = np.zeros_like(rec)
     _lib.check(_lib.lib.pine_gpu_test_shapes(sc._h, 0, rays.ctypes.data_as(_lib.c_f_p), len(rays),
@@ -148,6 +149,8 @@ def _scene_for(name):
         "classic_checker_cones8_90x45_s32_d6": lambda: scenes.classic_cones((90, 45), 8, checker_floor=True),
         "lights_zoo_64_s32_d6": lambda: scenes.lights_zoo((64, 64)),
         "lights_nosky_48_s16_d4": lambda: scenes.lights_zoo((48, 48), with_sky=False),
+        "xshapes_48_s16_d5": lambda: scenes.xshapes_zoo((48, 48)),
+        "xshapes_nolights_40_s8_d3": lambda: scenes.xshapes_zoo((40, 40), extra_lights=False),
         "mesh_glossy_48_s32_d6": lambda: scenes.sss((48, 48), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True),
     }[name]()
 

@@ -49,8 +49,9 @@ def test_host_math_matches_reference(oracle):
     assert_bit_equal(oracle.host_math(), np.load(os.path.join(GOLDEN, "host_math.npy")), "host math")
 
 
-def test_shape_records_match_reference(oracle):
-    z = np.load(os.path.join(GOLDEN, "shapes_zoo.npz"))
+@pytest.mark.parametrize("which", ["shapes_zoo", "shapes_xzoo"])
+def test_shape_records_match_reference(oracle, which):
+    z = np.load(os.path.join(GOLDEN, which + ".npz"))
     rec = z["records"]
     got = oracle.shapes(str(z["pscene"]), z["rays"], rec.shape[0])
     # compute_surface_info output is only defined on a hit (the reference leaves `it` untouched otherwise)

@@ -156,6 +156,31 @@ def test_script_builds_the_scene_the_api_builds_from_the_same_values():
     assert ps == s.describe()
 
 
+def test_plane_line_cylinder_triangle_constructors():
+    """geometry.cpp:922-929 registrations: Plane(vec3,vec3), Line(vec3,vec3,f32), Cylinder(vec3,vec3,f32),
+    Triangle(vec3,vec3,vec3) and their conversion to Shape; examples/shapes.pine == the same scene via the API."""
+    import pine_amd as pa
+    from pine_amd import prl
+    out = prl.interpret(open(os.path.join(ROOT, "examples", "shapes.pine")).read(), dry_run=True)
+    ps, spp, depth = prl.scene_of_dry_run(out)
+    assert (spp, depth) == (16, 5)
+    s = pa.Scene()
+    s.add("grey", pa.Diffuse([0.75, 0.75, 0.75]))
+    s.add("red", pa.Diffuse([0.875, 0.125, 0.125]))
+    s.add("steel", pa.Metal([0.875, 0.75, 0.5], 0.125))
+    s.add(pa.Plane([0, 0, 0], [0, 1, 0]), "grey")
+    s.add(pa.Cylinder([-0.5, 0.25, 1.25], [-0.5, 1.25, 1.25], 0.25), "red")
+    s.add(pa.Line([0.125, 0.125, 0.875], [0.75, 0.875, 1.5], 0.0625), "steel")
+    s.add(pa.Triangle([-0.25, 0.0, 1.75], [0.5, 0.0, 1.875], [0.125, 1.0, 1.75]), "red")
+    s.add(pa.Rect([0.0, 1.875, 1], [0.5, 0, 0], [0, 0, 0.5]), pa.Emissive([20.0, 18.0, 15.0]))
+    s.add(pa.Triangle([-1.0, 1.25, 1.0], [-1.0, 1.5, 1.5], [-1.0, 1.5, 0.75]), pa.Emissive([12.0, 4.0, 2.0]))
+    s.add(pa.Line([0.875, 0.5, 1.875], [0.875, 1.5, 1.875], 0.03125), pa.Emissive([2.0, 8.0, 14.0]))
+    s.set(pa.ThinLenCamera(pa.Film([96, 96]), [0, 1, -4], [0, 1, 0], 0.25))
+    assert ps == s.describe()
+    with pytest.raises(prl.PrlError, match="positive thickness"):
+        prl.interpret('s := Scene(); s.add(Line([0,0,0],[1,0,0],0.0), Diffuse([1,1,1]));', dry_run=True)
+
+
 def test_node_expressions_resolve_like_the_reference():
     """node.cpp:29-116: operators over Nodef / Node3f with the one-step conversions from numbers and vectors."""
     from pine_amd import prl

@@ -55,6 +55,9 @@ FILMS = {
     "lights_zoo_64_s32_d6": (lambda: scenes.lights_zoo((64, 64)), 32, 6),
     "lights_nosky_48_s16_d4": (lambda: scenes.lights_zoo((48, 48), with_sky=False), 16, 4),
     # triangle meshes without Subsurface (two-level BVH, mesh area light): the stage-queued kernel's mesh path
+    # Plane / Line / Cylinder / stand-alone Triangle, incl. emissive Triangle / Line / Plane (geometry.cpp:31-70,171-244,466-595)
+    "xshapes_48_s16_d5": (lambda: scenes.xshapes_zoo((48, 48)), 16, 5),
+    "xshapes_nolights_40_s8_d3": (lambda: scenes.xshapes_zoo((40, 40), extra_lights=False), 8, 3),
     "mesh_glossy_48_s32_d6": (lambda: scenes.sss((48, 48), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True), 32, 6),
 }
 
@@ -100,12 +103,14 @@ def main():
         tmax[200:400, 0] = rng.uniform(0.1, 2.5, 200).astype(np.float32)  # clipped rays
         rays = np.concatenate([o, d, tmin, tmax], axis=1).astype(np.float32)
         sp, rp, op = (os.path.join(tmp, x) for x in ("z.pscene", "rays.bin", "shapes.bin"))
-        zps = zoo.describe()
-        open(sp, "w").write(zps)
         rays.tofile(rp)
-        run_ref("shapes", sp, rp, op)
-        rec = np.fromfile(op, dtype=np.float32).reshape(-1, n, 11)
-        np.savez_compressed(os.path.join(OUT, "shapes_zoo.npz"), rays=rays, records=rec, pscene=np.array(zps))
+        # shapes_zoo: Rect / AABB / OBB / Sphere / Disk / Cone;  shapes_xzoo: Plane / Line / Cylinder / Triangle
+        for fname, zscene in (("shapes_zoo.npz", zoo), ("shapes_xzoo.npz", scenes.xshapes_zoo((48, 48)))):
+            zps = zscene.describe()
+            open(sp, "w").write(zps)
+            run_ref("shapes", sp, rp, op)
+            rec = np.fromfile(op, dtype=np.float32).reshape(-1, n, 11)
+            np.savez_compressed(os.path.join(OUT, fname), rays=rays, records=rec, pscene=np.array(zps))
 
         # 3. films
         meta = {}
