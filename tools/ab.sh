@@ -1,6 +1,11 @@
 #!/bin/bash
-# usage: tools/ab.sh lib1 lib2 ...   -- A/B experiment builds on ONE box: path_trace ms per lib, 2 rounds interleaved
-for round in 1 2; do
-for l in "$@"; do
-  echo -n "$l: "; PINE_GPU_LIB=pine_amd/lib/$l python bench.py --steps 4 --warmup 1 --no-cpu 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['kernels_ms']['path_trace'],2), 'ms', round(d['value'],1), 'Ms/s')"
-done; done
+# usage (GPU box): tools/ab.sh name1 name2 ...   -- bench each pine_amd/lib/x_<name>.so (A/B experiments)
+for n in "$@"; do
+  PINE_GPU_LIB=pine_amd/lib/x_$n.so timeout -k 10 120 python bench.py --steps 10 --warmup 3 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    l=l.strip()
+    if l.startswith('{'):
+        j=json.loads(l); print('$n', 'ms_per_step', round(j['ms_per_step'],3), 'Ms/s', round(j['value'],1), 'md5', j.get('film_md5'))
+"
+done
