@@ -255,8 +255,12 @@ PINE_HD bool box_hit_oct(const float* lo, const float* hi, const DRayOct& r, flo
   const float tmax0 = (nx ? lo[0] : hi[0]) * r.dir_inv.x - r.org_div_dir.x;
   const float tmax1 = (ny ? lo[1] : hi[1]) * r.dir_inv.y - r.org_div_dir.y;
   const float tmax2 = (nz ? lo[2] : hi[2]) * r.dir_inv.z - r.org_div_dir.z;
-  tmin = pmax(tmin0, pmax(tmin1, pmax(tmin2, tmin)));  // psl::max(a,b,c,d) src/psl/math.h:52-61
-  tmax = pmin(tmax0, pmin(tmax1, pmin(tmax2, tmax)));
+  // psl::max(a,b,c,d) src/psl/math.h:52-61 is the chain a > x ? a : x from the right.  Its right-hand
+  // operand is never NaN here (it starts from the ray's tmin / tmax), and a NaN on the left selects the
+  // right-hand operand: exactly the "ignore NaN" maximum the hardware's v_max3_f32 / v_min3_f32 compute.
+  // Only the sign of a zero result can differ, and the result is only ever compared.
+  tmin = __builtin_fmaxf(__builtin_fmaxf(tmin0, __builtin_fmaxf(tmin1, tmin2)), tmin);
+  tmax = __builtin_fminf(__builtin_fminf(tmax0, __builtin_fminf(tmax1, tmax2)), tmax);
   return tmin <= tmax;
 }
 // AABB::intersect(o, d, tmin&, tmax&) bbox.cpp:94-111 (also the body of AABB::hit(Ray) :75-93)

@@ -37,6 +37,11 @@ PINE_HD uint32_t asuint(float f) {
   return u;
 }
 PINE_HD uint32_t abstop12(float x) { return (asuint(x) >> 20) & 0x7ff; }
+PINE_HD float asfloat(uint32_t u) {
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
 
 // Polynomial data: glibc __sincosf_table[0]; table[1] is the same with c0..c4 negated.
 PINE_HD float sin_poly(double x, double x2, int n, double csign) {
@@ -121,35 +126,52 @@ PINE_HD float cosf_glibc(float y) {
   return sin_poly(x * sign, x * x, n ^ 1, csign);
 }
 
-// sin and cos of the same argument with one shared range reduction (the two results are exactly
-// sinf_glibc(y) and cosf_glibc(y): same reduction, same polynomials).
+// sin and cos of the same argument with one shared range reduction: exactly sinf_glibc(y) and
+// cosf_glibc(y), written without data-dependent branches for 64-wide execution.  What makes that possible:
+//  * for |y| < pi/4 the general reduction yields n = 0 and leaves x untouched, so the short path of
+//    sinf/cosf is the general path's arithmetic with n = 0 (same operations, same operands);
+//  * one of the two results is always the odd "sine" polynomial and the other the even "cosine" one
+//    (n and n^1 differ in parity): both are evaluated once and swapped by the parity of n;
+//  * the factors `sign` (on x) and `csign` (on the cosine coefficients) are +-1: the sine polynomial is odd
+//    in x and every step of either polynomial is a round-to-nearest operation, so multiplying the inputs
+//    by -1 negates the result exactly -- the sign is applied to the final float instead.
+// Concentric-disk sampling feeds this with theta in [-pi/4, 3pi/4]: half the lanes of a wave had n = 0 and
+// half n = 1, and the branchy form executed four polynomials plus both reductions for every wave.
 PINE_HD void sincosf_glibc(float y, float& sn, float& cs) {
-  double x = y;
+  const uint32_t top = abstop12(y);
+  if (__builtin_expect(!(top < abstop12(120.0f)), 0)) {  // |y| >= 120, inf, nan: never on a sampler path
+    sn = sinf_glibc(y);
+    cs = cosf_glibc(y);
+    return;
+  }
   int n;
-  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
-    const double x2 = x * x;
-    if (abstop12(y) < abstop12(0x1p-12f)) {
-      sn = y;
-      cs = 1.0f;
-      return;
-    }
-    sn = sin_poly(x, x2, 0, 1.0);
-    cs = sin_poly(x, x2, 1, 1.0);
-    return;
-  }
-  if (abstop12(y) < abstop12(120.0f))
-    x = reduce_fast(x, &n);
-  else if (abstop12(y) < abstop12(__builtin_inff()))
-    x = reduce_slow(x, &n);
-  else {
-    sn = cs = y - y;
-    return;
-  }
-  const double sign = (n & 3) == 1 || (n & 3) == 2 ? -1.0 : 1.0;
-  const double csign = (n & 2) ? -1.0 : 1.0;
-  const double xs = x * sign, x2 = x * x;
-  sn = sin_poly(xs, x2, n, csign);
-  cs = sin_poly(xs, x2, n ^ 1, csign);
+  const double xr = reduce_fast((double)y, &n);
+  const double x2 = xr * xr;
+  const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+  const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5,
+               c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+  // sine form (sin_poly, n even) on the unsigned reduced argument
+  const double x3 = xr * x2;
+  const double st1 = __builtin_fma(x2, s3, s2);
+  const double x7 = x3 * x2;
+  const double ss = __builtin_fma(x3, s1, xr);
+  const float S = (float)__builtin_fma(x7, st1, ss);
+  // cosine form (sin_poly, n odd) with the positive coefficient set
+  const double x4 = x2 * x2;
+  const double ct2 = __builtin_fma(x2, c4, c3);
+  const double ct1 = __builtin_fma(x2, c1, c0);
+  const double x6 = x4 * x2;
+  const double cc = __builtin_fma(x4, c2, ct1);
+  const float C = (float)__builtin_fma(x6, ct2, cc);
+  const uint32_t sneg = (((n & 3) == 1) | ((n & 3) == 2)) ? 0x80000000u : 0u;  // sign = {1,-1,-1,1}[n&3]
+  const uint32_t cneg = (n & 2) ? 0x80000000u : 0u;                             // csign
+  const float Ss = asfloat(asuint(S) ^ sneg), Cs = asfloat(asuint(C) ^ cneg);
+  const bool odd = (n & 1) != 0;
+  float rs = odd ? Cs : Ss;
+  float rc = odd ? Ss : Cs;
+  const bool tiny = top < abstop12(0x1p-12f);  // sinf: return y, cosf: return 1
+  sn = tiny ? y : rs;
+  cs = tiny ? 1.0f : rc;
 }
 
 
@@ -175,11 +197,6 @@ PINE_HD double asdouble(uint64_t u) {
   double d;
   memcpy(&d, &u, 8);
   return d;
-}
-PINE_HD float asfloat(uint32_t u) {
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
 }
 PINE_HD uint64_t exp2f_tab(unsigned i) {
   switch (i) {

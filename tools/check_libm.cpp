@@ -26,6 +26,10 @@ int main(int argc, char** argv) {
           float a2 = pine_libm::sinf_glibc(x), c2 = pine_libm::cosf_glibc(x);
           if (memcmp(&a, &a2, 4)) { if (bs < 3 && t == 0) printf("sin(%a): libm %a mine %a\n", x, a, a2); bs++; }
           if (memcmp(&c, &c2, 4)) { if (bc < 3 && t == 0) printf("cos(%a): libm %a mine %a\n", x, c, c2); bc++; }
+          float a3, c3;
+          pine_libm::sincosf_glibc(x, a3, c3);  // the branch-free shared-reduction form the kernels call
+          if (memcmp(&a, &a3, 4)) { if (bs < 3 && t == 0) printf("sincos.sin(%a): libm %a mine %a\n", x, a, a3); bs++; }
+          if (memcmp(&c, &c3, 4)) { if (bc < 3 && t == 0) printf("sincos.cos(%a): libm %a mine %a\n", x, c, c3); bc++; }
           n++;
         }
       }
