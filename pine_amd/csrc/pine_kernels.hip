@@ -233,6 +233,18 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
         hit = true;
         geom_out = word;
       }
+#ifdef PINE_DUP_SHAPES  /* cost-measurement builds only: run the selected shape tests a second time on an opaque copy of the ray */
+      {
+        const bool sel = PINE_DUP_SHAPES == 0 ? kind == SHAPE_RECT : kind == SHAPE_OBB;
+        if (sel) {
+          DRay rr = ray;
+          asm volatile("" : "+v"(rr.tmin));
+          const bool h2 = ANY ? shape_hit<F>(kind, sh, rr) : shape_intersect<F>(kind, sh, rr);
+          float sink = h2 ? rr.tmax : 0.0f;
+          asm volatile("" : : "v"(sink));
+        }
+      }
+#endif
     }
     return false;
   };
@@ -247,6 +259,16 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
     const DNode* node = &S.nodes[next];
     int l = -1, r = -1;
     float t0 = ray.tmax, t1 = ray.tmax;
+#ifdef PINE_DUP_NODES
+    {
+      float q0 = ray.tmax, q1 = ray.tmax, tm = ray.tmin;
+      asm volatile("" : "+v"(tm));
+      const bool b0 = box_hit_oct(node->lo0, node->hi0, oct, tm, q0);
+      const bool b1 = box_hit_oct(node->lo1, node->hi1, oct, tm, q1);
+      float sink = (b0 ? q0 : 0.0f) + (b1 ? q1 : 0.0f);
+      asm volatile("" : : "v"(sink));
+    }
+#endif
     if (box_hit_oct(node->lo0, node->hi0, oct, ray.tmin, t0)) {
       if (node->count[0] == 0) l = node->child[0];
       else if (leaf(node->child[0], node->count[0])) return true;

@@ -45,6 +45,7 @@ struct alignas(16) DShape {
 };
 static_assert(sizeof(DShape) == 128, "DShape must be 128 bytes");
 
+
 enum MaterialKind : int {
   MAT_EMISSIVE = 0,
   MAT_DIFFUSE = 1,

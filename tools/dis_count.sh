@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/dis_count.sh NAME [extra hipcc flags]  -- disassemble the cbox-only variants and count VALU / packed / mov
 name=$1; shift
-cd /root/repo/pine_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 --cuda-device-only -S -DPINE_ONLY_CBOX_VARIANT -w "$@" -x hip pine_kernels.hip -o ../../build/dis/$name.s || exit 1
+cd /root/repo/pine_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 --cuda-device-only -S -DPINE_ONLY_CBOX_VARIANT -w "$@" -x hip pine_kernels.hip -o ../../build/dis/$name.s || exit 1
 python3 - "$name" <<'PY'
 import re,sys
 s=open('/root/repo/build/dis/%s.s'%sys.argv[1]).read()
