@@ -348,24 +348,123 @@ BlueTables select_tables(const uint8_t* blob, int spp_eff) {
   t.rank = t.scramble + 131072;
   return t;
 }
+// ---- SobolSampler (sampler.h:83-164, sampler.cpp:81-113, lowdiscrepancy.h:73-80) ------------------
+inline uint64_t mix_bits(uint64_t v) {  // rng.h:81-88
+  v ^= (v >> 31);
+  v *= 0x7fb5d329728ea185ull;
+  v ^= (v >> 27);
+  v *= 0x81dadef4bc2dd44dull;
+  v ^= (v >> 33);
+  return v;
+}
+inline uint32_t reverse_bits32(uint32_t x) {  // math.h:20-27
+  x = (x & 0x55555555) << 1 | (x & 0xaaaaaaaa) >> 1;
+  x = (x & 0x33333333) << 2 | (x & 0xcccccccc) >> 2;
+  x = (x & 0x0f0f0f0f) << 4 | (x & 0xf0f0f0f0) >> 4;
+  x = (x & 0x00ff00ff) << 8 | (x & 0xff00ff00) >> 8;
+  return (x << 16) | (x >> 16);
+}
+inline uint64_t left_shift_64x2(uint64_t x) {  // vecmath.h:1231-1239
+  x &= 0xffffffff;
+  x = (x ^ (x << 16)) & 0x0000ffff0000ffffull;
+  x = (x ^ (x << 8)) & 0x00ff00ff00ff00ffull;
+  x = (x ^ (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+  x = (x ^ (x << 2)) & 0x3333333333333333ull;
+  x = (x ^ (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+inline uint64_t encode_morton64x2(uint32_t x, uint32_t y) {  // vecmath.h:1243-1245
+  return (left_shift_64x2(y) << 1) | left_shift_64x2(x);
+}
+inline int log2i_(int y) {  // psl::log2i = hsb = ieeeexp(float(x)) (src/psl/math.h:77-81,262-264)
+  float f = float(uint32_t(y));
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return int(0xff & (u >> 23)) - 127;
+}
+inline uint32_t fast_owen(uint32_t v, uint32_t seed) {  // SobolSampler::FastOwenScrambler sampler.h:95-109
+  v = reverse_bits32(v);
+  v ^= v * 0x3d20adeau;
+  v += seed;
+  v *= (seed >> 16) | 1;
+  v ^= v * 0x05526c56u;
+  v ^= v * 0x53a22864u;
+  return reverse_bits32(v);
+}
+// The first two of the 1024 Sobol' generator matrices (sobolmatrices.cpp:40-: 52 columns each) have closed
+// forms: dimension 0 is the bit reversal (column i = 2^31 >> i, zero from i = 32), dimension 1 follows
+// v[0] = 2^31, v[i+1] = v[i] ^ (v[i] >> 1) through all 52 columns.  SobolSampler only ever reads these two.
+inline uint32_t sobol_matrix(int dim, int i) {
+  if (dim == 0) return i < 32 ? 0x80000000u >> i : 0u;
+  uint32_t v = 0x80000000u;
+  for (int k = 0; k < i; k++) v ^= v >> 1;
+  return v;
+}
+inline float sobol_sample(int64_t a, int dim, uint32_t seed) {  // lowdiscrepancy.h:73-80 with FastOwenScrambler
+  uint32_t v = 0;
+  for (int i = 0; a != 0; a >>= 1, i++)
+    if (a & 1) v ^= sobol_matrix(dim, i);
+  v = fast_owen(v, seed);
+  return fmin_(float(v) * 0x1p-32f, kOneMinusEps);
+}
+
+enum SamplerKind { SAMPLER_BLUE = 0, SAMPLER_SOBOL = 1 };
 struct Sampler {
   BlueTables t;
+  int kind = SAMPLER_BLUE;
   int spp = 1;
   int dimension = 0;
   int px = 0, py = 0, index = 0;
   RNG rng;
   uint64_t* rng_draws = nullptr;
+  // SobolSampler state
+  int log2_spp = 0, nbase4_digits = 0;
+  uint64_t sobol_index = 0;
 
-  void start_pixel(int x, int y, int sample_index) {  // sampler.h:286-290 + :174-177
+  void init(int W, int H) {  // Sampler::init -> SobolSampler::init sampler.cpp:81-84 (a no-op for the others)
+    log2_spp = log2i_(spp);  // SobolSampler ctor sampler.h:127-129
+    int res = roundup2(std::max(W, H));
+    nbase4_digits = log2i_(res) + (log2_spp + 1) / 2;
+  }
+  void start_pixel(int x, int y, int sample_index) {  // sampler.h:286-290 + :174-177 / :135-138
     rng = RNG(hash_pixel(x, y, sample_index));
     px = x;
     py = y;
-    index = sample_index;  // NB: dimension is NOT reset here
+    index = sample_index;  // NB: BlueSobolSampler does NOT reset its dimension here
+    if (kind == SAMPLER_SOBOL) {
+      dimension = 0;
+      sobol_index = (encode_morton64x2(uint32_t(x), uint32_t(y)) << log2_spp) | uint64_t(sample_index);
+    }
   }
-  void start_next_sample() {  // sampler.h:178-181
+  void start_next_sample() {  // sampler.h:178-181 / :139-142
     dimension = 0;
     index++;
+    sobol_index++;
   }
+  uint64_t sobol_compute_sample_index() const {  // sampler.cpp:86-113
+    static const uint8_t permutations[24][4] = {
+        {0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 2, 1}, {0, 3, 1, 2},
+        {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 2, 0}, {1, 3, 0, 2},
+        {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 3, 0, 1}, {2, 3, 1, 0},
+        {3, 1, 2, 0}, {3, 1, 0, 2}, {3, 2, 1, 0}, {3, 2, 0, 1}, {3, 0, 2, 1}, {3, 0, 1, 2}};
+    uint64_t si = 0;
+    const bool only_power_of_2 = (log2_spp & 1) != 0;
+    const int last_digit = only_power_of_2 ? 1 : 0;
+    for (int i = nbase4_digits - 1; i >= last_digit; --i) {
+      int digit_shift = 2 * i - (only_power_of_2 ? 1 : 0);
+      int digit = int((sobol_index >> digit_shift) & 3);
+      uint64_t higher_digits = sobol_index >> (digit_shift + 2);
+      int p = int((mix_bits(higher_digits ^ (0x55555555u * uint32_t(dimension))) >> 24) % 24);
+      digit = permutations[p][digit];
+      si |= uint64_t(digit) << digit_shift;
+    }
+    if (only_power_of_2) {
+      int digit = int(sobol_index & 1);
+      si |= uint64_t(digit ^ int(mix_bits((sobol_index >> 1) ^ (0x55555555u * uint32_t(dimension))) & 1));
+    }
+    return si;
+  }
+  static uint64_t hash_int(int v) { return murmur64A(reinterpret_cast<const unsigned char*>(&v), 4, 0); }  // hash(dimension) rng.h:60-65
   float sample_dimension(int dim) const {  // bluenoise_*spp.cpp:14-34
     int pi = px & 127, pj = py & 127;
     int si = index & 255;
@@ -375,11 +474,25 @@ struct Sampler {
     value = value ^ t.scramble[(sd % 8) + (pi + pj * 128) * 8];
     return (0.5f + value) / 256.0f;
   }
-  float get1d() {  // sampler.h:183-187
+  float get1d() {  // sampler.h:183-187 / :143-148
+    if (kind == SAMPLER_SOBOL) {
+      uint64_t si = sobol_compute_sample_index();
+      dimension += 1;
+      uint64_t u = hash_int(dimension);
+      return sobol_sample(int64_t(si), 0, uint32_t(u));
+    }
     if (dimension >= 256) dimension = 2;
     return sample_dimension(dimension++);
   }
-  vec2 get2d() {  // sampler.h:188-194
+  vec2 get2d() {  // sampler.h:188-194 / :149-155
+    if (kind == SAMPLER_SOBOL) {
+      uint64_t si = sobol_compute_sample_index();
+      dimension += 2;
+      uint64_t u = hash_int(dimension);
+      float a = sobol_sample(int64_t(si), 0, uint32_t(u));
+      float b = sobol_sample(int64_t(si), 1, uint32_t(u >> 32));
+      return {a, b};
+    }
     if (dimension + 1 >= 256) dimension = 2;
     int dim = dimension;
     dimension += 2;
@@ -2576,6 +2689,8 @@ bool parse_pscene(const char* text, Scene& scene) {
   return true;
 }
 
+static int g_sampler_kind = SAMPLER_BLUE;  // test-infrastructure switch (oracle_set_sampler)
+
 // PathIntegrator::render (path.cpp:26-41) with parallel_for's scheduling shape (parallel.h:19-57)
 // shard_world > 1: only pixels of 8x8 tiles t = ty*tiles_x + tx with t % world == rank are rendered
 // (the product's multi-GPU partition, pine_amd/csrc/pine_kernels.hip decode_item); others untouched.
@@ -2583,8 +2698,9 @@ void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int dep
                  int y0, int y1, float* film, float* samples_out, oracle_stats* stats,
                  int shard_rank = 0, int shard_world = 1) {
   int W = scene.camera.W, H = scene.camera.H;
-  int spp = bluesobol_effective_spp(spp_req);
-  BlueTables bt = select_tables(tables, spp);
+  const int sampler_kind = g_sampler_kind;
+  int spp = sampler_kind == SAMPLER_SOBOL ? spp_req : bluesobol_effective_spp(spp_req);  // SobolSampler::spp() is the request as given
+  BlueTables bt = select_tables(tables, sampler_kind == SAMPLER_SOBOL ? 1 : spp);
   Integrator integ{&scene, depth};
   if (threads <= 0) threads = int(std::thread::hardware_concurrency());
   if (threads <= 0) threads = 1;
@@ -2600,7 +2716,9 @@ void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int dep
   auto work = [&](int tid) {
     Sampler sampler;
     sampler.t = bt;
+    sampler.kind = sampler_kind;
     sampler.spp = spp;
+    sampler.init(W, H);  // RTIntegrator::render integrator.cpp:29
     Counters& cnt = counters[tid];
     while (true) {
       int index = (global_index += batch_size) - batch_size;
@@ -2665,6 +2783,8 @@ void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int dep
 extern "C" {
 
 const char* oracle_last_error(void) { return g_error.c_str(); }
+
+void oracle_set_sampler(int kind) { g_sampler_kind = kind == SAMPLER_SOBOL ? SAMPLER_SOBOL : SAMPLER_BLUE; }
 
 int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,
                   int y0, int y1, float* film_out, oracle_stats* stats) {

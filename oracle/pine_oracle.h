@@ -30,6 +30,10 @@ typedef struct {
 int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,
                   int y0, int y1, float* film_out, oracle_stats* stats);
 
+/* Which sampler the render entry points construct: 0 = BlueSobolSampler(spp) (default), 1 = SobolSampler(spp)
+ * (sampler.h:83-164; spp is used as given, no rounding or clamp).  Process-wide, not thread-safe: test use only. */
+void oracle_set_sampler(int kind);
+
 /* Render only the pixels of this shard (8x8 tiles dealt round-robin, the product's multi-GPU
  * partition); film_out must be zero-initialised by the caller, other pixels are left untouched. */
 int oracle_render_shard(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,

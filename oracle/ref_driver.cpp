@@ -282,20 +282,22 @@ static const int kPixels[][2] = {{0, 0}, {1, 0}, {3, 5}, {127, 127}, {128, 5}, {
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   std::string cmd = argv[1];
-  if (cmd == "render" && argc == 6) {
+  if (cmd == "render" && (argc == 6 || argc == 7)) {
     Loaded L;
     load_pscene(argv[2], L);
     int spp = atoi(argv[3]), depth = atoi(argv[4]);
+    const bool sobol = argc == 7 && std::string(argv[6]) == "sobol";  // SobolSampler(spp) instead of BlueSampler(spp)
     // zero the film first: PathIntegrator::render does not clear it (path.cpp:38 plain store)
     L.scene.camera.film().clear();
-    auto integ = PathIntegrator(Accel(BVH()), BlueSobolSampler(spp), UniformLightSampler(), depth);
+    auto integ = PathIntegrator(Accel(BVH()), sobol ? Sampler(SobolSampler(spp)) : Sampler(BlueSobolSampler(spp)),
+                                UniformLightSampler(), depth);
     auto t0 = std::chrono::steady_clock::now();
     integ.render(L.scene);
     auto t1 = std::chrono::steady_clock::now();
     double sec = std::chrono::duration<double>(t1 - t0).count();
     auto& film = L.scene.camera.film();
     write_file(argv[5], film.data(), size_t(16) * L.W * L.H);
-    int eff = BlueSobolSampler(spp).spp();
+    int eff = sobol ? spp : BlueSobolSampler(spp).spp();
     printf("{\"seconds\": %.6f, \"threads\": %u, \"w\": %d, \"h\": %d, \"spp\": %d, \"depth\": %d, "
            "\"msamples_per_s\": %.6f}\n",
            sec, std::thread::hardware_concurrency(), L.W, L.H, eff, depth,

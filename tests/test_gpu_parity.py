@@ -303,6 +303,20 @@ def test_c1_full_size_whole_image_md5():
     np.testing.assert_allclose(film[..., :3].mean(axis=(0, 1), dtype=np.float64), st["mean_rgb"], rtol=1e-12)
 
 
+@pytest.mark.parametrize("name", ["C3_cbox_1920x1080_s1024_d8", "C4_classic_10k_cones_720x360_s64_d6", "C5_sss_320_s512_d8"])
+def test_other_baseline_configs_whole_image_md5(name):
+    """BASELINE configs C3 (1920x1080, BlueSampler(1024) -> 256 spp), C4 (classic + 10 000 cones) at full size and
+    C5 (Subsurface icosphere, a quarter of the film) : the whole film's md5 equals the REAL reference's."""
+    from pine_amd import scenes
+    st = json.load(open(os.path.join(GOLDEN, "stats_640.json")))[name]
+    sc = {"C3": lambda: scenes.cbox((1920, 1080), "committed"),
+          "C4": lambda: scenes.classic_cones((720, 360), 100),
+          "C5": lambda: scenes.sss((320, 320), 3)}[name[:2]]()
+    film, _ = _render(sc, st["spp"], st["depth"])
+    assert hashlib.md5(film.tobytes()).hexdigest() == st["md5"]
+    np.testing.assert_allclose(film[..., :3].mean(axis=(0, 1), dtype=np.float64), st["mean_rgb"], rtol=1e-12)
+
+
 def test_c2_full_size_whole_image_md5_and_properties():
     """BASELINE config C2 (640x640, 256 spp, depth 8): md5 vs the reference, plus size-independent
     properties: shard sum == whole, black lower half (camera on the floor plane), vertex count."""

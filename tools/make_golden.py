@@ -139,6 +139,18 @@ def main():
                                "ref_seconds": info["seconds"], "ref_threads": info["threads"],
                                "ref_msamples_per_s": info["msamples_per_s"]}
                 print(name, stats[name])
+            # the other BASELINE configs at full size (C5 at a quarter of the film: the reference needs minutes for it)
+            for name, build, spp, depth in (
+                    ("C3_cbox_1920x1080_s1024_d8", lambda: scenes.cbox((1920, 1080), "committed"), 1024, 8),
+                    ("C4_classic_10k_cones_720x360_s64_d6", lambda: scenes.classic_cones((720, 360), 100), 64, 6),
+                    ("C5_sss_320_s512_d8", lambda: scenes.sss((320, 320), 3), 512, 8)):
+                ps, film, info = ref_film(build(), spp, depth, tmp)
+                stats[name] = {"spp": spp, "depth": depth,
+                               "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
+                               "md5": hashlib.md5(film.tobytes()).hexdigest(),
+                               "ref_seconds": info["seconds"], "ref_threads": info["threads"],
+                               "ref_msamples_per_s": info["msamples_per_s"]}
+                print(name, stats[name], flush=True)
             json.dump(stats, open(stats_path, "w"), indent=1)
         json.dump(meta, open(os.path.join(OUT, "films.json"), "w"), indent=1)
 
