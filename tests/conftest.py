@@ -58,6 +58,10 @@ FILM_NAMES = [
 ]
 
 
+SOBOL_FILM_NAMES = ["sobol_cbox_readme_48_s8_d4", "sobol_cbox_ragged_45x37_s12_d3", "sobol_mats_zoo_32_s16_d6",
+                    "sobol_cbox_readme_24_s512_d5"]   # rendered by the reference with SobolSampler(spp)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as o

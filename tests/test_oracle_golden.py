@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, FILM_NAMES, assert_bit_equal, load_film
+from conftest import GOLDEN, FILM_NAMES, SOBOL_FILM_NAMES, assert_bit_equal, load_film
 
 
 @pytest.mark.parametrize("spp", [1, 16, 256])
@@ -68,6 +68,17 @@ def test_film_bit_identical_to_reference(oracle, name):
     film, st = oracle.render(ps, (w, h), spp, depth)
     assert_bit_equal(film, ref, name)
     assert st.camera_samples == w * h * oracle.effective_spp(spp)
+
+
+@pytest.mark.parametrize("name", SOBOL_FILM_NAMES)
+def test_sobol_sampler_film_bit_identical_to_reference(oracle, name):
+    """SobolSampler (sampler.h:83-164, sampler.cpp:81-113): Morton-indexed, base-4 digit permutations, fast Owen
+    scrambling -- the oracle's restatement against films the real reference rendered with SobolSampler(spp)."""
+    ref, ps, spp, depth = load_film(name)
+    h, w, _ = ref.shape
+    film, st = oracle.render(ps, (w, h), spp, depth, sampler="sobol")
+    assert_bit_equal(film, ref, name)
+    assert st.camera_samples == w * h * spp  # no rounding, no clamp
 
 
 def test_row_range_and_shards_compose(oracle):

@@ -28,12 +28,13 @@ def run_ref(*args):
     return subprocess.run([REF, *map(str, args)], capture_output=True, text=True, check=True).stdout
 
 
-def ref_film(scene, spp, depth, tmp):
+def ref_film(scene, spp, depth, tmp, sampler=None):
     w, h = scene.camera.film().size
     sp, fp = os.path.join(tmp, "s.pscene"), os.path.join(tmp, "s.film")
     ps = scene.describe()
     open(sp, "w").write(ps)
-    info = json.loads(run_ref("render", sp, spp, depth, fp).strip().splitlines()[-1])
+    extra = [sampler] if sampler else []  # "sobol": SobolSampler(spp) instead of BlueSampler(spp)
+    info = json.loads(run_ref("render", sp, spp, depth, fp, *extra).strip().splitlines()[-1])
     return ps, np.fromfile(fp, dtype=np.float32).reshape(h, w, 4), info
 
 
@@ -59,6 +60,15 @@ FILMS = {
     "xshapes_48_s16_d5": (lambda: scenes.xshapes_zoo((48, 48)), 16, 5),
     "xshapes_nolights_40_s8_d3": (lambda: scenes.xshapes_zoo((40, 40), extra_lights=False), 8, 3),
     "mesh_glossy_48_s32_d6": (lambda: scenes.sss((48, 48), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True), 32, 6),
+}
+
+
+SOBOL_FILMS = {
+    # SobolSampler(spp) (sampler.h:83-164): odd and even log2(spp), a non-power-of-two spp, more than 256 spp
+    "sobol_cbox_readme_48_s8_d4": (lambda: scenes.cbox((48, 48), "readme"), 8, 4),
+    "sobol_cbox_ragged_45x37_s12_d3": (lambda: scenes.cbox((45, 37), "committed"), 12, 3),
+    "sobol_mats_zoo_32_s16_d6": (lambda: scenes.materials_zoo((32, 32)), 16, 6),
+    "sobol_cbox_readme_24_s512_d5": (lambda: scenes.cbox((24, 24), "readme"), 512, 5),
 }
 
 
@@ -119,6 +129,15 @@ def main():
             np.savez_compressed(os.path.join(OUT, f"film_{name}.npz"), film=film, pscene=np.array(ps),
                                 spp=spp, depth=depth)
             meta[name] = {"spp": spp, "depth": depth, "size": [info["w"], info["h"]],
+                          "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
+                          "md5": hashlib.md5(film.tobytes()).hexdigest()}
+            print(name, meta[name]["mean_rgb"])
+
+        # 3b. SobolSampler films (oracle-only so far: pins oracle.render(..., sampler="sobol"))
+        for name, (build, spp, depth) in SOBOL_FILMS.items():
+            ps, film, info = ref_film(build(), spp, depth, tmp, "sobol")
+            np.savez_compressed(os.path.join(OUT, f"film_{name}.npz"), film=film, pscene=np.array(ps), spp=spp, depth=depth)
+            meta[name] = {"spp": spp, "depth": depth, "size": [info["w"], info["h"]], "sampler": "sobol",
                           "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
                           "md5": hashlib.md5(film.tobytes()).hexdigest()}
             print(name, meta[name]["mean_rgb"])
