@@ -163,7 +163,7 @@ int64_t pine_gpu_scene_accel_dump(pine_gpu_scene*, void* nodes_out, int64_t node
  * PathIntegrator(Accel, Sampler, LightSampler, int) + render(Scene&):
  * src/pine/impl/integrator/path.cpp:7-41, registered program_context.cpp:76-81.  The sampler is
  * BlueSampler(spp) (src/pine/core/sampler.cpp:115-121: spp rounded up to a power of two, clamped
- * to 256), the light sampler UniformLightSampler, the accel pine's BVH order.
+ * to 256) or SobolSampler(spp), the light sampler UniformLightSampler, the accel pine's BVH order.
  */
 typedef struct {
   int32_t spp;             /* requested samples per pixel (BlueSampler argument)            */
@@ -173,8 +173,13 @@ typedef struct {
   int32_t shard_world;     /* 1 = whole film                                                */
   int32_t samples_per_item;/* 0 = auto; work item = this many consecutive samples of a pixel */
   int32_t flags;           /* PINE_GPU_FLAG_*                                               */
-  int32_t reserved;
+  int32_t sampler;         /* PINE_GPU_SAMPLER_*: which Sampler the PathIntegrator is constructed with   */
 } pine_gpu_render_params;
+
+#define PINE_GPU_SAMPLER_BLUE  0 /* BlueSampler(spp)  src/pine/core/sampler.h:166-201 (the default)           */
+#define PINE_GPU_SAMPLER_SOBOL 1 /* SobolSampler(spp) src/pine/core/sampler.h:83-164, sampler.cpp:81-113: spp
+                                    as given (no clamp to 256); on the device a power of two up to 4096, and
+                                    not together with Subsurface materials                                  */
 
 #define PINE_GPU_FLAG_TIMING 1 /* record per-kernel HIP-event timings for the roofline report */
 

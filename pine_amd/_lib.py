@@ -31,7 +31,7 @@ class RenderParams(C.Structure):
         ("shard_world", C.c_int32),
         ("samples_per_item", C.c_int32),
         ("flags", C.c_int32),
-        ("reserved", C.c_int32),
+        ("sampler", C.c_int32),
     ]
 
 

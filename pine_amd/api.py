@@ -382,6 +382,7 @@ class ThinLenCamera:
 
 class BlueSampler:
     """BlueSobolSampler: spp rounded up to a power of two and clamped to 256 (sampler.cpp:115-121)."""
+    kind = 0  # PINE_GPU_SAMPLER_BLUE
 
     def __init__(self, samples_per_pixel):
         if samples_per_pixel <= 0:
@@ -394,6 +395,18 @@ class BlueSampler:
         while p < n:
             p *= 2
         return p
+
+
+class SobolSampler:
+    """SobolSampler(spp) (sampler.h:83-164): spp is used as given -- no rounding, no clamp to 256.  On the
+    device a power of two up to 4096, and not with Subsurface materials (the C ABI reports both)."""
+    kind = 1  # PINE_GPU_SAMPLER_SOBOL
+
+    def __init__(self, samples_per_pixel):
+        self.requested = int(samples_per_pixel)
+
+    def spp(self):
+        return self.requested
 
 
 # ---- Scene (src/pine/core/scene.cpp:64-79) -----------------------------------------------------
@@ -516,13 +529,17 @@ class Plan:
     """A PathIntegrator bound to a scene with all device state resident (bench / multi-GPU)."""
 
     def __init__(self, scene, spp, max_path_length, device=0, shard_rank=0, shard_world=1,
-                 samples_per_item=0, timing=False):
+                 samples_per_item=0, timing=False, sampler="blue"):
+        """spp: an int (BlueSampler(spp), or SobolSampler(spp) with sampler="sobol") or a sampler object."""
         if scene.camera is None:
             raise PineError("scene has no camera")
         self.scene = scene
+        kind = 1 if sampler == "sobol" else 0
+        if hasattr(spp, "requested"):
+            kind, spp = getattr(spp, "kind", 0), spp.requested
         self.params = _lib.RenderParams(int(spp), int(max_path_length), int(device), int(shard_rank),
                                         int(shard_world), int(samples_per_item),
-                                        _lib.FLAG_TIMING if timing else 0, 0)
+                                        _lib.FLAG_TIMING if timing else 0, kind)
         h = lib.pine_gpu_plan_create(scene._h, C.byref(self.params))
         if not h:
             raise PineError("PathIntegrator: " + _lib.last_error())
@@ -589,7 +606,8 @@ class PathIntegrator:
         if scene.camera is None:
             raise PineError("scene has no camera")
         film = scene.camera.film()
-        prm = _lib.RenderParams(self.sampler.requested, self.max_path_length, self.device, 0, 1, 0, 0, 0)
+        prm = _lib.RenderParams(self.sampler.requested, self.max_path_length, self.device, 0, 1, 0, 0,
+                                getattr(self.sampler, "kind", 0))
         out = np.zeros((film.size[1], film.size[0], 4), dtype=np.float32)
         check(lib.pine_gpu_path_render(scene._h, C.byref(prm), out.ctypes.data_as(_lib.c_f_p)), "PathIntegrator.render")
         film.pixels = out

@@ -27,7 +27,8 @@ enum : unsigned {
   F_NODES = 1u << 9,      // material parameters may be shading-node programs (node.h)
   F_LIGHTS = 1u << 10,    // Point / Spot / Directional lights or an environment light are present
   F_XSHAPES = 1u << 11,   // Plane / Line / Cylinder / stand-alone Triangle
-  F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES,
+  F_SOBOL = 1u << 12,     // the sampler may be SobolSampler (DTables::kind) instead of BlueSampler
+  F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES | F_SOBOL,
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -104,6 +105,10 @@ struct DTables {
   const uint32_t* lds_scr;   // scrambling bytes: dword k (dims 4k..4k+3 mod 8) at lds_scr[k * tile_stride]
   int tile_stride;           // = workgroup size: the slices are [dword][thread]
   int win_lo, win_len;       // dimensions [win_lo, win_lo + win_len) are present in the cache
+  // SobolSampler instead (F_SOBOL variants only; sampler.h:83-164): nothing is read from the tables
+  int kind;                  // 0 = BlueSampler, 1 = SobolSampler
+  int sobol_log2_spp;        // psl::log2i(spp) (sampler.h:127-129)
+  int sobol_digits;          // nbase4_digits (sampler.cpp:81-84)
 };
 // value = sobol[dim + (index ^ rank[(dim + pix*8) % N]) * 256] ^ scramble[dim % 8 + pix*8]
 // (bluenoise_*spp.cpp:14-34); LDS = true reads dims < kLdsSamplerDims from the workgroup cache.
@@ -136,18 +141,129 @@ struct DSampler {
   int index;      // sample index within the pixel
   int dimension;  // BlueSobolSampler::dimension
 };
-template <bool LDS = false>
-PINE_HD float sampler_get1d(const DTables& t, DSampler& s) {  // sampler.h:183-187
-  if (s.dimension >= 256) s.dimension = 2;
-  return blue_sample_dimension<LDS>(t, s.px, s.py, s.index, s.dimension++);
+// ---- SobolSampler (sampler.h:83-164, sampler.cpp:81-113, lowdiscrepancy.h:73-80): integer exact ----
+PINE_HD uint64_t mix_bits(uint64_t v) {  // rng.h:81-88
+  v ^= (v >> 31);
+  v *= 0x7fb5d329728ea185ull;
+  v ^= (v >> 27);
+  v *= 0x81dadef4bc2dd44dull;
+  v ^= (v >> 33);
+  return v;
 }
-template <bool LDS = false>
-PINE_HD f2 sampler_get2d(const DTables& t, DSampler& s) {  // sampler.h:188-194
+PINE_HD uint32_t reverse_bits32(uint32_t x) { return __builtin_bitreverse32(x); }  // math.h:20-27 (one v_bfrev_b32)
+PINE_HD uint64_t left_shift_64x2(uint64_t x) {  // vecmath.h:1231-1239
+  x &= 0xffffffffull;
+  x = (x ^ (x << 16)) & 0x0000ffff0000ffffull;
+  x = (x ^ (x << 8)) & 0x00ff00ff00ff00ffull;
+  x = (x ^ (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+  x = (x ^ (x << 2)) & 0x3333333333333333ull;
+  x = (x ^ (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+PINE_HD uint64_t hash_int(int v) {  // hash(dimension): murmur_hash64A over 4 bytes, seed 0 (rng.h:9-49, :60-65)
+  const uint64_t m = 0xc6a4a7935bd1e995ull;
+  const int r = 47;
+  uint64_t h = 0 ^ (4ull * m);
+  const uint32_t t = uint32_t(v);
+  h ^= uint64_t((t >> 24) & 0xff) << 24;
+  h ^= uint64_t((t >> 16) & 0xff) << 16;
+  h ^= uint64_t((t >> 8) & 0xff) << 8;
+  h ^= uint64_t(t & 0xff);
+  h *= m;
+  h ^= h >> r;
+  h *= m;
+  h ^= h >> r;
+  return h;
+}
+PINE_HD uint32_t fast_owen(uint32_t v, uint32_t seed) {  // FastOwenScrambler sampler.h:95-109
+  v = reverse_bits32(v);
+  v ^= v * 0x3d20adeau;
+  v += seed;
+  v *= (seed >> 16) | 1u;
+  v ^= v * 0x05526c56u;
+  v ^= v * 0x53a22864u;
+  return reverse_bits32(v);
+}
+// sobol_sample (lowdiscrepancy.h:73-80) for the two dimensions SobolSampler reads.  Their generator
+// matrices (sobolmatrices.cpp:40-, 52 columns each) have closed forms: dimension 0 is the bit reversal of
+// the low 32 index bits (column i = 2^31 >> i, zero from i = 32); dimension 1's columns follow
+// v[0] = 2^31, v[i+1] = v[i] ^ (v[i] >> 1) through all 52 (the oracle checks both against films rendered
+// by the reference).
+PINE_HD float sobol_sample01(uint64_t a, int dim, uint32_t seed) {
+  uint32_t v = 0;
+  if (dim == 0) {
+    v = reverse_bits32(uint32_t(a));
+  } else {
+    uint32_t col = 0x80000000u;
+    for (; a != 0; a >>= 1) {
+      if (a & 1) v ^= col;
+      col ^= col >> 1;
+    }
+  }
+  v = fast_owen(v, seed);
+  return pmin(float(v) * 0x1p-32f, kOneMinusEps);
+}
+PINE_HD uint64_t sobol_index_of(const DTables& t, int px, int py, int index) {  // sampler.h:135-142
+  const uint64_t morton = (left_shift_64x2(uint32_t(py)) << 1) | left_shift_64x2(uint32_t(px));  // vecmath.h:1243-1245
+  return (morton << t.sobol_log2_spp) + uint64_t(uint32_t(index));  // start_pixel ORs sample 0 in, start_next_sample increments
+}
+PINE_HD uint64_t sobol_compute_sample_index(const DTables& t, uint64_t sobol_index, int dimension) {  // sampler.cpp:86-113
+  // the 24 permutations of {0,1,2,3} in the reference's order, one per byte-quadruple: digit d of
+  // permutation p is (kPerm[p] >> (2 * d)) & 3
+  constexpr uint8_t kPerm[24] = {
+      0xe4, 0xb4, 0xd8, 0x78, 0x6c, 0x9c, 0xe1, 0xb1, 0xc9, 0x39, 0x2d, 0x8d,
+      0xc6, 0x36, 0xd2, 0x72, 0x4e, 0x1e, 0x27, 0x87, 0x1b, 0x4b, 0x63, 0x93};
+  uint64_t si = 0;
+  const bool only_power_of_2 = (t.sobol_log2_spp & 1) != 0;
+  const int last_digit = only_power_of_2 ? 1 : 0;
+  const uint64_t dim_mix = uint64_t(0x55555555u * uint32_t(dimension));
+  for (int i = t.sobol_digits - 1; i >= last_digit; --i) {
+    const int digit_shift = 2 * i - (only_power_of_2 ? 1 : 0);
+    const int digit = int((sobol_index >> digit_shift) & 3);
+    const uint64_t higher_digits = sobol_index >> (digit_shift + 2);
+    const int p = int((mix_bits(higher_digits ^ dim_mix) >> 24) % 24);
+    si |= uint64_t((kPerm[p] >> (2 * digit)) & 3) << digit_shift;
+  }
+  if (only_power_of_2) {
+    const int digit = int(sobol_index & 1);
+    si |= uint64_t(digit ^ int(mix_bits((sobol_index >> 1) ^ dim_mix) & 1));
+  }
+  return si;
+}
+
+// Sampler front: MODE bit 0 = the workgroup has the BlueSampler LDS cache, bit 1 = the variant also
+// carries SobolSampler (selected at run time by DTables::kind).
+constexpr int kSmLds = 1, kSmSobol = 2;
+template <int MODE = 0>
+PINE_HD float sampler_get1d(const DTables& t, DSampler& s) {  // sampler.h:183-187 / :143-148
+  if constexpr (MODE & kSmSobol) {
+    if (t.kind == 1) {
+      const uint64_t si = sobol_compute_sample_index(t, sobol_index_of(t, s.px, s.py, s.index), s.dimension);
+      s.dimension += 1;
+      const uint64_t u = hash_int(s.dimension);
+      return sobol_sample01(si, 0, uint32_t(u));
+    }
+  }
+  if (s.dimension >= 256) s.dimension = 2;
+  return blue_sample_dimension<(MODE & kSmLds) != 0>(t, s.px, s.py, s.index, s.dimension++);
+}
+template <int MODE = 0>
+PINE_HD f2 sampler_get2d(const DTables& t, DSampler& s) {  // sampler.h:188-194 / :149-155
+  if constexpr (MODE & kSmSobol) {
+    if (t.kind == 1) {
+      const uint64_t si = sobol_compute_sample_index(t, sobol_index_of(t, s.px, s.py, s.index), s.dimension);
+      s.dimension += 2;
+      const uint64_t u = hash_int(s.dimension);
+      const float a = sobol_sample01(si, 0, uint32_t(u));
+      const float b = sobol_sample01(si, 1, uint32_t(u >> 32));
+      return f2{a, b};
+    }
+  }
   if (s.dimension + 1 >= 256) s.dimension = 2;
   const int dim = s.dimension;
   s.dimension += 2;
-  const float a = blue_sample_dimension<LDS>(t, s.px, s.py, s.index, dim);
-  const float b = blue_sample_dimension<LDS>(t, s.px, s.py, s.index, dim + 1);
+  const float a = blue_sample_dimension<(MODE & kSmLds) != 0>(t, s.px, s.py, s.index, dim);
+  const float b = blue_sample_dimension<(MODE & kSmLds) != 0>(t, s.px, s.py, s.index, dim + 1);
   return f2{a, b};
 }
 // with_probability (sampler.h:317-324): consumes an RNG float only for prob strictly in (0,1)
@@ -1082,7 +1198,7 @@ struct DBsdfSample {
   float pdf;
   bool is_delta;
 };
-template <unsigned F = F_ALL, bool LDS = false>
+template <unsigned F = F_ALL, int LDS = 0>
 PINE_HD bool bxdf_sample(const DBxdf& b, const DTables& T, DSampler& sampler, DBsdfSample& bs) {
   const f3 wi = b.wi;
   bs.is_delta = false;

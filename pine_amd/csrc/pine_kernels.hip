@@ -388,20 +388,23 @@ constexpr int kOffStack = kOffSobol + kLdsSamplerDims * 256 / 4;
 constexpr size_t kLdsFixedBytes = size_t(kOffStack) * 4;
 
 // Packed per-lane path bookkeeping (one VGPR):
-//   bits 0-8 sample index within the pixel (= BlueSobolSampler::index), 9-17 sampler dimension,
-//   18-23 Vertex::length, 24-29 Vertex::diffuse_length, 30 Vertex::is_delta
+//   bits 0-11 sample index within the pixel (BlueSobolSampler::index / the low part of SobolSampler's index),
+//   12-20 sampler dimension, 21-26 Vertex::length, 27 Vertex::diffuse_length > 0 (all the path reads of it,
+//   path.cpp:93), 28 Vertex::is_delta.  Bits 29-31 stay clear (0xffffffff marks an empty context).
+constexpr int kMaxDeviceSpp = 4096;      // 12 bits of sample index
+constexpr int kMaxSamplerDimension = 511;  // 9 bits: BlueSampler wraps at 256; SobolSampler counts up to 8 draws per vertex
 struct PackedState {
   unsigned v;
-  __device__ __forceinline__ int s_cur() const { return int(v & 0x1ffu); }
-  __device__ __forceinline__ int dim() const { return int((v >> 9) & 0x1ffu); }
-  __device__ __forceinline__ int length() const { return int((v >> 18) & 0x3fu); }
-  __device__ __forceinline__ int diffuse_length() const { return int((v >> 24) & 0x3fu); }
-  __device__ __forceinline__ bool is_delta() const { return (v >> 30) & 1u; }
-  __device__ __forceinline__ void set_dim(int d) { v = (v & ~(0x1ffu << 9)) | (unsigned(d) << 9); }
-  __device__ __forceinline__ void start_sample(int s) { v = unsigned(s) | (1u << 30); }  // dim 0, first_vertex()
+  __device__ __forceinline__ int s_cur() const { return int(v & 0xfffu); }
+  __device__ __forceinline__ int dim() const { return int((v >> 12) & 0x1ffu); }
+  __device__ __forceinline__ int length() const { return int((v >> 21) & 0x3fu); }
+  __device__ __forceinline__ int diffuse_length() const { return int((v >> 27) & 1u); }  // 0 or "at least 1"
+  __device__ __forceinline__ bool is_delta() const { return (v >> 28) & 1u; }
+  __device__ __forceinline__ void set_dim(int d) { v = (v & ~(0x1ffu << 12)) | (unsigned(d) << 12); }
+  __device__ __forceinline__ void start_sample(int s) { v = unsigned(s) | (1u << 28); }  // dim 0, first_vertex()
   __device__ __forceinline__ void next_vertex(bool delta) {  // Vertex(pv, pdf, is_delta) path.cpp:18-19
-    v = (v & 0x3ffffu) + ((unsigned(length()) + 1u) << 18) + ((unsigned(diffuse_length()) + (delta ? 0u : 1u)) << 24) +
-        (delta ? (1u << 30) : 0u);
+    v = (v & 0x1fffffu) + ((unsigned(length()) + 1u) << 21) + (((v >> 27) & 1u) | (delta ? 0u : 1u)) * (1u << 27) +
+        (delta ? (1u << 28) : 0u);
   }
 };
 
@@ -410,6 +413,7 @@ __global__ void __launch_bounds__(kBlock, WAVES_PER_SIMD)
 path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, Counters* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  constexpr int kSM = kSmLds | ((F & F_SOBOL) ? kSmSobol : 0);  // sampler front mode (pine_device.h)
   const unsigned tid = threadIdx.x;
   float* const lds_f = reinterpret_cast<float*>(lds_raw);
   uint32_t* const lds_u = reinterpret_cast<uint32_t*>(lds_raw);
@@ -710,7 +714,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         bx.ior = mp.ior;
       } else if (is_sss) {
         const float fr = FrDielectric(dot(wi, it.n), mat->ior);
-        if (sampler_get1d<true>(T, sampler) < fr) {
+        if (sampler_get1d<kSM>(T, sampler) < fr) {
           bx.kind = BX_REFRACTIVE;
           bx.roughness = pmax(mp.roughness, min_roughness);
           bx.ior = mat->ior;
@@ -752,7 +756,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               h = shape_intersect<F>(shape, wr);
             }
             if (!h) break;  // sample_p returns nullopt: nothing changes
-            const float t = -plog(1 - sampler_get1d<true>(T, sampler)) * sigma_t_inv;
+            const float t = -plog(1 - sampler_get1d<kSM>(T, sampler)) * sigma_t_inv;
             if (wr.tmax < t) {
               beta_channel = channel + 1;
               it.p = sit.p;
@@ -763,7 +767,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               break;
             }
             p = ray_at(wr, t);
-            w = uniform_sphere(sampler_get2d<true>(T, sampler));
+            w = uniform_sphere(sampler_get2d<kSM>(T, sampler));
           }
         }
       }
@@ -773,8 +777,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       f3 nee = mk3(0.0f);
       if (!bxdf_is_delta<F>(bx)) {
         // g++ order for LightSampler::sample's arguments (lightsampler.h:27): get2d, then get1d
-        const f2 u2 = sampler_get2d<true>(T, sampler);
-        float u1 = sampler_get1d<true>(T, sampler);
+        const f2 u2 = sampler_get2d<kSM>(T, sampler);
+        float u1 = sampler_get1d<kSM>(T, sampler);
         if (S.num_lights > 0) {  // UniformLightSampler::sample lightsampler.cpp:12-26
           if (S.num_lights != 1) u1 *= float(S.num_lights);  // x * 1.0f == x exactly
           const int index = int(u1);
@@ -833,7 +837,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       bx.albedo = mp.albedo;
       bx.albedo_over_pi = mp.albedo_over_pi;
       DBsdfSample bs;
-      if (bxdf_sample<F, true>(bx, T, sampler, bs)) {
+      if (bxdf_sample<F, kSM>(bx, T, sampler, bs)) {
         const f3 wo_world = mul(l2w, bs.wo);
         const float cosine = absdot(wo_world, it.n);
         const int level = pv_length;
@@ -1260,9 +1264,20 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     set_error("max_path_length above the supported fold-stack depth (32)");
     return -1;
   }
-  const int spp = effective_spp(prm->spp);
+  // BlueSampler(n): n rounded up to a power of two, clamped to 256 (sampler.cpp:115-121).  SobolSampler(n):
+  // n as given (sampler.h:127-131); the work decomposition here needs a power of two.
+  const bool sobol = prm->sampler == PINE_GPU_SAMPLER_SOBOL;
+  if (prm->sampler != PINE_GPU_SAMPLER_BLUE && !sobol) {
+    set_error("unknown sampler kind");
+    return -1;
+  }
+  const int spp = sobol ? prm->spp : effective_spp(prm->spp);
   if (spp <= 0) {
-    set_error("samples per pixel must be positive");
+    set_error(sobol ? "`SobolSampler` should have positive samples per pixel" : "samples per pixel must be positive");
+    return -1;
+  }
+  if (sobol && ((spp & (spp - 1)) != 0 || spp > kMaxDeviceSpp)) {
+    set_error("SobolSampler on the device: samples per pixel must be a power of two, at most 4096");
     return -1;
   }
   if (prm->shard_world < 1 || prm->shard_rank < 0 || prm->shard_rank >= prm->shard_world) {
@@ -1322,6 +1337,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // tables: sobol + the selected spp variant
   int k = 0;
   while ((1 << k) < spp) k++;
+  if (sobol) k = 0;  // (SobolSampler reads no table; any variant keeps the BlueSampler window loads in bounds)
   // device layout: sobolT 64 KiB | scramble 128 KiB | rank 128 KiB | 64 bytes = rank[0..63] again, so
   // a pixel's 40 consecutive ranking bytes never need the reference's modulo wrap
   HIP_OK(hipMalloc((void**)&p->d_tables, 65536 + 262144 + 64));
@@ -1355,6 +1371,19 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.tables.tile_stride = 0;
   S.tables.win_lo = 0;
   S.tables.win_len = 0;
+  S.tables.kind = sobol ? 1 : 0;
+  {
+    // SobolSampler(spp): log2_spp = psl::log2i(spp); init(image_size): nbase4_digits =
+    // log2i(roundup2(max(w, h))) + (log2_spp + 1) / 2   (sampler.h:127-129, sampler.cpp:81-84)
+    int l2 = 0;
+    while ((2 << l2) <= spp) l2++;
+    int res = 1;
+    while (res < std::max(H.camera.W, H.camera.H)) res *= 2;
+    int lr = 0;
+    while ((2 << lr) <= res) lr++;
+    S.tables.sobol_log2_spp = l2;
+    S.tables.sobol_digits = lr + (l2 + 1) / 2;
+  }
   S.spp = spp;
   S.max_path_length = prm->max_path_length;
   int d_top = 0, d_mesh = 0;
@@ -1390,6 +1419,13 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     if (m.kind == MAT_SUBSURFACE) need |= F_SSS;
   }
   if (!node_ops.empty()) need |= F_NODES;
+  if (sobol) need |= F_SOBOL;
+  if (sobol && (need & F_SSS)) {
+    // a BSSRDF walk draws from the sampler at every step: SobolSampler's dimension counter (no wrap-around,
+    // unlike BlueSampler's) is unbounded there and does not fit the packed path state
+    set_error("SobolSampler with Subsurface materials is not supported on the device");
+    return -1;
+  }
   for (auto& L : light_list)
     if (L.kind != LIGHT_AREA) need |= F_LIGHTS;
   const bool lds_ok = size_t(S.blob_bytes) <= 32 * 1024 && getenv("PINE_GPU_NO_LDS_SCENE") == nullptr;

@@ -73,6 +73,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   constexpr int kQCtx = L::ctx, kQRing = L::ring, kQOffCtl = L::off_ctl, kQOffRing = L::off_ring, kQOffState = L::off_state,
                 kQOffSobol = L::off_sobol, kQOffWin = L::off_win, kQOffStack = L::off_stack;
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  constexpr int kSM = kSmLds | ((F & F_SOBOL) ? kSmSobol : 0);  // sampler front mode (pine_device.h)
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63;
   unsigned* const qctl = reinterpret_cast<unsigned*>(lds_raw + kQOffCtl);
@@ -366,7 +367,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           bx.ior = mp.ior;
         } else if (is_sss) {
           const float fr = FrDielectric(dot(wi, it.n), mat->ior);
-          if (sampler_get1d<true>(T, sampler) < fr) {
+          if (sampler_get1d<kSM>(T, sampler) < fr) {
             bx.kind = BX_REFRACTIVE;
             bx.roughness = pmax(mat->roughness, min_roughness);
             bx.ior = mat->ior;
@@ -406,7 +407,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                 hh = shape_intersect<F>(shape, wr);
               }
               if (!hh) break;
-              const float t = -plog(1 - sampler_get1d<true>(T, sampler)) * sigma_t_inv;
+              const float t = -plog(1 - sampler_get1d<kSM>(T, sampler)) * sigma_t_inv;
               if (wr.tmax < t) {
                 beta_channel = channel + 1;
                 it.p = sit.p;
@@ -417,7 +418,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                 break;
               }
               p = ray_at(wr, t);
-              w = uniform_sphere(sampler_get2d<true>(T, sampler));
+              w = uniform_sphere(sampler_get2d<kSM>(T, sampler));
             }
           }
         }
@@ -425,8 +426,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         // ---- next-event estimation (path.cpp:98-113) ----
         f3 nee = mk3(0.0f);
         if (!bxdf_is_delta<F>(bx)) {
-          const f2 u2 = sampler_get2d<true>(T, sampler);  // g++ order: get2d first (lightsampler.h:27)
-          float u1 = sampler_get1d<true>(T, sampler);
+          const f2 u2 = sampler_get2d<kSM>(T, sampler);  // g++ order: get2d first (lightsampler.h:27)
+          float u1 = sampler_get1d<kSM>(T, sampler);
           if constexpr (F & F_LIGHTS) {
             // general light list (light.cpp:11-84): area lights, delta lights (no MIS, path.cpp:104-106), Sky
             if (S.num_lights > 0) {
@@ -505,7 +506,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         bx.albedo = mp.albedo;
         bx.albedo_over_pi = mp.albedo_over_pi;
         DBsdfSample bs;
-        if (bxdf_sample<F, true>(bx, T, sampler, bs)) {
+        if (bxdf_sample<F, kSM>(bx, T, sampler, bs)) {
           const f3 wo_world = mul(l2w, bs.wo);
           const float cosine = absdot(wo_world, it.n);
           float4* q = fold_entry(id, pv_length);

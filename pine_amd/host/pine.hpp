@@ -128,11 +128,20 @@ struct ThinLenCamera {
   Film& film() { return film_; }
 };
 
-struct BlueSampler {
+struct BlueSampler {  // sampler.h:166-201
   int requested;
   explicit BlueSampler(int spp) : requested(spp) {
     if (spp <= 0) throw Error("`BlueSampler` should have positive samples per pixel");
   }
+};
+struct SobolSampler {  // sampler.h:83-164: spp as given (on the device a power of two up to 4096)
+  int requested;
+  explicit SobolSampler(int spp) : requested(spp) {}
+};
+struct Sampler {  // the variant PathIntegrator takes (sampler.h:275-; Uniform / Halton are not reproducible / not built)
+  int requested, kind;
+  Sampler(BlueSampler s) : requested(s.requested), kind(PINE_GPU_SAMPLER_BLUE) {}
+  Sampler(SobolSampler s) : requested(s.requested), kind(PINE_GPU_SAMPLER_SOBOL) {}
 };
 
 class Scene {
@@ -206,7 +215,7 @@ class Scene {
 
 class PathIntegrator {
  public:
-  PathIntegrator(BlueSampler sampler, int max_path_length, int device = 0)
+  PathIntegrator(Sampler sampler, int max_path_length, int device = 0)
       : sampler_(sampler), max_path_length_(max_path_length), device_(device) {
     if (max_path_length <= 0) throw Error("`PathIntegrator` expect `max_path_length` to be positive");
   }
@@ -217,11 +226,12 @@ class PathIntegrator {
     p.device = device_;
     p.shard_rank = 0;
     p.shard_world = 1;
+    p.sampler = sampler_.kind;
     check(pine_gpu_path_render(scene.handle(), &p, scene.camera.film_.pixels.data()), "PathIntegrator::render");
   }
 
  private:
-  BlueSampler sampler_;
+  Sampler sampler_;
   int max_path_length_, device_;
 };
 

@@ -151,7 +151,7 @@ struct LightObj : Object {
   float falloff = 0, extra = 0;
 };
 struct IntegratorObj : Object {
-  int spp = 0, depth = 0;
+  int spp = 0, depth = 0, sampler = 0;
 };
 
 static Value mk_i32(int v) {
@@ -1728,10 +1728,29 @@ Interp::Interp() {
     return retype(mk_i32(a[0]->i[0]), "BlueSampler");
   });
   r.convert("BlueSampler", "Sampler", [](const Value& v) { return retype(v, "Sampler"); });
+  // SobolSampler(i32) (sampler.cpp:182-188): the value carries the kind in i[1] (PINE_GPU_SAMPLER_SOBOL)
+  r.def("SobolSampler", {"i32"}, "SobolSampler", [](Interp&, std::vector<Cell>& a) {
+    Value v = retype(mk_i32(a[0]->i[0]), "SobolSampler");
+    v.i[1] = PINE_GPU_SAMPLER_SOBOL;
+    return v;
+  });
+  r.convert("SobolSampler", "Sampler", [](const Value& v) { return retype(v, "Sampler"); });
+  for (const char* k : {"BlueSampler", "SobolSampler"})
+    r.def("spp", {k}, "i32", [](Interp&, std::vector<Cell>& a) {
+      int n = a[0]->i[0];
+      if (a[0]->i[1] != PINE_GPU_SAMPLER_SOBOL) {  // BlueSobolSampler ctor sampler.cpp:115-121
+        n = n > 256 ? 256 : n;
+        int p = 1;
+        while (p < n) p *= 2;
+        n = p;
+      }
+      return mk_i32(n);
+    });
   r.def("PathIntegrator", {"Sampler", "i32"}, "PathIntegrator", [](Interp&, std::vector<Cell>& a) {
     if (a[1]->i[0] <= 0) fail("`PathIntegrator` expect `max_path_length` to be positive, get " + std::to_string(a[1]->i[0]));
     auto p = std::make_shared<IntegratorObj>();
     p->spp = a[0]->i[0];
+    p->sampler = a[0]->i[1];
     p->depth = a[1]->i[0];
     return mk_obj("PathIntegrator", p);
   });
@@ -1741,7 +1760,8 @@ Interp::Interp() {
     if (!s->camera) fail("PathIntegrator.render: scene has no camera");
     auto f = obj<CameraObj>(s->camera)->film;
     if (in.flags & PINE_PRL_DRY_RUN) {
-      in.log("@render PathIntegrator BlueSampler " + std::to_string(p->spp) + " max_path_length " + std::to_string(p->depth) + "\n");
+      in.log(std::string("@render PathIntegrator ") + (p->sampler == PINE_GPU_SAMPLER_SOBOL ? "SobolSampler " : "BlueSampler ") +
+             std::to_string(p->spp) + " max_path_length " + std::to_string(p->depth) + "\n");
       in.log(describe_scene(s->h));
       in.log("@end\n");
       return Value();
@@ -1752,6 +1772,7 @@ Interp::Interp() {
     prm.device = in.device;
     prm.shard_rank = 0;
     prm.shard_world = 1;
+    prm.sampler = p->sampler;
     f->pixels.assign(size_t(f->w) * f->h * 4, 0.0f);
     gpu_check(pine_gpu_path_render(s->h, &prm, f->pixels.data()), "PathIntegrator.render");
     in.last_film = f;
@@ -1780,7 +1801,7 @@ static std::string value_text(const Value& v) {
     snprintf(buf, sizeof buf, "%a", double(x));
     return std::string(buf);
   };
-  if (v.type == "i32" || v.type == "BlueSampler") s += std::to_string(v.i[0]);
+  if (v.type == "i32" || v.type == "BlueSampler" || v.type == "SobolSampler") s += std::to_string(v.i[0]);
   else if (v.type == "f32") s += hexf(v.f[0]);
   else if (v.type == "Nodef" || v.type == "Node3f") {
     auto n = std::dynamic_pointer_cast<NodeObj>(v.o);

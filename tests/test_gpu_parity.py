@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, FILM_NAMES, assert_bit_equal, load_film
+from conftest import SOBOL_FILM_NAMES, GOLDEN, FILM_NAMES, assert_bit_equal, load_film
 
 pytestmark = pytest.mark.gpu
 
@@ -170,6 +170,43 @@ def test_film_matches_reference_golden(name):
         assert (film.view(np.uint32) != ref.view(np.uint32)).any(axis=2).mean() < 0.01  # and all but a few pixels are identical
         return
     assert_bit_equal(film, ref, name)
+
+
+def _sobol_scene_for(name):
+    from pine_amd import scenes
+    return {
+        "sobol_cbox_readme_48_s8_d4": lambda: scenes.cbox((48, 48), "readme"),
+        "sobol_cbox_ragged_45x37_s12_d3": lambda: scenes.cbox((45, 37), "committed"),
+        "sobol_mats_zoo_32_s16_d6": lambda: scenes.materials_zoo((32, 32)),
+        "sobol_cbox_readme_24_s512_d5": lambda: scenes.cbox((24, 24), "readme"),
+    }[name]()
+
+
+@pytest.mark.parametrize("name", SOBOL_FILM_NAMES)
+def test_sobol_sampler_film_matches_reference_golden(name):
+    """PathIntegrator(SobolSampler(spp), depth): HIP film vs the film the REAL reference rendered with SobolSampler,
+    bit for bit (incl. 512 spp, above BlueSampler's cap).  A non-power-of-two spp is the reference's to take and the
+    device's to refuse, loudly."""
+    import pine_amd as pa
+    ref, ps, spp, depth = load_film(name)
+    sc = _sobol_scene_for(name)
+    assert sc.describe() == ps
+    if spp & (spp - 1):
+        with pytest.raises(pa.PineError, match="power of two"):
+            pa.Plan(sc, pa.SobolSampler(spp), depth)
+        return
+    film, st = _render(sc, pa.SobolSampler(spp), depth)
+    assert st.spp_effective == spp
+    assert_bit_equal(film, ref, name)
+
+
+def test_sobol_sampler_limits():
+    import pine_amd as pa
+    from pine_amd import scenes
+    with pytest.raises(pa.PineError, match="Subsurface"):
+        pa.Plan(scenes.sss((16, 16), 1), pa.SobolSampler(4), 4)
+    with pytest.raises(pa.PineError, match="positive"):
+        pa.Plan(scenes.cbox((16, 16)), pa.SobolSampler(0), 4)
 
 
 def test_one_shot_host_film_entry_point():

@@ -181,6 +181,19 @@ def test_plane_line_cylinder_triangle_constructors():
         prl.interpret('s := Scene(); s.add(Line([0,0,0],[1,0,0],0.0), Diffuse([1,1,1]));', dry_run=True)
 
 
+def test_sobol_sampler_in_scripts():
+    """sampler.cpp:182-198: SobolSampler(i32) converts to Sampler like BlueSampler; spp() is the argument as given
+    (BlueSampler's is rounded up to a power of two and clamped to 256)."""
+    from pine_amd import prl
+    assert prl.evaluate("SobolSampler(1000).spp()") == "i32 1000"
+    assert prl.evaluate("BlueSampler(1000).spp()") == "i32 256"
+    assert prl.evaluate("BlueSampler(5).spp()") == "i32 8"
+    src = _cornell((64, 64), 32, 4).replace("BlueSampler(spp)", "SobolSampler(spp)")
+    assert "SobolSampler(spp)" in src
+    out = prl.interpret(src, dry_run=True)
+    assert "@render PathIntegrator SobolSampler 32 max_path_length 4" in out
+
+
 def test_node_expressions_resolve_like_the_reference():
     """node.cpp:29-116: operators over Nodef / Node3f with the one-step conversions from numbers and vectors."""
     from pine_amd import prl
