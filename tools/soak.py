@@ -15,6 +15,9 @@ configs = [
     ("tiny 24x16", scenes.cbox((24, 16), "readme"), 16, 5, {}),
     ("classic12", scenes.classic_cones((90, 45), 12), 32, 6, {}),
     ("zoo", scenes.shapes_zoo((48, 48)), 16, 5, {}),
+    ("xshapes", scenes.xshapes_zoo((48, 48)), 16, 5, {}),
+    ("lights", scenes.lights_zoo((64, 64)), 32, 6, {}),
+    ("sobol 64", scenes.cbox((96, 96), "readme"), pine_amd.SobolSampler(64), 6, {}),
 ]
 plans = []
 for name, sc, spp, d, kw in configs:
