@@ -114,9 +114,6 @@ struct DTables {
 // (bluenoise_*spp.cpp:14-34); LDS = true reads dims < kLdsSamplerDims from the workgroup cache.
 template <bool LDS = false>
 PINE_HD float blue_sample_dimension(const DTables& t, int px, int py, int index, int dim) {
-#ifdef PINE_ABL_SAMPLER  /* experiment builds only: no table loads (wrong values, timing only) */
-  return (0.5f + float((px * 7 + py * 31 + dim * 13 + index * 3) & 255)) / 256.0f;
-#endif
   const int si = index & 255;
   const int sd = dim & 255;
   if constexpr (LDS) {

@@ -465,9 +465,6 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     return reinterpret_cast<float4*>(fold) + (size_t(blockIdx.x * kBlock + tid) * size_t(S.max_path_length) + size_t(level)) * 2;
   };
   auto fold_store = [&](int level, const float (&e)[8]) {
-#ifdef PINE_ABL_FOLD
-    return;
-#endif
     if (level < kLdsFoldLevels) {
 #pragma unroll
       for (int i = 0; i < 8; i++) lds_f[kOffFold + (level * 8 + i) * kBlock + tid] = e[i];
@@ -478,10 +475,6 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     }
   };
   auto fold_load = [&](int level, float (&e)[8]) {
-#ifdef PINE_ABL_FOLD
-    for (int i = 0; i < 8; i++) e[i] = 0.25f;
-    return;
-#endif
     if (level < kLdsFoldLevels) {
 #pragma unroll
       for (int i = 0; i < 8; i++) e[i] = lds_f[kOffFold + (level * 8 + i) * kBlock + tid];
@@ -809,11 +802,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             DRay sr = spawn_ray(it.p, it.n, lw, ldist);
             int g2, p2;
             SEC_MARK(5);  // light sampling
-#ifdef PINE_ABL_NOSHADOW
-            const bool occluded = sr.tmax < 0;
-#else
             const bool occluded = scene_traverse<true, F>(V, sr, stack, g2, p2);
-#endif
             SEC_MARK(6);  // shadow traversal
             if (!occluded) {
               bx.albedo = mp.albedo;
@@ -870,11 +859,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       bool lp_valid = has_light_pdf;
       float lp = light_pdf;
       REGION(8);  // terminal fold entry
-#ifdef PINE_ABL_FOLDLOOP
-      for (int level = -1; level >= 0; level--) {
-#else
       for (int level = pv_length - 1; level >= 0; level--) {
-#endif
         REGION(9);  // fold level
         float e[8];
         fold_load(level, e);
@@ -927,11 +912,6 @@ constexpr unsigned kFBoxes = F_AABB | F_OBB;
 constexpr unsigned kFAnalytic = F_AABB | F_OBB | F_SPHERE | F_DISK | F_CONE | F_UBER;
 static const KernelVariant kVariants[] = {
     {kFBoxes | F_LDS_SCENE, 4, path_trace_kernel<kFBoxes | F_LDS_SCENE, 4>, "rect+box/diffuse, scene in LDS"},
-#ifdef PINE_EXPERIMENT_WPS
-    {kFBoxes | F_LDS_SCENE, 5, path_trace_kernel<kFBoxes | F_LDS_SCENE, 5>, "rect+box/diffuse, scene in LDS, 5 waves"},
-    {kFBoxes | F_LDS_SCENE, 6, path_trace_kernel<kFBoxes | F_LDS_SCENE, 6>, "rect+box/diffuse, scene in LDS, 6 waves"},
-    {kFBoxes | F_LDS_SCENE, 8, path_trace_kernel<kFBoxes | F_LDS_SCENE, 8>, "rect+box/diffuse, scene in LDS, 8 waves"},
-#endif
 #ifndef PINE_ONLY_CBOX_VARIANT  /* experiment builds compile just the first variant */
     {kFAnalytic | F_LDS_SCENE, 2, path_trace_kernel<kFAnalytic | F_LDS_SCENE, 2>, "analytic shapes/uber, scene in LDS"},
     {kFAnalytic, 2, path_trace_kernel<kFAnalytic, 2>, "analytic shapes/uber"},

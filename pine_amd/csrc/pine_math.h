@@ -57,75 +57,20 @@ PINE_HD float prcp(float v) {  // == 1.0f / v
 #endif
 }
 // libm-exact sin/cos (see pine_libm.h); on the host these equal std::sin/std::cos of glibc.
-#ifdef PINE_ABL_SINCOS  /* experiment builds only: hardware approximations (timing only) */
-PINE_HD float psin(float v) { return __sinf(v); }
-PINE_HD float pcos(float v) { return __cosf(v); }
-#else
 PINE_HD float psin(float v) { return pine_libm::sinf_glibc(v); }
 PINE_HD float pcos(float v) { return pine_libm::cosf_glibc(v); }
-#endif
 // libm-exact pow / log (pine_libm.h): psl::pow == std::pow (src/psl/math.h:201-202), psl::log == std::log
 PINE_HD float ppow(float a, float b) { return pine_libm::powf_glibc(a, b); }
 PINE_HD float plog(float v) { return pine_libm::logf_glibc(v); }
 PINE_HD void psincos(float v, float& sn, float& cs) {
-#ifdef PINE_ABL_SINCOS
-  sn = psin(v);
-  cs = pcos(v);
-#else
   pine_libm::sincosf_glibc(v, sn, cs);
-#endif
 }
 
 // ---- division ------------------------------------------------------------------------------------
-// `a / b` in device code is hipcc's IEEE-correct expansion: v_div_scale x2, v_rcp, 5 fma/mul,
-// v_div_fmas, v_div_fixup = 11 VALU instructions, and divisions are ~45 % of this path's arithmetic
-// (normalise, plane tests, pdfs).  The scale/fmas/fixup steps only matter for operands near the
-// exponent limits; for ordinary operands the same Newton sequence without them yields the same
-// correctly rounded quotient in 7 instructions.  pdiv() takes that short path when the divisor's
-// and the dividend's exponents are comfortably inside the normal range (or the dividend is zero)
-// and falls back to the full expansion otherwise; tools/div_test.hip checks it bit for bit against
-// `/` on 1e11 operand pairs on the GPU.  PdivR shares the refined reciprocal between several
-// dividends (vec3 / scalar).
-struct PdivR {
-  float d, r;  // divisor, refined reciprocal
-  bool ok;     // divisor in the safe range
-};
-PINE_HD bool pdiv_safe_exp(float x) {  // biased exponent in [68, 186]: |x| in [2^-59, 2^60), so that
-  // the quotient of two such numbers and every intermediate stay well inside the normal range
-  const uint32_t e = (uint32_t(__builtin_bit_cast(int32_t, x)) >> 23) & 0xffu;
-  return e - 68u <= 118u;
-}
-PINE_HD PdivR pdiv_prepare(float d) {
-  PdivR p;
-  p.d = d;
-  p.ok = pdiv_safe_exp(d);
-#if defined(__HIP_DEVICE_COMPILE__)
-  const float r0 = __builtin_amdgcn_rcpf(d);
-  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-  p.r = __builtin_fmaf(e0, r0, r0);
-#else
-  p.r = 0.0f;
-#endif
-  return p;
-}
-PINE_HD float pdiv_apply(float n, const PdivR& p, bool* fast = nullptr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const bool ok = p.ok && (pdiv_safe_exp(n) || n == 0.0f);
-  if (fast) *fast = ok;
-  if (ok) {
-    const float q0 = n * p.r;
-    const float e1 = __builtin_fmaf(-p.d, q0, n);
-    const float q1 = __builtin_fmaf(e1, p.r, q0);
-    const float e2 = __builtin_fmaf(-p.d, q1, n);
-    return __builtin_fmaf(e2, p.r, q1);
-  }
-#else
-  if (fast) *fast = false;
-#endif
-  return n / p.d;
-}
-PINE_HD float pdiv(float n, float d) { return pdiv_apply(n, pdiv_prepare(d)); }
-PINE_HD float pdiv_checked(float n, float d, bool& fast) { return pdiv_apply(n, pdiv_prepare(d), &fast); }
+// `a / b` in device code is hipcc's IEEE-correct expansion (v_div_scale x2, v_rcp, 5 fma/mul, v_div_fmas,
+// v_div_fixup).  A guarded short form (shared refined reciprocal + two residual steps, full expansion
+// outside a safe exponent range) was built, verified bit for bit on 1e11 operand pairs, and measured
+// SLOWER in the path kernel; it is not kept.  Plain division everywhere.
 
 struct f2 {
   float x, y;
@@ -166,7 +111,7 @@ PINE_HD f3 cross(f3 a, f3 b) {                                                 /
 PINE_HD float length_squared(f3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
 PINE_HD float length(f3 v) { return psqrt(length_squared(v)); }
 PINE_HD float distance(f3 a, f3 b) { return length(a - b); }
-// (Tried: v / len with one shared refined reciprocal -- pdiv above applied to the three components behind a
+// (Tried: v / len with one shared refined reciprocal applied to the three components behind a
 //  range guard.  Identical bits, 29 instead of 42 VALU instructions, and 3.5 % SLOWER in the path kernel:
 //  the guard's compares and the rare-path branch cost more than the divisions they save.  Plain division.)
 PINE_HD f3 div_by_length(f3 v, float d) { return v / d; }

@@ -19,9 +19,6 @@
 // device functions in the same order per path; only the scheduling differs.
 #pragma once
 
-#ifndef PINE_QFOLD_BATCH
-#define PINE_QFOLD_BATCH 1
-#endif
 
 namespace pine_gpu {
 
@@ -604,29 +601,10 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             lp_valid = false;
           };
           int level = pv_length - 1;
-#if PINE_QFOLD_BATCH > 1
-          // entries are fetched PINE_QFOLD_BATCH levels at a time (all loads in flight together)
-          // instead of one dependent L2 round trip per level
-          while (level >= 0) {
-            float4 pa[PINE_QFOLD_BATCH], pb[PINE_QFOLD_BATCH];
-#pragma unroll
-            for (int j = 0; j < PINE_QFOLD_BATCH; j++)
-              if (level - j >= 0) {
-                const float4* q = fold_entry(id, level - j);
-                pa[j] = q[0];
-                pb[j] = q[1];
-              }
-#pragma unroll
-            for (int j = 0; j < PINE_QFOLD_BATCH; j++)
-              if (level - j >= 0) fold_step(pa[j], pb[j]);
-            level -= PINE_QFOLD_BATCH;
-          }
-#else
           for (; level >= 0; level--) {
             const float4* q = fold_entry(id, level);
             fold_step(q[0], q[1]);
           }
-#endif
           const int s_now = st.s_cur();
           sample_base = cstu[CF_SBASE * kQCtx + id];
           pxy = cstu[CF_PXY * kQCtx + id];
