@@ -92,6 +92,7 @@ struct DeviceScene {
   const float* tri_verts;
   const DLight* lights;
   const DNodeOp* node_ops;  // shading-node programs (F_NODES variants)
+  const DShape* leaf;       // leaf[i] = the shape record of top-level primitive entry prims[i], see SceneView
   int num_lights;           // entries of `lights` (the light sampler's N)
   int env_light;            // index of the environment light in `lights`, or -1
   int num_shapes;
@@ -104,13 +105,19 @@ struct DeviceScene {
   // the small scene records packed in one 16-byte-aligned blob (for LDS staging):
   const uint4* blob;
   int blob_bytes;
-  int off_nodes, off_shapes, off_materials, off_bvhs, off_prims, off_lights, off_node_ops;  // byte offsets in the blob
+  int off_nodes, off_shapes, off_materials, off_bvhs, off_prims, off_lights, off_node_ops, off_leaf;  // byte offsets in the blob
+  int top_prim_begin;  // prims[top_prim_begin ..) are the top-level BVH's entries
 };
 
 // What the traversal and shading code reads.  In the F_LDS_SCENE specialisation every pointer is
 // derived from the workgroup's LDS copy of the blob (so the loads are ds_read, ~64-cycle latency,
 // instead of L1/L2 round trips); otherwise they point into HBM-backed global memory.
 struct SceneView {
+  // leaf[i]: a COPY of the shape record of top-level primitive entry i, in BVH leaf order, whose `kind`
+  // field holds the packed primitive word (index | emissive | kind).  The leaf loop then needs one memory
+  // round trip per primitive (record address = base + 128 i) instead of two dependent ones (word, then
+  // shapes[word & mask]).  `leaf` is biased by -top_prim_begin so that the BVH's own indices address it.
+  const DShape* leaf;
   const DShape* shapes;
   const DMaterial* materials;
   const DNode* nodes;
@@ -208,10 +215,9 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
   auto leaf = [&](int start, int count) -> bool {
     for (int i = start; i < start + count; i++) {
       REGION(ANY ? 5 : 2);  // leaf primitive test
-      const int word = S.prims[i];
-      const int g = word & kPrimIndexMask;
+      const DShape* sh = &S.leaf[i];
+      const int word = sh->kind;  // (the packed word rides in the copy's kind field)
       const int kind = word >> kPrimKindShift;
-      const DShape* sh = &S.shapes[g];
       bool is_mesh = false;
       if constexpr (F & F_MESH) is_mesh = kind == SHAPE_MESH;
       if (is_mesh) {
@@ -447,8 +453,10 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.prims = reinterpret_cast<const int*>(base + S.off_prims);
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
+    V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
   } else {
     __syncthreads();  // Sobol rows staged above
+    V.leaf = S.leaf;
     V.nodes = S.nodes;
     V.shapes = S.shapes;
     V.materials = S.materials;
@@ -1306,6 +1314,14 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     packed_prims[i] = g | (H.materials[size_t(sh.material)].kind == MAT_EMISSIVE ? kPrimEmissiveBit : 0) | (sh.kind << kPrimKindShift);
   }
   S.off_prims = put(packed_prims.data(), packed_prims.size() * sizeof(int));
+  std::vector<DShape> leaf_shapes;  // SceneView::leaf
+  for (size_t i = size_t(A.top_prim_begin); i < packed_prims.size(); i++) {
+    DShape c = shapes[size_t(packed_prims[i] & kPrimIndexMask)];
+    c.kind = packed_prims[i];
+    leaf_shapes.push_back(c);
+  }
+  S.off_leaf = put(leaf_shapes.data(), leaf_shapes.size() * sizeof(DShape));
+  S.top_prim_begin = A.top_prim_begin;
   std::vector<DLight> light_list = H.lights;  // + the environment light last (lightsampler.cpp:6-10)
   if (H.has_env) light_list.push_back(H.env);
   S.off_lights = put(light_list.data(), light_list.size() * sizeof(DLight));
@@ -1335,6 +1351,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.materials = reinterpret_cast<const DMaterial*>(p->d_blob + S.off_materials);
   S.bvhs = reinterpret_cast<const DBvh*>(p->d_blob + S.off_bvhs);
   S.prims = reinterpret_cast<const int*>(p->d_blob + S.off_prims);
+  S.leaf = reinterpret_cast<const DShape*>(p->d_blob + S.off_leaf) - S.top_prim_begin;
   S.lights = reinterpret_cast<const DLight*>(p->d_blob + S.off_lights);
   S.node_ops = reinterpret_cast<const DNodeOp*>(p->d_blob + S.off_node_ops);
   S.tri_verts = p->d_tri;

@@ -101,7 +101,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.prims = reinterpret_cast<const int*>(base + S.off_prims);
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
+    V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
   } else {
+    V.leaf = S.leaf;
     V.nodes = S.nodes;
     V.shapes = S.shapes;
     V.materials = S.materials;
