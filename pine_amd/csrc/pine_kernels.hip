@@ -944,6 +944,9 @@ static const QueueVariant kQueueVariants[] = {
 #ifndef PINE_ONLY_CBOX_VARIANT
     PINE_QV(kFAnalytic | F_LDS_SCENE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS"),
     PINE_QV(kFAnalytic, PINE_QCTX, "queue: analytic shapes/uber"),
+    // the same analytic feature set with 1024 contexts, for BVHs whose traversal stack (4 KB of LDS per slot)
+    // leaves no room for 1536 (the 10 000-cone scene: depth 16)
+    PINE_QV(kFAnalytic, 1024, "queue: analytic shapes/uber, 1024 contexts (deep BVH)"),
     // everything except Subsurface (meshes, node-graph materials, every light kind); 1024 contexts so that
     // a deep traversal stack (4 KB of LDS per slot, two BVH levels for meshes) fits
     PINE_QV((F_ALL & ~F_SSS), 1024, "queue: all but SSS, 1024 contexts (deep BVH)"),
