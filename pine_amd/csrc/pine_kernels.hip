@@ -940,6 +940,7 @@ struct QueueVariant {
 };
 #define PINE_QV(F, CTX, NAME) {F, CTX, QLayout<CTX>::fixed_bytes, path_queue_kernel<F, CTX>, NAME}
 static const QueueVariant kQueueVariants[] = {
+    PINE_QV(F_OBB | F_LDS_SCENE, PINE_QCTX, "queue: rect+transformed box/diffuse, scene in LDS"),  // cbox exactly
     PINE_QV(kFBoxes | F_LDS_SCENE, PINE_QCTX, "queue: rect+box/diffuse, scene in LDS"),
 #ifndef PINE_ONLY_CBOX_VARIANT
     PINE_QV(kFAnalytic | F_LDS_SCENE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS"),
