@@ -947,6 +947,7 @@ static const QueueVariant kQueueVariants[] = {
     PINE_QV(kFAnalytic, PINE_QCTX, "queue: analytic shapes/uber"),
     // the same analytic feature set with 1024 contexts, for BVHs whose traversal stack (4 KB of LDS per slot)
     // leaves no room for 1536 (the 10 000-cone scene: depth 16)
+    PINE_QV(F_SPHERE | F_DISK | F_CONE | F_UBER, 1024, "queue: rect+sphere+disk+cone/uber, 1024 contexts (classic.pine's kinds exactly)"),
     PINE_QV(kFAnalytic, 1024, "queue: analytic shapes/uber, 1024 contexts (deep BVH)"),
     // everything except Subsurface (meshes, node-graph materials, every light kind); 1024 contexts so that
     // a deep traversal stack (4 KB of LDS per slot, two BVH levels for meshes) fits
