@@ -7,6 +7,7 @@
  * function table mirrors the names, overloads and one-step implicit conversions registered in
  * setup_program_context() (src/pine/core/program_context.cpp:23-125) for the PathIntegrator path;
  * `PathIntegrator(...).render(scene)` runs on the MI355X through libpine_gpu.so.
+ * Statements, loops, `fn` definitions with `return`; no `class`, no lambdas.
  * No LLVM, no CPU rendering fallback.
  */
 #ifndef PINE_PRL_H

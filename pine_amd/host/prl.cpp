@@ -244,12 +244,14 @@ struct Resolved {
 struct Node;
 using NodeP = std::shared_ptr<Node>;
 struct Node {
-  enum Kind { Num, Bool, Str, Vec, Id, Call, Member, Unary, Binary, Decl, Block, While, For, If, ExprStmt, Break, Continue, Empty } kind;
+  enum Kind { Num, Bool, Str, Vec, Id, Call, Member, Unary, Binary, Decl, Block, While, For, If, ExprStmt, Break, Continue, Empty, FnDef, Return } kind;
   int line = 0, col = 0;
   std::string text;          // literal text / identifier / function name / operator
   std::vector<NodeP> kids;   // operands / arguments / statements
   int flag = 0;              // Decl: 0 `:=`, 1 `&=`, 2 `=`;  Bool: value
   NodeP a, b, c, d;          // For: init, cond, inc, body; If: cond(a) body(b) else(c); While: cond(a) body(b)
+  std::vector<std::pair<std::string, std::string>> params;  // FnDef: (name, type) pairs; text = name, rtype = return type, b = body
+  std::string rtype;
 };
 static NodeP mk(Node::Kind k, int line, int col) {
   auto n = std::make_shared<Node>();
@@ -323,10 +325,41 @@ struct Parser {
     if (expect("while")) return while_();
     if (expect("for")) return for_();
     if (expect("if")) return if_chain();
-    if (expect("fn")) error("`fn` definitions are not supported by this front-end");
+    if (expect("fn")) return fn_def();
     if (expect("class")) error("`class` definitions are not supported by this front-end");
     return stmt();
   }
+  // fn name(a: T, b: U): R { ... }   (jit.cpp:1695-1706, 1935-1969; function-typed parameters are lambdas'
+  // business and stay unsupported)
+  std::string type_name() {
+    skip();
+    if (expect("(")) error("function types (lambdas) are not supported by this front-end");
+    std::string t = id();
+    if (accept("&")) t += "&";
+    return t;
+  }
+  NodeP fn_def() {
+    auto n = here(Node::FnDef);
+    consume("fn", "to start function definition");
+    n->text = id();
+    consume("(", "to begin parameter definition");
+    if (!expect(")"))
+      while (true) {
+        std::string name = id();
+        consume(":", "to specify its type");
+        n->params.push_back({name, type_name()});
+        if (expect(")")) break;
+        consume(",", "to continue specify parameter");
+      }
+    consume(")", "to end parameter definition");
+    consume(":", "to specify return type");
+    n->rtype = type_name();
+    fn_depth++;
+    n->b = block(false);
+    fn_depth--;
+    return n;
+  }
+  int fn_depth = 0;
   NodeP while_() {
     auto n = here(Node::While);
     consume("while");
@@ -414,7 +447,11 @@ struct Parser {
     NodeP s;
     if (accept("break")) s = mk(Node::Break, at->line, at->col);
     else if (accept("continue")) s = mk(Node::Continue, at->line, at->col);
-    else if (accept("return")) error("`return` can only be used inside a function");
+    else if (accept("return")) {
+      if (fn_depth == 0) error("`return` can only be used inside a function");
+      s = mk(Node::Return, at->line, at->col);
+      if (!expect(";")) s->a = expr();
+    }
     else {
       if (!eof() && idstart(src[pos])) {
         const size_t save = pos;
@@ -665,6 +702,9 @@ struct Parser {
 // ------------------------------------------------------------------------------------------------
 struct BreakSignal {};
 struct ContinueSignal {};
+struct ReturnSignal {
+  Cell value;  // null for `return;`
+};
 
 struct Interp {
   Registry R;
@@ -816,6 +856,64 @@ struct Interp {
     return f->impl(*this, one).b;
   }
 
+  // A script function (jit.cpp FunctionDefinition): registered like a built-in, so calls resolve through the
+  // same overload / one-step-conversion rules.  The body sees its parameters only -- in the reference it is a
+  // separate JIT'd function and the script's top-level variables are locals of main() -- plus the registered
+  // constants and functions.  The returned value converts to the declared type by a registered conversion.
+  void define_function(const NodeP& def) {
+    std::vector<std::string> ptypes;
+    for (auto& pr : def->params) {
+      std::string t = pr.second;
+      const std::string bare = (!t.empty() && t.back() == '&') ? t.substr(0, t.size() - 1) : t;
+      if (!known_type(bare)) error(*def, "Type `" + bare + "` is not found");
+      ptypes.push_back(t);
+    }
+    if (def->rtype != "void" && !known_type(def->rtype)) error(*def, "Type `" + def->rtype + "` is not found");
+    NodeP d = def;
+    R.def(def->text, ptypes, def->rtype, [d](Interp& in, std::vector<Cell>& args) -> Value {
+      std::vector<std::map<std::string, Cell>> saved;
+      saved.swap(in.scopes);
+      in.scopes.emplace_back();
+      for (size_t k = 0; k < d->params.size(); k++) {
+        const std::string& t = d->params[k].second;
+        // by value unless declared `T&`
+        in.scopes.back()[d->params[k].first] = (!t.empty() && t.back() == '&') ? args[k] : cell(*args[k]);
+      }
+      if (++in.call_depth > 200) {
+        in.call_depth--;
+        in.scopes.swap(saved);
+        in.error(*d, "function calls nested more than 200 deep");
+      }
+      Cell result;
+      try {
+        in.exec(d->b);
+      } catch (ReturnSignal& r) {
+        result = r.value;
+      } catch (...) {
+        in.call_depth--;
+        in.scopes.swap(saved);
+        throw;
+      }
+      in.call_depth--;
+      in.scopes.swap(saved);
+      if (d->rtype == "void") return Value();
+      if (!result) in.error(*d, "function `" + d->text + "` ended without returning a `" + d->rtype + "`");
+      if (result->type == d->rtype) return *result;
+      if (const Fn* cv = in.R.unique("@convert." + result->type + "." + d->rtype)) {
+        std::vector<Cell> one{result};
+        return cv->impl(in, one);
+      }
+      in.error(*d, "function `" + d->text + "` returns `" + result->type + "` where `" + d->rtype + "` is declared");
+    });
+  }
+  bool known_type(const std::string& t) const {
+    static const char* basic[] = {"i32", "f32", "bool", "str", "vec2", "vec3", "vec4", "vec2i", "vec3i", "vec4i", "mat4"};
+    for (const char* b : basic)
+      if (t == b) return true;
+    if (R.types.count(t)) return true;
+    return R.fns.count(t) != 0;  // a type with a registered constructor of its own name (Scene, Rect, Diffuse, ...)
+  }
+  int call_depth = 0;
   void exec(const NodeP& n) {
     switch (n->kind) {
       case Node::Empty: return;
@@ -831,6 +929,8 @@ struct Interp {
         return;
       }
       case Node::ExprStmt: eval(n->a); return;
+      case Node::Return: throw ReturnSignal{n->a ? eval(n->a) : nullptr};
+      case Node::FnDef: define_function(n); return;
       case Node::Decl: {  // jit.cpp:1252-1264
         if (n->flag == 2)
           if (Cell x = find_var(n->text)) {

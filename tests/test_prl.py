@@ -111,7 +111,7 @@ def test_statements_and_control_flow():
     assert out.split("\n") == ["10", "3", "1.5000", "10", "2.5000", "4", "21", "9", "ten", "[2 4 6]", "[0.5000 0.2500]",
                                "true", "ab3", ""]
     for src, msg in [("x := 1; y := x +;", "primary expression"), ("break;", "loop"), ("a := 1 a := 2;", "Expect `;`"),
-                     ("fn f(): i32 { }", "not supported"), ("s := Scene(); s.render(3);", "is not found"),
+                     ("class A { }", "not supported"), ("s := Scene(); s.render(3);", "is not found"),
                      ("for i in 0..3 { undefined_thing; }", "is not found"), ("PathIntegrator(BlueSampler(4), 0);", "max_path_length"),
                      ("BlueSampler(0);", "positive samples"), ("s := Scene(); s.add(Rect([0,0,0],[1,0,0],[0,0,1]), \"m\");", "Can't find material")]:
         with pytest.raises(prl.PrlError, match=msg):
@@ -179,6 +179,49 @@ def test_plane_line_cylinder_triangle_constructors():
     assert ps == s.describe()
     with pytest.raises(prl.PrlError, match="positive thickness"):
         prl.interpret('s := Scene(); s.add(Line([0,0,0],[1,0,0],0.0), Diffuse([1,1,1]));', dry_run=True)
+
+
+def test_script_functions():
+    """`fn name(a: T, ...): R { ... }` and `return` (jit.cpp:1695-1721): registered like built-ins, so overload
+    resolution and the one-step conversions apply to calls and to the returned value; a body sees only its
+    parameters (in the reference it is a separate JIT'd function; top-level variables are locals of main)."""
+    from pine_amd import prl
+    src = """
+fn sq(x: f32): f32 { return x * x; }
+fn fact(n: i32): i32 { if n <= 1 { return 1; } return n * fact(n - 1); }
+fn first_big(limit: i32): i32 { for i in 0..100 { if i * i > limit { return i; } } return -1; }
+fn bump(v: vec3&): void { v = v + [1.0, 0.0, 0.0]; }
+fn sq(v: vec3): f32 { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; }
+p := [1.0, 2.0, 3.0];
+bump(p);
+println("" + sq(3) + " " + fact(5) + " " + first_big(50) + " " + p + " " + sq(p));
+"""
+    assert prl.interpret(src, dry_run=True).strip() == "9.0000 120 8 [2.0000 2.0000 3.0000] 17.0000"
+    for bad, msg in [("fn f(x: f32): f32 { return y; } f(1.0);", "Variable `y` is not found"),
+                     ("y := 2.0; fn f(x: f32): f32 { return x * y; } f(1.0);", "Variable `y` is not found"),
+                     ("fn f(x: f32): f32 { } f(1.0);", "ended without returning"),
+                     ("fn f(x: nosuch): f32 { return 1.0; }", "Type `nosuch` is not found"),
+                     ("return 3;", "only be used inside a function"),
+                     ("fn f(x: f32): Shape { return x; } f(1.0);", "where `Shape` is declared"),
+                     ("fn r(n: i32): i32 { return r(n + 1); } r(0);", "nested more than 200 deep"),
+                     ("f := (p: vec3): f32 { return p[0]; };", "not supported")]:
+        with pytest.raises(prl.PrlError, match=msg):
+            prl.interpret(bad, dry_run=True)
+    # examples/functions.pine: functions returning Shape / Material build the scene the API builds directly
+    import pine_amd as pa
+    out = prl.interpret(open(os.path.join(ROOT, "examples", "functions.pine")).read(), dry_run=True)
+    ps, spp, depth = prl.scene_of_dry_run(out)
+    s = pa.Scene()
+    s.add("floor", pa.Diffuse([0.75, 0.75, 0.75]))
+    s.add(pa.Rect([0, 0, 1], [3, 0, 0], [0, 0, 3], True), "floor")
+    s.add(pa.Rect([0, 1, 2.5], [3, 0, 0], [0, 2, 0], True), "floor")
+    for i in range(5):
+        x, h = -1.0 + 0.5 * i, (0.5 if i % 2 == 0 else 1.0)
+        s.add(pa.Box(pa.AABB([x, 0.0, 1.0], [x + 0.25, h, 1.25]), pa.translate([0.0, 0.0, 0.0])),
+              pa.Diffuse([0.25 + 0.125 * i, 0.5, 0.75 - 0.125 * i]))
+    s.add(pa.Rect([0.0, 1.875, 1], [0.5, 0, 0], [0, 0, 0.5]), pa.Emissive([20.0, 18.0, 15.0]))
+    s.set(pa.ThinLenCamera(pa.Film([96, 96]), [0, 1, -4], [0, 1, 0], 0.25))
+    assert (spp, depth) == (16, 5) and ps == s.describe()
 
 
 def test_sobol_sampler_in_scripts():
