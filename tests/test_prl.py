@@ -347,3 +347,21 @@ def test_script_render_equals_oracle_of_the_scene_it_built(oracle):
     assert film is not None and film.shape == (56, 72, 4)
     ref, _ = oracle.render(ps, (72, 56), spp, depth)
     assert_bit_equal(film, ref, "front-end render vs oracle of the same scene description")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,save,sampler", [("shapes.pine", "shapes.png", "blue"), ("functions.pine", "functions.png", "blue"),
+                                                 ("functions.pine", "functions.png", "sobol")])
+def test_example_scripts_render_equal_the_oracle(oracle, script, save, sampler):
+    """examples/shapes.pine (Plane / Line / Cylinder / Triangle) and examples/functions.pine (`fn`) on the GPU,
+    the latter also with SobolSampler: the film equals the oracle's render of the scene the script built."""
+    from pine_amd import prl
+    src = open(os.path.join(ROOT, "examples", script)).read().replace(f'scene.camera.film().save("{save}");', "")
+    if sampler == "sobol":
+        src = src.replace("BlueSampler(16)", "SobolSampler(16)")
+    ps, spp, depth = prl.scene_of_dry_run(prl.interpret(src, dry_run=True))
+    prl.interpret(src)
+    film = prl.last_film()
+    assert film is not None and film.shape == (96, 96, 4)
+    ref, _ = oracle.render(ps, (96, 96), spp, depth, sampler=sampler)
+    assert_bit_equal(film, ref, script)
