@@ -256,13 +256,13 @@ def test_node_expressions_resolve_like_the_reference():
 
 
 def _classic(n, size, spp):
-    src = open(os.path.join(ROOT, "examples", "classic.pine")).read()
+    src = open(os.path.join(ROOT, "examples", "cone_field.pine")).read()
     return src.replace("n := 100;", f"n := {n};").replace("size := [720, 360];", f"size := [{size[0]}, {size[1]}];").replace(
         "BlueSampler(64)", f"BlueSampler({spp})").replace('scene.camera.film().save("classic.png");', "")
 
 
 def test_classic_script_with_loops_and_node_graphs_builds_a_valid_scene(oracle):
-    """examples/classic.pine: PRL for-loops place the cones, the floor is a node graph; the scene description
+    """examples/cone_field.pine: PRL for-loops place the cones, the floor is a node graph; the scene description
     the front-end produces is accepted and rendered by the (reference-pinned) oracle."""
     from pine_amd import prl
     ps, spp, depth = prl.scene_of_dry_run(prl.interpret(_classic(6, (48, 24), 4), dry_run=True))
@@ -280,7 +280,7 @@ def test_classic_script_render_equals_oracle(oracle):
     ps, spp, depth = prl.scene_of_dry_run(prl.interpret(src, dry_run=True))
     prl.interpret(src)
     ref, _ = oracle.render(ps, (90, 45), spp, depth)
-    assert_bit_equal(prl.last_film(), ref, "classic.pine through the front-end vs oracle")
+    assert_bit_equal(prl.last_film(), ref, "cone_field.pine through the front-end vs oracle")
 
 
 def _lights_script(size_note=""):
