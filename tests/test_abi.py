@@ -157,3 +157,38 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".h", ".cpp", ".hip", ".hpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path only: on a host without a GPU it stops with a message, it never falls
+    back to timing the CPU oracle as if it were the product."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())  # no metric line
+
+
+def test_bench_reference_baseline_reports_the_real_binary(oracle):
+    """cpu_baseline kind "reference": oracle/_ref/pine_ref (when the build container made it) renders the scene
+    description the product builds, through the code path bench.py uses -- here at 16 spp, against the port."""
+    import hashlib
+    import importlib.util
+    exe = os.path.join(ROOT, "oracle", "_ref", "pine_ref")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/pine_ref not built (no /root/reference here)")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from pine_amd import scenes
+    sc = scenes.cbox((640, 640), "committed")
+    bench.SPP = 16  # (the function renders bench.SPP samples per pixel when the calibration run says they fit)
+    port, _ = oracle.render(sc.describe(), (640, 640), 16, bench.DEPTH)
+    md5 = hashlib.md5(port.tobytes()).hexdigest()
+    out = bench.cpu_baseline_reference(sc, gpu_md5=md5, budget_s=1e9)
+    assert out and out["kind"] == "reference" and out["cores"] >= 1 and out["value"] > 0
+    assert out["film_md5"] == md5 and out["film_equals_gpu"] is True
