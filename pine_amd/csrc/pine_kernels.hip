@@ -1568,20 +1568,23 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
   HIP_OK(hipMemsetAsync(p->d_counters, 0, sizeof(Counters), stream));
   hipEvent_t* ev = p->ev[p->launch_count % pine_gpu_plan::kEvRing];
   if (p->timed) HIP_OK(hipEventRecord(ev[0], stream));
-  if (p->W.items_per_pixel > 1) {
+  // (a shard can own no tile at all -- more ranks than 8x8 tiles: nothing to launch, the film / slab stays zero)
+  const bool has_work = p->W.num_local_tiles > 0;
+  if (has_work && p->W.items_per_pixel > 1) {
     const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
     hipLaunchKernelGGL(rng_checkpoint_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                        p->W, p->film_w, p->film_h, p->S.spp, p->d_ckpt);
   }
   if (p->timed) HIP_OK(hipEventRecord(ev[1], stream));
-  if (p->queue_variant >= 0)
+  if (!has_work) {
+  } else if (p->queue_variant >= 0)
     hipLaunchKernelGGL(kQueueVariants[p->queue_variant].fn, dim3(p->grid), dim3(kQBlock), p->lds_bytes, stream, p->S,
                        p->W, (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_ctxg, p->d_counters);
   else
     hipLaunchKernelGGL(kVariants[p->variant].fn, dim3(p->grid), dim3(kBlock), p->lds_bytes, stream, p->S, p->W,
                        (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_counters);
   if (p->timed) HIP_OK(hipEventRecord(ev[2], stream));
-  {
+  if (has_work) {
     const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
     hipLaunchKernelGGL(resolve_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, p->W,
                        p->film_w, p->film_h, p->S.spp, p->d_samples, (float4*)film_dev, p->d_counters, packed ? 1 : 0);

@@ -319,6 +319,25 @@ def test_edge_cases():
     assert st.spp_effective == 8
 
 
+def test_shards_without_tiles_and_tiny_films(oracle):
+    """More ranks than tiles: a rank that owns no tile launches, finishes and writes zeros; the shards still sum
+    to the full film.  And a 1x1 film (one partial tile)."""
+    from pine_amd import scenes
+    sc = scenes.cbox((24, 16), "readme")  # 3 x 2 = 6 tiles
+    ref, _ = oracle.render(sc.describe(), (24, 16), 16, 4)
+    tot = np.zeros_like(ref)
+    for r in range(8):
+        f, st = _render(sc, 16, 4, shard_rank=r, shard_world=8)
+        if r >= 6:
+            assert st.camera_samples == 0 and (f == 0).all()
+        tot += f
+    assert_bit_equal(tot, ref, "8 shards of a 6-tile film")
+    one = scenes.cbox((1, 1), "readme")
+    f, st = _render(one, 8, 3)
+    ref1, _ = oracle.render(one.describe(), (1, 1), 8, 3)
+    assert_bit_equal(f, ref1, "1x1 film")
+
+
 def test_errors_are_reported_not_fatal():
     import pine_amd as pa
     from pine_amd import scenes
