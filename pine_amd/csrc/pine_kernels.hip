@@ -258,6 +258,7 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
     if (leaf(top.root_start, top.root_count)) return true;
     return hit;
   }
+  if (top.root < 0) return false;  // geometries exist but none has primitives (only empty meshes): nothing to visit
   int sp = 0;
   int next = top.root;
   while (true) {

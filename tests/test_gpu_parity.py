@@ -332,6 +332,14 @@ def test_shards_without_tiles_and_tiny_films(oracle):
             assert st.camera_samples == 0 and (f == 0).all()
         tot += f
     assert_bit_equal(tot, ref, "8 shards of a 6-tile film")
+    # a scene whose only geometry is a mesh without triangles: no top-level primitive at all (bvh.cpp:458 skips it)
+    import pine_amd as pa
+    em = pa.Scene()
+    em.add("d", pa.Diffuse([0.5, 0.5, 0.5]))
+    em.add(pa.Mesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32)), "d")
+    em.set(pa.ThinLenCamera(pa.Film([8, 8]), [0, 0, 0], [0, 0, 1], 0.4))
+    f, st = _render(em, 4, 3)
+    assert (f[..., :3] == 0).all() and (f[..., 3] == 1).all() and st.vertices == 8 * 8 * 4
     one = scenes.cbox((1, 1), "readme")
     f, st = _render(one, 8, 3)
     ref1, _ = oracle.render(one.describe(), (1, 1), 8, 3)
