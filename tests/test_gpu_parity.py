@@ -346,6 +346,26 @@ def test_shards_without_tiles_and_tiny_films(oracle):
     assert_bit_equal(f, ref1, "1x1 film")
 
 
+def test_small_meshes_and_two_area_lights(oracle):
+    """A one-triangle and a two-triangle mesh (leaf-root mesh BVHs, one of them emissive), and two emissive Rects
+    in the lean Rect + Box variant (the light sampler's N != 1 branch, lightsampler.cpp:13-29)."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    sc = scenes.cbox((40, 40), "readme", boxes=False)
+    sc.add("m", pa.Diffuse([0.7, 0.3, 0.2]))
+    sc.add(pa.Mesh(np.float32([[-0.5, 0.2, 1.2], [0.3, 0.2, 1.4], [-0.1, 1.0, 1.3]]), np.uint32([[0, 1, 2]])), "m")
+    sc.add(pa.Mesh(np.float32([[0.2, 0.1, 0.8], [0.8, 0.1, 0.9], [0.8, 0.7, 0.9], [0.2, 0.7, 0.8]]), np.uint32([[0, 1, 2], [0, 2, 3]])),
+           pa.Emissive([6.0, 5.0, 3.0]))
+    f, _ = _render(sc, 16, 5)
+    ref, _ = oracle.render(sc.describe(), (40, 40), 16, 5)
+    assert_bit_equal(f, ref, "small meshes")
+    two = scenes.cbox((40, 40), "readme")
+    two.add(pa.Rect([0.5, 1.0, 1.9], [0.3, 0, 0], [0, 0.3, 0], True), pa.Emissive([30.0, 10.0, 5.0]))
+    f, _ = _render(two, 16, 5)
+    ref, _ = oracle.render(two.describe(), (40, 40), 16, 5)
+    assert_bit_equal(f, ref, "two area lights")
+
+
 def test_errors_are_reported_not_fatal():
     import pine_amd as pa
     from pine_amd import scenes
