@@ -217,3 +217,58 @@ def xshapes_zoo(size=(64, 64), extra_lights=True):
         scene.add(Plane([0, 6, 0], [0, -1, 0]), Emissive([0.15, 0.2, 0.3]))
     scene.set(ThinLenCamera(Film(list(size)), [0, 1, -4], [0, 1, 0], 0.25))
     return scene
+
+
+def random_scene(seed):
+    """A seeded random mix of every shape, material and light kind in a two-wall room (fuzzing: tools/fuzz_scenes.py,
+    tests): returns (scene, spp, max_path_length)."""
+    import pine_amd as pa
+    r = np.random.default_rng(seed)
+    f = lambda lo, hi: float(np.float32(r.uniform(lo, hi)))
+    v = lambda lo, hi: [f(lo, hi), f(lo, hi), f(lo, hi)]
+    s = pa.Scene()
+    mats = []
+    nodes = r.random() < 0.4
+    for i in range(int(r.integers(2, 6))):
+        k = int(r.integers(0, 6))
+        col = v(0.1, 0.95)
+        if nodes and r.random() < 0.5:
+            col = pa.lerp(pa.Checkerboard(pa.Position() * f(1, 4), 0.5), col, v(0.05, 0.9))
+        if k == 0: m = pa.Diffuse(col)
+        elif k == 1: m = pa.Metal(col, f(0.0, 0.6))
+        elif k == 2: m = pa.Glossy(col, f(0.0, 0.5), f(1.1, 1.8))
+        elif k == 3: m = pa.Glass(col, f(0.0, 0.3), f(1.1, 1.8))
+        elif k == 4: m = pa.Uber(col, f(0.0, 0.8), float(r.integers(0, 2)), 0.0)
+        else: m = pa.Diffuse(col)
+        s.add(f"m{i}", m)
+        mats.append(f"m{i}")
+    pick = lambda: mats[int(r.integers(0, len(mats)))]
+    # a room so that paths bounce
+    s.add(pa.Rect([0, 0, 1], [3, 0, 0], [0, 0, 3], True), pick())
+    s.add(pa.Rect([0, 1, 2.5], [3, 0, 0], [0, 2, 0], True), pick())
+    for i in range(int(r.integers(3, 10))):
+        k = int(r.integers(0, 11))
+        c = [f(-1, 1), f(0.1, 1.2), f(0.6, 2.0)]
+        m = pick()
+        if k == 0: s.add(pa.Sphere(c, f(0.1, 0.4)), m)
+        elif k == 1: s.add(pa.Disk(c, v(-1, 1), f(0.1, 0.5)), m)
+        elif k == 2: s.add(pa.Cone([c[0], 0.0, c[2]], [0, 1, 0], f(0.1, 0.3), f(0.2, 0.8)), m)
+        elif k == 3: s.add(pa.AABB(c, [c[0] + f(0.1, 0.5), c[1] + f(0.1, 0.5), c[2] + f(0.1, 0.5)]), m)
+        elif k == 4: s.add(pa.Box(pa.AABB([0, 0, 0], [1, 1, 1]), pa.translate(c) * pa.rotate_y(f(-1, 1)) * pa.scale(v(0.2, 0.6))), m)
+        elif k == 5: s.add(pa.Rect(c, v(-0.6, 0.6), v(-0.6, 0.6)), m) if True else None
+        elif k == 6: s.add(pa.Line(c, [c[0] + f(-0.8, 0.8), c[1] + f(-0.3, 0.8), c[2] + f(-0.5, 0.5)], f(0.02, 0.08)), m)
+        elif k == 7: s.add(pa.Cylinder(c, [c[0] + f(-0.3, 0.3), c[1] + f(0.2, 0.8), c[2] + f(-0.3, 0.3)], f(0.1, 0.3)), m)
+        elif k == 8: s.add(pa.Triangle(c, [c[0] + f(0.2, 0.8), c[1], c[2] + f(-0.3, 0.3)], [c[0] + f(-0.2, 0.4), c[1] + f(0.3, 0.9), c[2]]), m)
+        elif k == 9:
+            vs = np.float32([c, [c[0] + 0.5, c[1], c[2]], [c[0] + 0.5, c[1] + 0.5, c[2] + 0.1], [c[0], c[1] + 0.5, c[2] + 0.1]])
+            s.add(pa.Mesh(vs, np.uint32([[0, 1, 2], [0, 2, 3]])), m)
+        else: s.add(pa.Plane([0, f(-0.2, 0.0), 0], [f(-0.1, 0.1), 1, f(-0.1, 0.1)]), m)
+    # lights: an area lamp always, others sometimes (add order matters to the light sampler)
+    if r.random() < 0.4: s.add(pa.PointLight(v(-0.8, 1.8), v(1, 4)))
+    s.add(pa.Rect([f(-0.5, 0.5), 1.9, f(0.6, 1.6)], [f(0.2, 0.6), 0, 0], [0, 0, f(0.2, 0.6)]), pa.Emissive(v(8, 25)))
+    if r.random() < 0.3: s.add(pa.SpotLight(v(-0.8, 1.8), [f(-0.3, 0.3), -1.0, f(-0.3, 0.3)], v(2, 6), f(0.2, 0.6), f(0.05, 0.2)))
+    if r.random() < 0.3: s.add(pa.DirectionalLight([f(-1, 1), 1.0, f(-1, 0)], v(0.2, 0.8)))
+    if r.random() < 0.3: s.add(pa.Sphere([f(-0.8, 0.8), f(1.0, 1.6), f(0.8, 1.6)], f(0.05, 0.15)), pa.Emissive(v(5, 20)))
+    if r.random() < 0.3: s.set(pa.Sky(v(0.3, 1.0)))
+    s.set(pa.ThinLenCamera(pa.Film([28, 20]), [f(-0.3, 0.3), f(0.8, 1.2), -4], [0, 1, 0], 0.25))
+    return s, int(2 ** r.integers(1, 4)), int(r.integers(2, 7))

@@ -366,6 +366,17 @@ def test_small_meshes_and_two_area_lights(oracle):
     assert_bit_equal(f, ref, "two area lights")
 
 
+def test_random_scenes_match_the_oracle(oracle):
+    """Fuzzing on the device: 40 seeded random scenes (every shape / material / light kind, random spp and depth)."""
+    from pine_amd import scenes
+    for seed in range(3000, 3040):
+        sc, spp, depth = scenes.random_scene(seed)
+        w, h = sc.camera.film().size
+        f, _ = _render(sc, spp, depth)
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
+        assert_bit_equal(f, ref, f"random scene {seed}")
+
+
 def test_errors_are_reported_not_fatal():
     import pine_amd as pa
     from pine_amd import scenes

@@ -116,3 +116,25 @@ def test_stats_file_present():
     # SURVEY.md Appendix C sanity values of the g++ oracle
     np.testing.assert_allclose(c1["mean_rgb"], [0.093782, 0.058198, 0.017012], atol=1e-6)
     np.testing.assert_allclose(c1["center_pixel"], [0.087721169, 0.0352332816, 0.00938287377], rtol=1e-7)
+
+
+def test_random_scenes_oracle_equals_the_reference_binary(oracle):
+    """Fuzzing: seeded random mixes of every shape / material / light kind (pine_amd.scenes.random_scene); the
+    restatement against oracle/_ref/pine_ref, bit for bit.  (tools/fuzz_scenes.py ran 300 seeds both ways.)"""
+    import subprocess
+    from pine_amd import scenes
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "pine_ref")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/pine_ref not built (no /root/reference here)")
+    import tempfile
+    for seed in range(2000, 2012):
+        sc, spp, depth = scenes.random_scene(seed)
+        ps = sc.describe()
+        w, h = sc.camera.film().size
+        mine, _ = oracle.render(ps, (w, h), spp, depth)
+        with tempfile.TemporaryDirectory() as tmp:
+            sp, fp = os.path.join(tmp, "s.pscene"), os.path.join(tmp, "s.film")
+            open(sp, "w").write(ps)
+            subprocess.run([exe, "render", sp, str(spp), str(depth), fp], check=True, capture_output=True, timeout=120)
+            ref = np.fromfile(fp, dtype=np.float32).reshape(h, w, 4)
+        assert_bit_equal(mine, ref, f"random scene {seed}")

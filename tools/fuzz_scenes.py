@@ -1,0 +1,57 @@
+"""Randomised scene fuzzing: seeded random mixes of every shape, material and light kind.
+   python tools/fuzz_scenes.py ref N   -- here (CPU): the oracle restatement against the real reference binary
+   python tools/fuzz_scenes.py gpu N   -- on the GPU box: the HIP path against the oracle
+Every film must match bit for bit."""
+import sys, os, subprocess, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+if len(sys.argv) > 1 and sys.argv[1] == "gpu":
+    import torch  # (before anything else touches the HIP runtime)
+import pine_amd as pa
+from oracle import oracle
+
+REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "pine_ref")
+
+
+from pine_amd.scenes import random_scene as rnd_scene  # noqa: E402
+
+
+def main():
+    mode, n = sys.argv[1], int(sys.argv[2])
+    bad = 0
+    for seed in range(1000, 1000 + n):
+        try:
+            sc, spp, depth = rnd_scene(seed)
+        except pa.PineError as e:  # e.g. a degenerate random Rect: a legitimate rejection
+            print(seed, "scene rejected:", str(e)[:60])
+            continue
+        ps = sc.describe()
+        w, h = sc.camera.film().size
+        ref, _ = oracle.render(ps, (w, h), spp, depth)
+        if mode == "ref":
+            with tempfile.TemporaryDirectory() as tmp:
+                sp, fp = os.path.join(tmp, "s.pscene"), os.path.join(tmp, "s.film")
+                open(sp, "w").write(ps)
+                r = subprocess.run([REF, "render", sp, str(spp), str(depth), fp], capture_output=True, text=True, timeout=120)
+                if r.returncode:
+                    print(seed, "reference failed:", r.stderr[-200:])
+                    bad += 1
+                    continue
+                other = np.fromfile(fp, dtype=np.float32).reshape(h, w, 4)
+        else:
+            plan = pa.Plan(sc, spp, depth)
+            film = torch.zeros((h, w, 4), device="cuda")
+            plan.launch(film.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            other = film.cpu().numpy()
+            plan.close()
+        d = int((ref.view(np.uint32) != other.view(np.uint32)).any(axis=2).sum())
+        nan = int(np.isnan(other).sum())
+        print(seed, f"spp {spp} depth {depth}: mismatched pixels {d} nan {nan} mean {float(other[..., :3].mean()):.4f}", flush=True)
+        bad += d > 0
+    print("scenes with mismatches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
