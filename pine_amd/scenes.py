@@ -219,7 +219,7 @@ def xshapes_zoo(size=(64, 64), extra_lights=True):
     return scene
 
 
-def random_scene(seed):
+def random_scene(seed, variety=False):
     """A seeded random mix of every shape, material and light kind in a two-wall room (fuzzing: tools/fuzz_scenes.py,
     tests): returns (scene, spp, max_path_length)."""
     import pine_amd as pa
@@ -270,5 +270,11 @@ def random_scene(seed):
     if r.random() < 0.3: s.add(pa.DirectionalLight([f(-1, 1), 1.0, f(-1, 0)], v(0.2, 0.8)))
     if r.random() < 0.3: s.add(pa.Sphere([f(-0.8, 0.8), f(1.0, 1.6), f(0.8, 1.6)], f(0.05, 0.15)), pa.Emissive(v(5, 20)))
     if r.random() < 0.3: s.set(pa.Sky(v(0.3, 1.0)))
+    if variety:  # also: odd film sizes, a thin lens, SobolSampler (returns a fourth element, the sampler name)
+        size = [int(r.integers(1, 40)), int(r.integers(1, 30))]
+        lens = (f(0.01, 0.08), f(2.0, 6.0)) if r.random() < 0.4 else (0.0, 1.0)
+        s.set(pa.ThinLenCamera(pa.Film(size), [f(-0.3, 0.3), f(0.8, 1.2), -4], [0, 1, 0], 0.25, lens[0], lens[1]))
+        sampler = "sobol" if r.random() < 0.4 else "blue"
+        return s, int(2 ** r.integers(0, 5)), int(r.integers(1, 9)), sampler
     s.set(pa.ThinLenCamera(pa.Film([28, 20]), [f(-0.3, 0.3), f(0.8, 1.2), -4], [0, 1, 0], 0.25))
     return s, int(2 ** r.integers(1, 4)), int(r.integers(2, 7))

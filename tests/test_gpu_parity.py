@@ -370,10 +370,10 @@ def test_random_scenes_match_the_oracle(oracle):
     """Fuzzing on the device: 40 seeded random scenes (every shape / material / light kind, random spp and depth)."""
     from pine_amd import scenes
     for seed in range(3000, 3040):
-        sc, spp, depth = scenes.random_scene(seed)
+        sc, spp, depth, sampler = scenes.random_scene(seed, variety=True)  # + odd film sizes, thin lens, SobolSampler
         w, h = sc.camera.film().size
-        f, _ = _render(sc, spp, depth)
-        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
+        f, _ = _render(sc, spp, depth, sampler=sampler)
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth, sampler=sampler)
         assert_bit_equal(f, ref, f"random scene {seed}")
 
 

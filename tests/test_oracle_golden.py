@@ -128,13 +128,14 @@ def test_random_scenes_oracle_equals_the_reference_binary(oracle):
         pytest.skip("oracle/_ref/pine_ref not built (no /root/reference here)")
     import tempfile
     for seed in range(2000, 2012):
-        sc, spp, depth = scenes.random_scene(seed)
+        sc, spp, depth, sampler = scenes.random_scene(seed, variety=True)  # + odd film sizes, thin lens, SobolSampler
         ps = sc.describe()
         w, h = sc.camera.film().size
-        mine, _ = oracle.render(ps, (w, h), spp, depth)
+        mine, _ = oracle.render(ps, (w, h), spp, depth, sampler=sampler)
         with tempfile.TemporaryDirectory() as tmp:
             sp, fp = os.path.join(tmp, "s.pscene"), os.path.join(tmp, "s.film")
             open(sp, "w").write(ps)
-            subprocess.run([exe, "render", sp, str(spp), str(depth), fp], check=True, capture_output=True, timeout=120)
+            subprocess.run([exe, "render", sp, str(spp), str(depth), fp] + (["sobol"] if sampler == "sobol" else []),
+                           check=True, capture_output=True, timeout=120)
             ref = np.fromfile(fp, dtype=np.float32).reshape(h, w, 4)
         assert_bit_equal(mine, ref, f"random scene {seed}")

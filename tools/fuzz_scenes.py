@@ -21,25 +21,26 @@ def main():
     bad = 0
     for seed in range(1000, 1000 + n):
         try:
-            sc, spp, depth = rnd_scene(seed)
+            sc, spp, depth, sampler = rnd_scene(seed, variety=True)
         except pa.PineError as e:  # e.g. a degenerate random Rect: a legitimate rejection
             print(seed, "scene rejected:", str(e)[:60])
             continue
         ps = sc.describe()
         w, h = sc.camera.film().size
-        ref, _ = oracle.render(ps, (w, h), spp, depth)
+        ref, _ = oracle.render(ps, (w, h), spp, depth, sampler=sampler)
         if mode == "ref":
             with tempfile.TemporaryDirectory() as tmp:
                 sp, fp = os.path.join(tmp, "s.pscene"), os.path.join(tmp, "s.film")
                 open(sp, "w").write(ps)
-                r = subprocess.run([REF, "render", sp, str(spp), str(depth), fp], capture_output=True, text=True, timeout=120)
+                r = subprocess.run([REF, "render", sp, str(spp), str(depth), fp] + (["sobol"] if sampler == "sobol" else []),
+                                   capture_output=True, text=True, timeout=120)
                 if r.returncode:
                     print(seed, "reference failed:", r.stderr[-200:])
                     bad += 1
                     continue
                 other = np.fromfile(fp, dtype=np.float32).reshape(h, w, 4)
         else:
-            plan = pa.Plan(sc, spp, depth)
+            plan = pa.Plan(sc, spp, depth, sampler=sampler)
             film = torch.zeros((h, w, 4), device="cuda")
             plan.launch(film.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
@@ -47,7 +48,7 @@ def main():
             plan.close()
         d = int((ref.view(np.uint32) != other.view(np.uint32)).any(axis=2).sum())
         nan = int(np.isnan(other).sum())
-        print(seed, f"spp {spp} depth {depth}: mismatched pixels {d} nan {nan} mean {float(other[..., :3].mean()):.4f}", flush=True)
+        print(seed, f"{w}x{h} {sampler} spp {spp} depth {depth}: mismatched pixels {d} nan {nan} mean {float(other[..., :3].mean()):.4f}", flush=True)
         bad += d > 0
     print("scenes with mismatches:", bad)
     return 1 if bad else 0
