@@ -238,6 +238,8 @@ def random_scene(seed, variety=False):
         elif k == 1: m = pa.Metal(col, f(0.0, 0.6))
         elif k == 2: m = pa.Glossy(col, f(0.0, 0.5), f(1.1, 1.8))
         elif k == 3: m = pa.Glass(col, f(0.0, 0.3), f(1.1, 1.8))
+        elif k == 4 and variety == 2:  # fractional metallic / transmission: the lobe choice draws from the pixel's RNG (sampler.h:317-324)
+            m = pa.Uber(col, f(0.0, 0.8), f(0.0, 1.0), f(0.0, 1.0), f(1.1, 1.8))
         elif k == 4: m = pa.Uber(col, f(0.0, 0.8), float(r.integers(0, 2)), 0.0)
         else: m = pa.Diffuse(col)
         s.add(f"m{i}", m)
@@ -263,6 +265,9 @@ def random_scene(seed, variety=False):
             vs = np.float32([c, [c[0] + 0.5, c[1], c[2]], [c[0] + 0.5, c[1] + 0.5, c[2] + 0.1], [c[0], c[1] + 0.5, c[2] + 0.1]])
             s.add(pa.Mesh(vs, np.uint32([[0, 1, 2], [0, 2, 3]])), m)
         else: s.add(pa.Plane([0, f(-0.2, 0.0), 0], [f(-0.1, 0.1), 1, f(-0.1, 0.1)]), m)
+    if variety == 2 and r.random() < 0.6:  # a Subsurface icosphere (BSSRDF random walk inside a mesh: megakernel path)
+        vs, fs = icosphere(1, f(0.2, 0.4), (f(-0.6, 0.6), f(0.4, 0.9), f(0.8, 1.6)))
+        s.add(pa.Mesh(vs, fs), pa.Subsurface(v(0.5, 0.95), f(0.1, 0.5), v(5.0, 40.0)))
     # lights: an area lamp always, others sometimes (add order matters to the light sampler)
     if r.random() < 0.4: s.add(pa.PointLight(v(-0.8, 1.8), v(1, 4)))
     s.add(pa.Rect([f(-0.5, 0.5), 1.9, f(0.6, 1.6)], [f(0.2, 0.6), 0, 0], [0, 0, f(0.2, 0.6)]), pa.Emissive(v(8, 25)))
@@ -274,7 +279,7 @@ def random_scene(seed, variety=False):
         size = [int(r.integers(1, 40)), int(r.integers(1, 30))]
         lens = (f(0.01, 0.08), f(2.0, 6.0)) if r.random() < 0.4 else (0.0, 1.0)
         s.set(pa.ThinLenCamera(pa.Film(size), [f(-0.3, 0.3), f(0.8, 1.2), -4], [0, 1, 0], 0.25, lens[0], lens[1]))
-        sampler = "sobol" if r.random() < 0.4 else "blue"
+        sampler = "sobol" if (r.random() < 0.4 and variety != 2) else "blue"  # (SobolSampler + Subsurface is refused on the device)
         return s, int(2 ** r.integers(0, 5)), int(r.integers(1, 9)), sampler
     s.set(pa.ThinLenCamera(pa.Film([28, 20]), [f(-0.3, 0.3), f(0.8, 1.2), -4], [0, 1, 0], 0.25))
     return s, int(2 ** r.integers(1, 4)), int(r.integers(2, 7))

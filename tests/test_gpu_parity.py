@@ -375,6 +375,12 @@ def test_random_scenes_match_the_oracle(oracle):
         f, _ = _render(sc, spp, depth, sampler=sampler)
         ref, _ = oracle.render(sc.describe(), (w, h), spp, depth, sampler=sampler)
         assert_bit_equal(f, ref, f"random scene {seed}")
+    for seed in range(4000, 4015):  # fractional Uber lobes (in-path RNG: serial samples) and Subsurface meshes (megakernel)
+        sc, spp, depth, sampler = scenes.random_scene(seed, variety=2)
+        w, h = sc.camera.film().size
+        f, _ = _render(sc, spp, depth, sampler=sampler)
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth, sampler=sampler)
+        assert_bit_equal(f, ref, f"random scene {seed} (in-path RNG)")
 
 
 def test_errors_are_reported_not_fatal():

@@ -127,8 +127,9 @@ def test_random_scenes_oracle_equals_the_reference_binary(oracle):
     if not os.access(exe, os.X_OK):
         pytest.skip("oracle/_ref/pine_ref not built (no /root/reference here)")
     import tempfile
-    for seed in range(2000, 2012):
-        sc, spp, depth, sampler = scenes.random_scene(seed, variety=True)  # + odd film sizes, thin lens, SobolSampler
+    for seed, variety in [(k, 1) for k in range(2000, 2012)] + [(k, 2) for k in range(2100, 2106)]:
+        # variety 1: + odd film sizes, thin lens, SobolSampler; 2: + fractional Uber lobes, Subsurface meshes (in-path RNG)
+        sc, spp, depth, sampler = scenes.random_scene(seed, variety=variety)
         ps = sc.describe()
         w, h = sc.camera.film().size
         mine, _ = oracle.render(ps, (w, h), spp, depth, sampler=sampler)

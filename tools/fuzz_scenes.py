@@ -18,10 +18,11 @@ from pine_amd.scenes import random_scene as rnd_scene  # noqa: E402
 
 def main():
     mode, n = sys.argv[1], int(sys.argv[2])
+    variety = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # 2: also fractional Uber lobes and Subsurface meshes (in-path RNG)
     bad = 0
     for seed in range(1000, 1000 + n):
         try:
-            sc, spp, depth, sampler = rnd_scene(seed, variety=True)
+            sc, spp, depth, sampler = rnd_scene(seed, variety=variety)
         except pa.PineError as e:  # e.g. a degenerate random Rect: a legitimate rejection
             print(seed, "scene rejected:", str(e)[:60])
             continue
