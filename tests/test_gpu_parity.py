@@ -383,6 +383,35 @@ def test_random_scenes_match_the_oracle(oracle):
         assert_bit_equal(f, ref, f"random scene {seed} (in-path RNG)")
 
 
+def test_random_scenes_shard_sums_and_packed_slabs():
+    """Fuzzing the multi-GPU decomposition: for random scenes and world sizes, the shards' films sum to the
+    one-GPU film, and the packed slabs unpack to it (what bench.py gathers)."""
+    import torch
+    import pine_amd as pa
+    from pine_amd import scenes
+    rng = np.random.default_rng(5)
+    for seed in range(5000, 5012):
+        sc, spp, depth, sampler = scenes.random_scene(seed, variety=1)
+        w, h = sc.camera.film().size
+        full, _ = _render(sc, spp, depth, sampler=sampler)
+        world = int(rng.choice([2, 3, 5, 8]))
+        tot = np.zeros_like(full)
+        n = int(pa._lib.lib.pine_gpu_packed_slab_floats(w, h, world))
+        slabs = torch.zeros((world, n), dtype=torch.float32, device="cuda")
+        for r in range(world):
+            f, _ = _render(sc, spp, depth, sampler=sampler, shard_rank=r, shard_world=world)
+            tot += f
+            plan = pa.Plan(sc, spp, depth, sampler=sampler, shard_rank=r, shard_world=world)
+            plan.launch_packed(slabs[r].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            plan.close()
+        assert_bit_equal(tot, full, f"scene {seed}: {world} shards")
+        film = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+        pa.film_unpack((w, h), world, slabs.data_ptr(), film.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_equal(film.cpu().numpy(), full, f"scene {seed}: packed slabs of {world} ranks")
+
+
 def test_errors_are_reported_not_fatal():
     import pine_amd as pa
     from pine_amd import scenes
