@@ -34,13 +34,19 @@ int main(int argc, char** argv) {
   std::stringstream ss;
   ss << f.rdbuf();
   const std::string source = ss.str();
-  auto worker = std::async(std::launch::async, [&] { return pine_prl_interpret(source.c_str(), flags, device); });
+  // (pine_prl_last_error() is per thread: the worker reads it)
+  std::string error;
+  auto worker = std::async(std::launch::async, [&] {
+    const int rc = pine_prl_interpret(source.c_str(), flags, device);
+    if (rc < 0) error = pine_prl_last_error();
+    return rc;
+  });
   while (worker.wait_for(std::chrono::milliseconds(200)) != std::future_status::ready) {
     const float p = pine_gpu_progress();
     if (p > 0 && p < 1) fprintf(stderr, "\r[progress] %5.1f%%", 100.0 * p);
   }
   if (worker.get() < 0) {
-    fprintf(stderr, "%s: %s\n", path, pine_prl_last_error());
+    fprintf(stderr, "%s: %s\n", path, error.c_str());
     return 1;
   }
   return 0;

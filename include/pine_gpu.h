@@ -187,7 +187,8 @@ typedef struct {
  * dealt round-robin to `world` ranks (host-side helper; the kernels use the same mapping). */
 int pine_gpu_shard_of_pixel(int film_w, int x, int y, int world);
 
-/* Path to the packed BlueSobol tables (pine_amd/data/bluesobol_u8.bin); call once per process. */
+/* Path to the packed BlueSobol tables (pine_amd/data/bluesobol_u8.bin).  Optional: without it the library looks at
+ * $PINE_GPU_TABLES, then at ../data/bluesobol_u8.bin relative to the directory libpine_gpu.so was loaded from. */
 int pine_gpu_set_table_path(const char* path);
 
 /* One-shot, drop-in form: render into a HOST film of W*H float4 (row 0 first, exactly

@@ -28,6 +28,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/pine_gpu.h"
 #include "pine_device.h"
 #include "pine_host.h"
@@ -1123,6 +1125,19 @@ static std::atomic<float> g_progress{0.0f};
 static int load_tables() {
   std::lock_guard<std::mutex> lock(g_table_mutex);
   if (!g_tables.empty()) return 0;
+  if (g_table_path.empty()) {
+    // not set by the host: $PINE_GPU_TABLES, else data/bluesobol_u8.bin next to the directory this library sits in
+    // (pine_amd/lib/libpine_gpu.so -> pine_amd/data/), wherever the process was started from
+    if (const char* env = getenv("PINE_GPU_TABLES")) g_table_path = env;
+    else {
+      Dl_info info;
+      if (dladdr(reinterpret_cast<const void*>(&load_tables), &info) && info.dli_fname) {
+        std::string lib = info.dli_fname;
+        const size_t slash = lib.rfind('/');
+        g_table_path = (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/../data/bluesobol_u8.bin";
+      }
+    }
+  }
   if (g_table_path.empty()) {
     set_error("BlueSobol table path not set (pine_gpu_set_table_path)");
     return -1;
