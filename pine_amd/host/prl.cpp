@@ -1846,6 +1846,14 @@ Interp::Interp() {
       }
       return mk_i32(n);
     });
+  // names a script may reach for that this build deliberately does not provide: say why
+  r.def("UniformSampler", {"i32"}, "Sampler", [](Interp&, std::vector<Cell>&) -> Value {
+    fail("`UniformSampler` is not provided: its stream depends on the reference's thread scheduling (per-thread RNG clones, "
+         "no per-pixel reseed), so there is no result to reproduce -- use BlueSampler or SobolSampler");
+  });
+  r.def("HaltonSampler", {"i32"}, "Sampler", [](Interp&, std::vector<Cell>&) -> Value {
+    fail("`HaltonSampler` is not built on the GPU path -- use BlueSampler or SobolSampler");
+  });
   r.def("PathIntegrator", {"Sampler", "i32"}, "PathIntegrator", [](Interp&, std::vector<Cell>& a) {
     if (a[1]->i[0] <= 0) fail("`PathIntegrator` expect `max_path_length` to be positive, get " + std::to_string(a[1]->i[0]));
     auto p = std::make_shared<IntegratorObj>();

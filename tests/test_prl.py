@@ -231,6 +231,10 @@ def test_sobol_sampler_in_scripts():
     assert prl.evaluate("SobolSampler(1000).spp()") == "i32 1000"
     assert prl.evaluate("BlueSampler(1000).spp()") == "i32 256"
     assert prl.evaluate("BlueSampler(5).spp()") == "i32 8"
+    with pytest.raises(prl.PrlError, match="thread scheduling"):
+        prl.interpret("PathIntegrator(UniformSampler(4), 3);", dry_run=True)
+    with pytest.raises(prl.PrlError, match="not built"):
+        prl.interpret("PathIntegrator(HaltonSampler(4), 3);", dry_run=True)
     src = _cornell((64, 64), 32, 4).replace("BlueSampler(spp)", "SobolSampler(spp)")
     assert "SobolSampler(spp)" in src
     out = prl.interpret(src, dry_run=True)
