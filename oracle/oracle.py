@@ -46,12 +46,12 @@ def _tp():
 
 
 def render(pscene: str, size, spp, depth, threads=0, rows=None, sampler="blue"):
-    """-> (film[h,w,4] float32, Stats).  sampler: "blue" = BlueSampler(spp), "sobol" = SobolSampler(spp)."""
+    """-> (film[h,w,4] float32, Stats).  sampler: "blue" = BlueSampler(spp), "sobol" = SobolSampler(spp), "halton" = HaltonSampler(spp)."""
     w, h = size
     film = np.zeros((h, w, 4), np.float32)
     st = Stats()
     y0, y1 = rows if rows else (0, 0)
-    lib().oracle_set_sampler(1 if sampler == "sobol" else 0)
+    lib().oracle_set_sampler({"sobol": 1, "halton": 2}.get(sampler, 0))
     try:
         rc = lib().oracle_render(pscene.encode(), _tp(), int(spp), int(depth), int(threads), int(y0), int(y1),
                                  film.ctypes.data_as(C.c_void_p), C.byref(st))

@@ -408,7 +408,107 @@ inline float sobol_sample(int64_t a, int dim, uint32_t seed) {  // lowdiscrepanc
   return fmin_(float(v) * 0x1p-32f, kOneMinusEps);
 }
 
-enum SamplerKind { SAMPLER_BLUE = 0, SAMPLER_SOBOL = 1 };
+// ---- HaltonSampler (sampler.h:40-81, sampler.cpp:16-79, lowdiscrepancy.h:10-52, lowdiscrepancy.cpp:5-17) --------
+// Oracle only so far (the device refuses it): the tables are derived, not stored -- Primes[] is the first 1000
+// primes and PrimeSums[] their prefix sums (primes.cpp), the digit permutations come from a default-seeded RNG.
+struct HaltonTables {
+  std::vector<int> primes, sums;
+  std::vector<uint16_t> perms;
+  int baseScales[2], baseExponents[2], multInverse[2], sampleStride;
+  static void extended_gcd(uint64_t a, uint64_t b, int64_t& gcd, int64_t& x, int64_t& y) {  // sampler.cpp:16-31 (int d, r as there)
+    int d = int(a / b);
+    int r = int(a - uint64_t(d) * b);
+    if (r == 0) {
+      gcd = int64_t(b);
+      x = 0;
+      y = 1;
+      return;
+    }
+    int64_t nx, ny;
+    extended_gcd(b, uint64_t(r), gcd, nx, ny);
+    x = ny;
+    y = nx - d * ny;
+  }
+  static int64_t mod_(int64_t a, int64_t b) {  // psl::mod src/psl/math.h:103-107
+    int64_t r = a - (a / b) * b;
+    return r < 0 ? r + b : r;
+  }
+  HaltonTables() {
+    for (int n = 2; int(primes.size()) < 1000; n++) {
+      bool is_prime = true;
+      for (int d = 2; d * d <= n; d++)
+        if (n % d == 0) {
+          is_prime = false;
+          break;
+        }
+      if (is_prime) primes.push_back(n);
+    }
+    int acc = 0;
+    for (int p : primes) {
+      sums.push_back(acc);
+      acc += p;
+    }
+    perms.resize(size_t(acc));
+    RNG rng;  // HaltonSampler ctor: `RNG rng;` (seed 0)
+    uint16_t* p = perms.data();
+    for (int i = 0; i < 1000; i++) {
+      for (int j = 0; j < primes[i]; j++) p[j] = uint16_t(j);
+      for (int k = 0; k < primes[i]; k++) {  // shuffle(p, count, 1, rng) lowdiscrepancy.h:55-61
+        uint64_t h = rng.next64u();
+        uint32_t other = uint32_t(k) + uint32_t(h ^ (h >> 32)) % uint32_t(primes[i] - k);
+        std::swap(p[k], p[other]);
+      }
+      p += primes[i];
+    }
+    for (int i = 0; i < 2; i++) {
+      int base = i == 0 ? 2 : 3, scale = 1, exp = 0;
+      while (scale < 128) {  // MaxHaltonResolution
+        scale *= base;
+        ++exp;
+      }
+      baseScales[i] = scale;
+      baseExponents[i] = exp;
+    }
+    auto mult_inverse = [](int64_t a, int64_t n) {
+      int64_t gcd, x, y;
+      extended_gcd(uint64_t(a), uint64_t(n), gcd, x, y);
+      return uint64_t(mod_(x, n));
+    };
+    multInverse[0] = int(mult_inverse(baseScales[0], baseScales[1]));
+    multInverse[1] = int(mult_inverse(baseScales[1], baseScales[0]));
+    sampleStride = baseScales[0] * baseScales[1];
+  }
+  float scrambled_radical_inverse(int baseIndex, uint64_t a) const {  // lowdiscrepancy.h:26-40
+    const uint16_t* perm = &perms[size_t(sums[baseIndex])];
+    int base = primes[baseIndex];
+    float invBase = 1.0f / base, invBaseN = 1.0f;
+    uint64_t reversedDigits = 0;
+    while (a) {
+      uint64_t next = a / uint64_t(base);
+      uint64_t digits = a - next * uint64_t(base);
+      reversedDigits = reversedDigits * uint64_t(base) + perm[digits];
+      invBaseN *= invBase;
+      a = next;
+    }
+    float series = perm[0] / (base + 1.0f);
+    return fmin_((float(reversedDigits) + series) * invBaseN, kOneMinusEps);
+  }
+  static uint64_t inverse_radical_inverse(uint64_t inverse, int base, int nDigits) {  // lowdiscrepancy.h:42-51
+    uint64_t index = 0;
+    for (int i = 0; i < nDigits; i++) {
+      uint64_t digit = inverse % uint64_t(base);
+      inverse /= uint64_t(base);
+      index = index * uint64_t(base) + digit;
+    }
+    return index;
+  }
+};
+static const HaltonTables& halton_tables() {
+  static const HaltonTables t;
+  return t;
+}
+
+enum SamplerKind { SAMPLER_BLUE = 0, SAMPLER_SOBOL = 1, SAMPLER_HALTON = 2 };
 struct Sampler {
   BlueTables t;
   int kind = SAMPLER_BLUE;
@@ -420,6 +520,8 @@ struct Sampler {
   // SobolSampler state
   int log2_spp = 0, nbase4_digits = 0;
   uint64_t sobol_index = 0;
+  // HaltonSampler state
+  int64_t halton_index = 0;
 
   void init(int W, int H) {  // Sampler::init -> SobolSampler::init sampler.cpp:81-84 (a no-op for the others)
     log2_spp = log2i_(spp);  // SobolSampler ctor sampler.h:127-129
@@ -435,11 +537,26 @@ struct Sampler {
       dimension = 0;
       sobol_index = (encode_morton64x2(uint32_t(x), uint32_t(y)) << log2_spp) | uint64_t(sample_index);
     }
+    if (kind == SAMPLER_HALTON) {  // sampler.cpp:64-79
+      const HaltonTables& H = halton_tables();
+      halton_index = 0;
+      if (H.sampleStride > 1) {
+        const int pm[2] = {int(HaltonTables::mod_(x, 128)), int(HaltonTables::mod_(y, 128))};
+        for (int i = 0; i < 2; i++) {
+          uint64_t dimOffset = HaltonTables::inverse_radical_inverse(uint64_t(pm[i]), i == 0 ? 2 : 3, H.baseExponents[i]);
+          halton_index += int64_t(dimOffset * uint64_t(H.baseScales[1 - i]) * uint64_t(H.multInverse[1 - i]));
+        }
+        halton_index %= H.sampleStride;
+      }
+      halton_index += int64_t(sample_index) * H.sampleStride;
+      dimension = 2;
+    }
   }
-  void start_next_sample() {  // sampler.h:178-181 / :139-142
-    dimension = 0;
+  void start_next_sample() {  // sampler.h:178-181 / :139-142 / :48-51
+    dimension = kind == SAMPLER_HALTON ? 2 : 0;
     index++;
     sobol_index++;
+    halton_index += halton_tables().sampleStride;
   }
   uint64_t sobol_compute_sample_index() const {  // sampler.cpp:86-113
     static const uint8_t permutations[24][4] = {
@@ -474,7 +591,11 @@ struct Sampler {
     value = value ^ t.scramble[(sd % 8) + (pi + pj * 128) * 8];
     return (0.5f + value) / 256.0f;
   }
-  float get1d() {  // sampler.h:183-187 / :143-148
+  float get1d() {  // sampler.h:183-187 / :143-148 / :52-56
+    if (kind == SAMPLER_HALTON) {
+      if (dimension >= 1000) dimension = 2;
+      return halton_tables().scrambled_radical_inverse(dimension++, uint64_t(halton_index));
+    }
     if (kind == SAMPLER_SOBOL) {
       uint64_t si = sobol_compute_sample_index();
       dimension += 1;
@@ -484,7 +605,15 @@ struct Sampler {
     if (dimension >= 256) dimension = 2;
     return sample_dimension(dimension++);
   }
-  vec2 get2d() {  // sampler.h:188-194 / :149-155
+  vec2 get2d() {  // sampler.h:188-194 / :149-155 / :57-63
+    if (kind == SAMPLER_HALTON) {
+      if (dimension + 1 >= 1000) dimension = 2;
+      const int dim = dimension;
+      dimension += 2;
+      const float a = halton_tables().scrambled_radical_inverse(dim, uint64_t(halton_index));
+      const float b = halton_tables().scrambled_radical_inverse(dim + 1, uint64_t(halton_index));
+      return {a, b};
+    }
     if (kind == SAMPLER_SOBOL) {
       uint64_t si = sobol_compute_sample_index();
       dimension += 2;
@@ -2699,8 +2828,8 @@ void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int dep
                  int shard_rank = 0, int shard_world = 1) {
   int W = scene.camera.W, H = scene.camera.H;
   const int sampler_kind = g_sampler_kind;
-  int spp = sampler_kind == SAMPLER_SOBOL ? spp_req : bluesobol_effective_spp(spp_req);  // SobolSampler::spp() is the request as given
-  BlueTables bt = select_tables(tables, sampler_kind == SAMPLER_SOBOL ? 1 : spp);
+  int spp = sampler_kind != SAMPLER_BLUE ? spp_req : bluesobol_effective_spp(spp_req);  // Sobol / Halton: spp() is the request as given
+  BlueTables bt = select_tables(tables, sampler_kind != SAMPLER_BLUE ? 1 : spp);
   Integrator integ{&scene, depth};
   if (threads <= 0) threads = int(std::thread::hardware_concurrency());
   if (threads <= 0) threads = 1;
@@ -2784,7 +2913,7 @@ extern "C" {
 
 const char* oracle_last_error(void) { return g_error.c_str(); }
 
-void oracle_set_sampler(int kind) { g_sampler_kind = kind == SAMPLER_SOBOL ? SAMPLER_SOBOL : SAMPLER_BLUE; }
+void oracle_set_sampler(int kind) { g_sampler_kind = kind == SAMPLER_SOBOL ? SAMPLER_SOBOL : kind == SAMPLER_HALTON ? SAMPLER_HALTON : SAMPLER_BLUE; }
 
 int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,
                   int y0, int y1, float* film_out, oracle_stats* stats) {

@@ -31,7 +31,7 @@ int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth,
                   int y0, int y1, float* film_out, oracle_stats* stats);
 
 /* Which sampler the render entry points construct: 0 = BlueSobolSampler(spp) (default), 1 = SobolSampler(spp)
- * (sampler.h:83-164; spp is used as given, no rounding or clamp).  Process-wide, not thread-safe: test use only. */
+ * (sampler.h:83-164), 2 = HaltonSampler(spp) (sampler.h:40-81); for the latter two spp is used as given.  Process-wide, not thread-safe: test use only. */
 void oracle_set_sampler(int kind);
 
 /* Render only the pixels of this shard (8x8 tiles dealt round-robin, the product's multi-GPU

@@ -289,7 +289,9 @@ int main(int argc, char** argv) {
     const bool sobol = argc == 7 && std::string(argv[6]) == "sobol";  // SobolSampler(spp) instead of BlueSampler(spp)
     // zero the film first: PathIntegrator::render does not clear it (path.cpp:38 plain store)
     L.scene.camera.film().clear();
-    auto integ = PathIntegrator(Accel(BVH()), sobol ? Sampler(SobolSampler(spp)) : Sampler(BlueSobolSampler(spp)),
+    const bool halton = argc == 7 && std::string(argv[6]) == "halton";  // HaltonSampler(spp)
+    auto integ = PathIntegrator(Accel(BVH()),
+                                sobol ? Sampler(SobolSampler(spp)) : halton ? Sampler(HaltonSampler(spp)) : Sampler(BlueSobolSampler(spp)),
                                 UniformLightSampler(), depth);
     auto t0 = std::chrono::steady_clock::now();
     integ.render(L.scene);
@@ -297,7 +299,7 @@ int main(int argc, char** argv) {
     double sec = std::chrono::duration<double>(t1 - t0).count();
     auto& film = L.scene.camera.film();
     write_file(argv[5], film.data(), size_t(16) * L.W * L.H);
-    int eff = sobol ? spp : BlueSobolSampler(spp).spp();
+    int eff = (sobol || halton) ? spp : BlueSobolSampler(spp).spp();
     printf("{\"seconds\": %.6f, \"threads\": %u, \"w\": %d, \"h\": %d, \"spp\": %d, \"depth\": %d, "
            "\"msamples_per_s\": %.6f}\n",
            sec, std::thread::hardware_concurrency(), L.W, L.H, eff, depth,

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, FILM_NAMES, SOBOL_FILM_NAMES, assert_bit_equal, load_film
+from conftest import GOLDEN, FILM_NAMES, SOBOL_FILM_NAMES, HALTON_FILM_NAMES, assert_bit_equal, load_film
 
 
 @pytest.mark.parametrize("spp", [1, 16, 256])
@@ -79,6 +79,19 @@ def test_sobol_sampler_film_bit_identical_to_reference(oracle, name):
     film, st = oracle.render(ps, (w, h), spp, depth, sampler="sobol")
     assert_bit_equal(film, ref, name)
     assert st.camera_samples == w * h * spp  # no rounding, no clamp
+
+
+@pytest.mark.parametrize("name", HALTON_FILM_NAMES)
+def test_halton_sampler_film_bit_identical_to_reference(oracle, name):
+    """HaltonSampler (sampler.h:40-81, sampler.cpp:16-79): scrambled radical inverses over the first 1000 primes, the
+    digit permutations shuffled by a default-seeded RNG, pixel offsets through the 128 x 243 grid -- the oracle's
+    restatement (tables derived, not stored) against films the real reference rendered with HaltonSampler(spp).
+    Oracle only: the device path refuses this sampler."""
+    ref, ps, spp, depth = load_film(name)
+    h, w, _ = ref.shape
+    film, st = oracle.render(ps, (w, h), spp, depth, sampler="halton")
+    assert_bit_equal(film, ref, name)
+    assert st.camera_samples == w * h * spp
 
 
 def test_row_range_and_shards_compose(oracle):

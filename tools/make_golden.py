@@ -72,6 +72,13 @@ SOBOL_FILMS = {
 }
 
 
+HALTON_FILMS = {
+    # HaltonSampler(spp) (sampler.h:40-81): restated in the oracle only (the device refuses it)
+    "halton_cbox_readme_40_s8_d4": (lambda: scenes.cbox((40, 40), "readme"), 8, 4),
+    "halton_mats_zoo_32_s12_d6": (lambda: scenes.materials_zoo((32, 32)), 12, 6),
+}
+
+
 def main():
     full = "--full" in sys.argv
     os.makedirs(OUT, exist_ok=True)
@@ -138,6 +145,14 @@ def main():
             ps, film, info = ref_film(build(), spp, depth, tmp, "sobol")
             np.savez_compressed(os.path.join(OUT, f"film_{name}.npz"), film=film, pscene=np.array(ps), spp=spp, depth=depth)
             meta[name] = {"spp": spp, "depth": depth, "size": [info["w"], info["h"]], "sampler": "sobol",
+                          "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
+                          "md5": hashlib.md5(film.tobytes()).hexdigest()}
+            print(name, meta[name]["mean_rgb"])
+
+        for name, (build, spp, depth) in HALTON_FILMS.items():
+            ps, film, info = ref_film(build(), spp, depth, tmp, "halton")
+            np.savez_compressed(os.path.join(OUT, f"film_{name}.npz"), film=film, pscene=np.array(ps), spp=spp, depth=depth)
+            meta[name] = {"spp": spp, "depth": depth, "size": [info["w"], info["h"]], "sampler": "halton",
                           "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
                           "md5": hashlib.md5(film.tobytes()).hexdigest()}
             print(name, meta[name]["mean_rgb"])
