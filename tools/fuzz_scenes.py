@@ -1,6 +1,7 @@
 """Randomised scene fuzzing: seeded random mixes of every shape, material and light kind.
    python tools/fuzz_scenes.py ref N   -- here (CPU): the oracle restatement against the real reference binary
    python tools/fuzz_scenes.py gpu N   -- on the GPU box: the HIP path against the oracle
+   optional: VARIETY (1 | 2) and the first SEED
 Every film must match bit for bit."""
 import sys, os, subprocess, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,8 +20,9 @@ from pine_amd.scenes import random_scene as rnd_scene  # noqa: E402
 def main():
     mode, n = sys.argv[1], int(sys.argv[2])
     variety = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # 2: also fractional Uber lobes and Subsurface meshes (in-path RNG)
+    base = int(sys.argv[4]) if len(sys.argv) > 4 else 1000  # first seed
     bad = 0
-    for seed in range(1000, 1000 + n):
+    for seed in range(base, base + n):
         try:
             sc, spp, depth, sampler = rnd_scene(seed, variety=variety)
         except pa.PineError as e:  # e.g. a degenerate random Rect: a legitimate rejection
