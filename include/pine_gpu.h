@@ -182,6 +182,10 @@ typedef struct {
                                     not together with Subsurface materials                                  */
 
 #define PINE_GPU_FLAG_TIMING 1 /* record per-kernel HIP-event timings for the roofline report */
+#define PINE_GPU_FLAG_PROGRESS 2 /* the kernels post the claimed work-item count to host memory now and then, so that
+                                    pine_gpu_progress() moves while a launch runs (pine_gpu_path_render sets it itself) */
+#define PINE_GPU_FLAG_DEBUG_FORCE_BAIL 0x100 /* test hook: the stage-queued path kernel raises its protocol-failure
+                                    bail-out at once; every synchronising entry point must then FAIL (never return the film) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are
  * dealt round-robin to `world` ranks (host-side helper; the kernels use the same mapping). */
@@ -227,8 +231,13 @@ typedef struct {
   int32_t lds_bytes;
   int32_t timed_launches;    /* number of launches the three timings are averaged over        */
 } pine_gpu_plan_stats;
-/* Blocks until the last launch has finished (needed to read the device-side counters). */
+/* Blocks until the last launch has finished (needed to read the device-side counters).  Fails (< 0) if the
+ * path kernel of that launch bailed out of a bounded wait: its film is incomplete. */
 int pine_gpu_plan_stats_get(pine_gpu_plan*, pine_gpu_plan_stats* out);
+/* For callers that launch asynchronously and read the film themselves: blocks until the plan's last launch
+ * has finished; 0 = it completed, < 0 = its path kernel bailed out (pine_gpu_last_error() names the wait that
+ * ran out) and the film must be discarded.  The reference has no counterpart: its render() cannot fail part-way. */
+int pine_gpu_plan_check(pine_gpu_plan*);
 
 /* Diagnostic builds only (-DPINE_PROFILE_SECTIONS): per-section wave-cycle sums of the last launch
  * (all zeros in the product build). */

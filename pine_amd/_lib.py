@@ -53,6 +53,8 @@ class PlanStats(C.Structure):
 
 
 FLAG_TIMING = 1
+FLAG_PROGRESS = 2
+FLAG_DEBUG_FORCE_BAIL = 0x100
 
 # every symbol include/pine_gpu.h declares, with its signature
 SIGNATURES = {
@@ -120,6 +122,7 @@ SIGNATURES = {
     "pine_gpu_film_unpack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pine_gpu_plan_destroy": (None, [C.c_void_p]),
     "pine_gpu_plan_stats_get": (C.c_int, [C.c_void_p, C.POINTER(PlanStats)]),
+    "pine_gpu_plan_check": (C.c_int, [C.c_void_p]),
     "pine_gpu_plan_read_samples": (C.c_int, [C.c_void_p, c_f_p, C.c_int64]),
     "pine_gpu_plan_debug_sections": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "pine_gpu_test_sampler": (C.c_int, [C.c_int, C.c_int, c_f_p, C.c_int64]),

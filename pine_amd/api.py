@@ -529,7 +529,7 @@ class Plan:
     """A PathIntegrator bound to a scene with all device state resident (bench / multi-GPU)."""
 
     def __init__(self, scene, spp, max_path_length, device=0, shard_rank=0, shard_world=1,
-                 samples_per_item=0, timing=False, sampler="blue"):
+                 samples_per_item=0, timing=False, sampler="blue", flags=0):
         """spp: an int (BlueSampler(spp), or SobolSampler(spp) with sampler="sobol") or a sampler object."""
         if scene.camera is None:
             raise PineError("scene has no camera")
@@ -539,7 +539,7 @@ class Plan:
             kind, spp = getattr(spp, "kind", 0), spp.requested
         self.params = _lib.RenderParams(int(spp), int(max_path_length), int(device), int(shard_rank),
                                         int(shard_world), int(samples_per_item),
-                                        _lib.FLAG_TIMING if timing else 0, kind)
+                                        (_lib.FLAG_TIMING if timing else 0) | int(flags), kind)
         h = lib.pine_gpu_plan_create(scene._h, C.byref(self.params))
         if not h:
             raise PineError("PathIntegrator: " + _lib.last_error())
@@ -555,6 +555,10 @@ class Plan:
     def slab_floats(self):
         w, h = self.scene.camera.film().size
         return int(lib.pine_gpu_packed_slab_floats(w, h, self.params.shard_world))
+
+    def check(self):
+        """Wait for the last launch; raises PineError if its path kernel bailed out (incomplete film)."""
+        check(lib.pine_gpu_plan_check(self._h), "render")
 
     def stats(self):
         st = _lib.PlanStats()
@@ -597,16 +601,16 @@ class PathIntegrator:
     """PathIntegrator(sampler, max_path_length).render(scene) -- the convenience overload a .pine
     script uses (program_context.cpp:79-81); pine-BVH traversal order, UniformLightSampler."""
 
-    def __init__(self, sampler, max_path_length, device=0):
+    def __init__(self, sampler, max_path_length, device=0, flags=0):
         if max_path_length <= 0:  # path.cpp:12-13
             raise PineError(f"`PathIntegrator` expect `max_path_length` to be positive, get {max_path_length}")
-        self.sampler, self.max_path_length, self.device = sampler, int(max_path_length), device
+        self.sampler, self.max_path_length, self.device, self.flags = sampler, int(max_path_length), device, int(flags)
 
     def render(self, scene):
         if scene.camera is None:
             raise PineError("scene has no camera")
         film = scene.camera.film()
-        prm = _lib.RenderParams(self.sampler.requested, self.max_path_length, self.device, 0, 1, 0, 0,
+        prm = _lib.RenderParams(self.sampler.requested, self.max_path_length, self.device, 0, 1, 0, self.flags,
                                 getattr(self.sampler, "kind", 0))
         out = np.zeros((film.size[1], film.size[0], 4), dtype=np.float32)
         check(lib.pine_gpu_path_render(scene._h, C.byref(prm), out.ctypes.data_as(_lib.c_f_p)), "PathIntegrator.render")

@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -141,7 +142,15 @@ struct WorkParams {
   int log2_items_per_pixel;
   unsigned tiles_x_magic;  // ceil(2^32 / tiles_x): see decode_item
   unsigned long long total_items;  // num_local_tiles * items_per_pixel * 64
+  unsigned long long idle_budget_ticks;  // stage-queued kernel: a wave that finds no work for this long (100 MHz wall clock) bails out
+  int debug_force_bail;  // test hook (PINE_GPU_FLAG_DEBUG_FORCE_BAIL): the first wave bails out at once
+  unsigned long long* progress;  // host-mapped word (or null): work items claimed so far, stored now and then (get_progress)
 };
+// get_progress() (integrator.cpp:17-19): every 16th / 64th pool claim posts the claimed-item count to host memory
+__device__ __forceinline__ void post_progress(const WorkParams& W, unsigned long long claimed, unsigned shift) {
+  if (W.progress && ((claimed >> shift) & 15ull) == 0ull)
+    __hip_atomic_store(W.progress, claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ------------------------------------------------------------------------------------------------
 // BVH traversal -- pine's ordered stack traversal (src/pine/impl/accel/bvh.cpp:321-451), with the
@@ -369,6 +378,11 @@ struct Counters {
   unsigned long long next_item;
   unsigned long long vertices;
   unsigned long long shadow_rays;
+  // protocol failure of the stage-queued kernel (a bounded spin or the idle budget ran out): number of
+  // bail-outs of the launch, and the code / operands of one of them.  Read by every host entry point
+  // that synchronises (plan_check): a launch with bail_count != 0 has an incomplete film and FAILS.
+  unsigned long long bail_count;
+  unsigned long long bail_code, bail_a, bail_b;
   unsigned long long pad;
   unsigned long long section_cycles[16];  // diagnostic builds (-DPINE_PROFILE_SECTIONS) only
 };
@@ -399,11 +413,15 @@ constexpr size_t kLdsFixedBytes = size_t(kOffStack) * 4;
 // Packed per-lane path bookkeeping (one VGPR):
 //   bits 0-11 sample index within the pixel (BlueSobolSampler::index / the low part of SobolSampler's index),
 //   12-20 sampler dimension, 21-26 Vertex::length, 27 Vertex::diffuse_length > 0 (all the path reads of it,
-//   path.cpp:93), 28 Vertex::is_delta.  Bits 29-31 stay clear (0xffffffff marks an empty context).
+//   path.cpp:93), 28 Vertex::is_delta, 29-30 the stage-queued kernel's BSSRDF walk status of the vertex being shaded
+//   (kWalk*).  Bit 31 stays clear (0xffffffff marks an empty context).
 constexpr int kMaxDeviceSpp = 4096;      // 12 bits of sample index
 constexpr int kMaxSamplerDimension = 511;  // 9 bits: BlueSampler wraps at 256; SobolSampler counts up to 8 draws per vertex
+enum : unsigned { kWalkNone = 0, kWalkRunning = 1, kWalkExited = 2, kWalkFailed = 3 };
 struct PackedState {
   unsigned v;
+  __device__ __forceinline__ unsigned walk() const { return (v >> 29) & 3u; }
+  __device__ __forceinline__ void set_walk(unsigned w) { v = (v & ~(3u << 29)) | (w << 29); }
   __device__ __forceinline__ int s_cur() const { return int(v & 0xfffu); }
   __device__ __forceinline__ int dim() const { return int((v >> 12) & 0x1ffu); }
   __device__ __forceinline__ int length() const { return int((v >> 21) & 0x3fu); }
@@ -550,6 +568,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           if (base >= W.total_items) {
             queue_empty = true;
           } else {
+            if ((tid & 63) == 0) post_progress(W, base, 9);
             pool_next = base;
             pool_end = base + kPoolItems < W.total_items ? base + kPoolItems : W.total_items;
           }
@@ -932,7 +951,7 @@ static const KernelVariant kVariants[] = {
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 
-// stage-queued kernel (pine_queue_kernel.h): same feature lattice, without the SSS variants
+// stage-queued kernel (pine_queue_kernel.h): same feature lattice
 using QueueKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, uint32_t*, Counters*);
 struct QueueVariant {
   unsigned features;
@@ -941,7 +960,7 @@ struct QueueVariant {
   QueueKernelFn fn;
   const char* name;
 };
-#define PINE_QV(F, CTX, NAME) {F, CTX, QLayout<CTX>::fixed_bytes, path_queue_kernel<F, CTX>, NAME}
+#define PINE_QV(F, CTX, NAME) {F, CTX, QLayout<CTX, ((F) & F_SSS) ? 3 : 2>::fixed_bytes, path_queue_kernel<F, CTX>, NAME}
 static const QueueVariant kQueueVariants[] = {
     PINE_QV(F_OBB | F_LDS_SCENE, PINE_QCTX, "queue: rect+transformed box/diffuse, scene in LDS"),  // cbox exactly
     PINE_QV(kFBoxes | F_LDS_SCENE, PINE_QCTX, "queue: rect+box/diffuse, scene in LDS"),
@@ -955,6 +974,9 @@ static const QueueVariant kQueueVariants[] = {
     // everything except Subsurface (meshes, node-graph materials, every light kind); 1024 contexts so that
     // a deep traversal stack (4 KB of LDS per slot, two BVH levels for meshes) fits
     PINE_QV((F_ALL & ~F_SSS), 1024, "queue: all but SSS, 1024 contexts (deep BVH)"),
+    // Subsurface: the BSSRDF random walk is a third stage (W) with its own queue
+    PINE_QV(F_MESH | F_SSS, 1024, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts"),
+    PINE_QV(F_ALL, 1024, "queue: all features, walk stage, 1024 contexts"),
 #endif
 };
 constexpr int kNumQueueVariants = int(sizeof(kQueueVariants) / sizeof(kQueueVariants[0]));
@@ -1118,13 +1140,21 @@ __global__ void test_shapes_kernel(const DShape* shapes, int num_shapes, const f
   } while (0)
 
 static std::string g_table_path;
-static std::vector<uint8_t> g_tables;
+// The packed tables are immutable once read; users take a shared snapshot, so a concurrent
+// pine_gpu_set_table_path (which only drops the library's own reference) cannot free them under a reader.
+using TableBlob = std::shared_ptr<const std::vector<uint8_t>>;
+static TableBlob g_tables;
 static std::mutex g_table_mutex;
 static std::atomic<float> g_progress{0.0f};
+static std::atomic<const volatile unsigned long long*> g_progress_src{nullptr};
+static std::atomic<unsigned long long> g_progress_total{0};
 
-static int load_tables() {
+static int load_tables(TableBlob& out) {
   std::lock_guard<std::mutex> lock(g_table_mutex);
-  if (!g_tables.empty()) return 0;
+  if (g_tables) {
+    out = g_tables;
+    return 0;
+  }
   if (g_table_path.empty()) {
     // not set by the host: $PINE_GPU_TABLES, else data/bluesobol_u8.bin next to the directory this library sits in
     // (pine_amd/lib/libpine_gpu.so -> pine_amd/data/), wherever the process was started from
@@ -1154,16 +1184,17 @@ static int load_tables() {
     set_error("short read of " + g_table_path);
     return -1;
   }
-  g_tables.swap(buf);
+  g_tables = std::make_shared<const std::vector<uint8_t>>(std::move(buf));
+  out = g_tables;
   return 0;
 }
 // The device keeps sobol_256spp_256d transposed ([dimension][sample] instead of [sample][dimension]):
 // lanes of a wave usually ask for the same dimension at 64 different (ranked) sample rows, which is
 // one 256-byte row here instead of 64 cache lines 256 bytes apart.
-static std::vector<uint8_t> transposed_sobol() {
+static std::vector<uint8_t> transposed_sobol(const std::vector<uint8_t>& tables) {
   std::vector<uint8_t> t(65536);
   for (int s = 0; s < 256; s++)
-    for (int d = 0; d < 256; d++) t[d * 256 + s] = g_tables[s * 256 + d];
+    for (int d = 0; d < 256; d++) t[d * 256 + s] = tables[s * 256 + d];
   return t;
 }
 static int effective_spp(int spp) {  // BlueSobolSampler ctor sampler.cpp:115-121
@@ -1225,11 +1256,47 @@ struct pine_gpu_plan {
   bool timed = false;
   bool launched = false;
   hipStream_t last_stream = nullptr;
+  unsigned long long* h_progress = nullptr;  // host-mapped progress word (PINE_GPU_FLAG_PROGRESS)
 };
+
+static int plan_check_counters(const Counters& c) {
+  if (c.bail_count == 0) return 0;
+  static const char* const kWhat[] = {"?", "idle budget exhausted with work outstanding", "ring slot never filled", "item-pool lock never released",
+                                      "work-item hand-out did not converge", "?", "?", "forced by PINE_GPU_FLAG_DEBUG_FORCE_BAIL"};
+  char msg[256];
+  snprintf(msg, sizeof msg, "path kernel bailed out (%llu wave(s)): code %llu (%s), operands 0x%llx 0x%llx -- the film of this launch is incomplete",
+           c.bail_count, c.bail_code, c.bail_code < 8 ? kWhat[c.bail_code] : "?", c.bail_a, c.bail_b);
+  set_error(msg);
+  return -1;
+}
 
 extern "C" {
 
-float pine_gpu_progress(void) { return g_progress.load(); }
+float pine_gpu_progress(void) {
+  // while a one-shot render is in flight: items claimed by the device / items of the launch
+  const volatile unsigned long long* src = g_progress_src.load();
+  if (src) {
+    const unsigned long long total = g_progress_total.load();
+    const float f = total ? float(double(*src) / double(total)) : 0.0f;
+    return f < 1.0f ? f : 1.0f;
+  }
+  return g_progress.load();
+}
+
+/* Synchronise with the plan's last launch and report a protocol failure of its path kernel (a bounded
+ * spin or the idle budget ran out: the film of that launch is incomplete).  0 = the launch completed. */
+int pine_gpu_plan_check(pine_gpu_plan* p) {
+  if (!p) {
+    set_error("null argument");
+    return -1;
+  }
+  if (!p->launched) return 0;
+  HIP_OK(hipSetDevice(p->device));
+  HIP_OK(hipStreamSynchronize(p->last_stream));
+  Counters c;
+  HIP_OK(hipMemcpy(&c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  return plan_check_counters(c);
+}
 
 int pine_gpu_set_table_path(const char* path) {
   if (!path) {
@@ -1238,7 +1305,7 @@ int pine_gpu_set_table_path(const char* path) {
   }
   std::lock_guard<std::mutex> lock(g_table_mutex);
   g_table_path = path;
-  g_tables.clear();
+  g_tables.reset();  // (plans being built keep their own snapshot)
   return 0;
 }
 
@@ -1253,6 +1320,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_samples);
   (void)hipFree(p->d_fold);
   (void)hipFree(p->d_counters);
+  if (p->h_progress) (void)hipHostFree(p->h_progress);
   for (auto& slot : p->ev)
     for (auto& e : slot)
       if (e) (void)hipEventDestroy(e);
@@ -1293,7 +1361,9 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     set_error("bad shard rank/world");
     return -1;
   }
-  if (load_tables()) return -1;
+  TableBlob tables_blob;
+  if (load_tables(tables_blob)) return -1;
+  const std::vector<uint8_t>& g_tables = *tables_blob;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     set_error("no HIP device available: the PathIntegrator hot path requires an AMD GPU (no CPU fallback)");
@@ -1359,7 +1429,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // a pixel's 40 consecutive ranking bytes never need the reference's modulo wrap
   HIP_OK(hipMalloc((void**)&p->d_tables, 65536 + 262144 + 64));
   {
-    const std::vector<uint8_t> st = transposed_sobol();
+    const std::vector<uint8_t> st = transposed_sobol(g_tables);
     HIP_OK(hipMemcpy(p->d_tables, st.data(), 65536, hipMemcpyHostToDevice));
   }
   HIP_OK(hipMemcpy(p->d_tables + 65536, g_tables.data() + 65536 + size_t(k) * 262144, 262144, hipMemcpyHostToDevice));
@@ -1461,14 +1531,13 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     return -1;
   }
   if (kVariants[p->variant].features & F_LDS_SCENE) p->lds_bytes += size_t(S.blob_bytes);
-  // The stage-queued kernel is the default whenever a variant covers the scene and its LDS fits
-  // (not for Subsurface materials and meshes: see pine_queue_kernel.h); PINE_GPU_KERNEL=mega forces
-  // the lane-owns-a-path kernel, which covers every scene.
+  // The stage-queued kernel is the default whenever a variant covers the scene and its LDS fits;
+  // PINE_GPU_KERNEL=mega forces the lane-owns-a-path kernel, which covers every scene.
   p->queue_variant = -1;
   {
     const char* ksel = getenv("PINE_GPU_KERNEL");
     const bool want_queue = !(ksel && std::string(ksel) == "mega");
-    if (want_queue && !(need & F_SSS)) {
+    if (want_queue) {
       for (int v = 0; v < kNumQueueVariants; v++) {
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
@@ -1521,6 +1590,28 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   while ((1 << W.log2_items_per_pixel) < W.items_per_pixel) W.log2_items_per_pixel++;
   W.tiles_x_magic = unsigned(((1ull << 32) + unsigned(W.tiles_x) - 1) / unsigned(W.tiles_x));  // tiles_x >= 1
   W.total_items = (unsigned long long)W.num_local_tiles * W.items_per_pixel * 64ull;
+  // packing limits of the kernels: pixel coordinates travel as 16 + 16 bits, the sample-buffer index of a
+  // context as 32 bits
+  if (p->film_w > 65535 || p->film_h > 65535) {
+    set_error("film sides above 65535 are not supported");
+    return -1;
+  }
+  if ((unsigned long long)W.num_local_tiles * 64ull * (unsigned long long)spp >= (1ull << 32)) {
+    set_error("film pixels x samples per pixel of one shard must stay below 2^32 (render in several shards)");
+    return -1;
+  }
+  {
+    double budget_s = 30.0;
+    if (const char* e = getenv("PINE_GPU_IDLE_BUDGET_S")) budget_s = atof(e) > 0 ? atof(e) : budget_s;
+    W.idle_budget_ticks = (unsigned long long)(budget_s * 100e6);  // wall_clock64(): 100 MHz
+  }
+  W.debug_force_bail = (prm->flags & PINE_GPU_FLAG_DEBUG_FORCE_BAIL) ? 1 : 0;
+  W.progress = nullptr;
+  if (prm->flags & PINE_GPU_FLAG_PROGRESS) {
+    HIP_OK(hipHostMalloc((void**)&p->h_progress, sizeof(unsigned long long), hipHostMallocMapped));
+    *p->h_progress = 0;
+    HIP_OK(hipHostGetDevicePointer((void**)&W.progress, p->h_progress, 0));
+  }
 
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));
@@ -1547,7 +1638,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   const size_t fold_slots = p->queue_variant >= 0 ? size_t(p->grid) * qctx : size_t(p->grid) * kBlock;
   HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * fold_slots * sizeof(float)));
   if (p->queue_variant >= 0)
-    HIP_OK(hipMalloc((void**)&p->d_ctxg, size_t(p->grid) * qctx * kQCtxGlobalDwords * sizeof(uint32_t)));
+    HIP_OK(hipMalloc((void**)&p->d_ctxg, size_t(p->grid) * qctx * q_ctx_global_dwords(kQueueVariants[p->queue_variant].features) * sizeof(uint32_t)));
   HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
   p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
   if (p->timed)
@@ -1678,6 +1769,7 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
     HIP_OK(hipStreamSynchronize(p->last_stream));
     Counters c;
     HIP_OK(hipMemcpy(&c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    if (plan_check_counters(c)) return -1;
     out->vertices = c.vertices;
     out->shadow_rays = c.shadow_rays;
     if (p->timed) {
@@ -1760,7 +1852,9 @@ int pine_gpu_path_render(pine_gpu_scene* scene, const pine_gpu_render_params* pr
     set_error("null argument");
     return -1;
   }
-  pine_gpu_plan* p = pine_gpu_plan_create(scene, prm);
+  pine_gpu_render_params prm2 = *prm;
+  prm2.flags |= PINE_GPU_FLAG_PROGRESS;  // the reference's CLI polls get_progress() while render() runs (src/cli/pine.cpp:36-40)
+  pine_gpu_plan* p = pine_gpu_plan_create(scene, &prm2);
   if (!p) return -1;
   int rc = -1;
   void* d_film = nullptr;
@@ -1770,14 +1864,18 @@ int pine_gpu_path_render(pine_gpu_scene* scene, const pine_gpu_render_params* pr
       set_error("hipMalloc(film) failed");
       break;
     }
+    g_progress_total.store(p->W.total_items);
+    g_progress_src.store(p->h_progress);
     if (pine_gpu_plan_launch(p, d_film, nullptr)) break;
     if (hipMemcpy(film_out, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
       set_error("film download failed");
       break;
     }
-    g_progress.store(1.0f);
+    if (pine_gpu_plan_check(p)) break;  // a bailed-out path kernel leaves an incomplete film: fail, do not return it as a result
     rc = 0;
   } while (0);
+  g_progress_src.store(nullptr);
+  g_progress.store(rc ? 0.0f : 1.0f);
   std::string keep = rc ? pine_gpu_last_error() : "";
   hipFree(d_film);
   pine_gpu_plan_destroy(p);
@@ -1830,7 +1928,9 @@ int pine_gpu_test_powlog(int device, const float* x, const float* y, int64_t n, 
 }
 int pine_gpu_test_sampler(int device, int spp_req, float* out, int64_t capacity) {
   if (need_device(device)) return -1;
-  if (load_tables()) return -1;
+  TableBlob tables_blob;
+  if (load_tables(tables_blob)) return -1;
+  const std::vector<uint8_t>& g_tables = *tables_blob;
   const int spp = effective_spp(spp_req);
   const int64_t need = int64_t(6) * spp * (260 + 270);
   if (capacity < need) {
@@ -1843,7 +1943,7 @@ int pine_gpu_test_sampler(int device, int spp_req, float* out, int64_t capacity)
   float* dout;
   HIP_OK(hipMalloc((void**)&dt, 65536 + 262144));
   {
-    const std::vector<uint8_t> st = transposed_sobol();
+    const std::vector<uint8_t> st = transposed_sobol(g_tables);
     HIP_OK(hipMemcpy(dt, st.data(), 65536, hipMemcpyHostToDevice));
   }
   HIP_OK(hipMemcpy(dt + 65536, g_tables.data() + 65536 + size_t(k) * 262144, 262144, hipMemcpyHostToDevice));

@@ -31,42 +31,52 @@ constexpr int kQBlock = PINE_QBLOCK;  // threads per workgroup (one workgroup pe
 #endif
 constexpr int kQFields = 12;   // dwords of context state
 constexpr int kQPoolItems = 512;
-enum : int { QS_S = 0, QS_T = 1, QS_COUNT = 2 };
+enum : int { QS_S = 0, QS_T = 1, QS_W = 2 };  // the walk queue W exists in the Subsurface (F_SSS) variants only
 // context state fields (SoA in LDS: cst[field * kQCtx + id])
 enum : int { CF_OX, CF_OY, CF_OZ, CF_DX, CF_DY, CF_DZ, CF_TMAX, CF_ST, CF_PXY, CF_SBASE, CF_GEOM, CF_PRIM };
 constexpr unsigned kStFresh = 0xffffffffu;  // context has no path yet
-// control words
-enum : int { QC_HEAD = 0, QC_TAIL = 2, QC_BUSY = 6, /* heads at 0..1, tails at 2..3 (one u64) */ QC_LOCK = 7, QC_PNEXT = 8, QC_PEND = 10, QC_EXHAUSTED = 12, QC_ABORT = 13, QC_WORDS = 16 };
+// control words: heads at 0..2; the S and T tails are ONE u64 (4..5) so that a stage reserves slots in both with one
+// atomic; the W tail at 6
+enum : int { QC_HEAD = 0, QC_TAIL = 4, QC_BUSY = 7, QC_LOCK = 8, QC_EXHAUSTED = 9, QC_PNEXT = 10, QC_PEND = 12, QC_ABORT = 14, QC_WORDS = 16 };
 constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a protocol bug must end the kernel, not hang the GPU
 constexpr int kQWinDwords = 5;  // per-thread sampler window: 3 dwords of ranking bytes (12 dimensions) + 2 of scrambling bytes
 
 // LDS layout (dword offsets) for CTX path contexts per workgroup: the default is 1.5 contexts per thread;
 // scenes whose BVH needs a deep traversal stack (4 KB of LDS per stack slot) use the 1024-context layout.
-template <int CTX>
+template <int CTX, int NQ = 2>
 struct QLayout {
   static constexpr int ctx = CTX;
   static constexpr int ring = CTX <= 1024 ? 1024 : 2048;  // ring capacity (power of two >= CTX)
   static constexpr int off_ctl = 0;
-  static constexpr int off_ring = off_ctl + QC_WORDS;  // QS_COUNT rings of `ring` dwords (id + 1, 0 = empty)
-  static constexpr int off_state = off_ring + QS_COUNT * ring;
+  static constexpr int off_ring = off_ctl + QC_WORDS;  // NQ rings of `ring` dwords (id + 1, 0 = empty)
+  static constexpr int off_state = off_ring + NQ * ring;
   static constexpr int off_sobol = off_state + kQFields * CTX;
   static constexpr int off_win = off_sobol + kLdsSamplerDims * 256 / 4;
   static constexpr int off_stack = off_win + kQWinDwords * kQBlock;
   static constexpr size_t fixed_bytes = size_t(off_stack) * 4;
 };
 
-// per-context global record: the pixel's RNG state (2 x u64).  The sampler's per-pixel ranking and
-// scrambling bytes are read straight from the 256 KB tables (L2-resident, shared by every context).
-constexpr int kQCtxGlobalDwords = 4;
+// per-context global record (L2-resident): the pixel's RNG state (2 x u64); in the Subsurface variants also
+// the BSSRDF beta channel of every pending level (2 bits each, bxdf.cpp:335 / path.cpp:121) and the state
+// of a random walk in flight.  The sampler's per-pixel ranking and scrambling bytes are read straight from
+// the 256 KB tables (L2-resident, shared by every context).
+//   float4 0: RNG            1: beta flags lo, hi, -, -
+//   float4 2: walk ray origin (at exit: the exit point) | channel    3: walk direction | tmax    4: exit normal
+constexpr int kQCtxGlobalDwordsPlain = 4, kQCtxGlobalDwordsSss = 20;
+constexpr int q_ctx_global_dwords(unsigned F) { return (F & F_SSS) ? kQCtxGlobalDwordsSss : kQCtxGlobalDwordsPlain; }
 
-// Not instantiated with F_SSS: the BSSRDF beta channel per pending level is not carried by the
-// contexts (scenes with Subsurface materials run path_trace_kernel).  Everything else -- meshes, node
-// graphs, delta lights, the environment light -- is covered by the "all but SSS" variant.
+// Subsurface (F_SSS): the BSSRDF random walk (bxdf.cpp:329-353) is a stage of its own, W -- ONE free-flight
+// step per pass (closest hit inside the shape, exponential free flight, exit or uniform-sphere scatter), the
+// context re-queued between steps, so that a wave's 64 lanes are 64 walks in the same phase whatever their
+// lengths.  Stage S starts a walk (refraction into the shape, channel pick) and is entered a second time when
+// the walk has ended, with the exit point in the context's global record.
 template <unsigned F, int CTX = PINE_QCTX>
 __global__ void __launch_bounds__(kQBlock, kQBlock / 256)
 path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
-  using L = QLayout<CTX>;
+  constexpr int kNQ = (F & F_SSS) ? 3 : 2;
+  constexpr int kQCtxGlobalDwords = q_ctx_global_dwords(F);
+  using L = QLayout<CTX, kNQ>;
   constexpr int kQCtx = L::ctx, kQRing = L::ring, kQOffCtl = L::off_ctl, kQOffRing = L::off_ring, kQOffState = L::off_state,
                 kQOffSobol = L::off_sobol, kQOffWin = L::off_win, kQOffStack = L::off_stack;
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -114,7 +124,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   }
   // queues: every context starts "fresh" in the terminal queue (stage T hands out work items)
   if (tid < QC_WORDS) qctl[tid] = 0;
-  for (int i = tid; i < QS_COUNT * kQRing; i += kQBlock) ring[i] = 0;
+  for (int i = tid; i < kNQ * kQRing; i += kQBlock) ring[i] = 0;
   __syncthreads();
   for (int i = tid; i < kQCtx; i += kQBlock) {
     ring[QS_T * kQRing + i] = unsigned(i + 1);
@@ -145,6 +155,18 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if (to_s | to_t) {
       const unsigned slot = to_s ? unsigned(QS_S * kQRing) + ((base_s + unsigned(__popcll(ms & below))) & (kQRing - 1))
                                  : unsigned(QS_T * kQRing) + ((base_t + unsigned(__popcll(mt & below))) & (kQRing - 1));
+      __atomic_store_n(&ring[slot], unsigned(id + 1), __ATOMIC_RELAXED);
+    }
+  };
+  // the walk queue has its own tail word (F_SSS variants)
+  auto push_w = [&](bool to_w, int id) {
+    const unsigned long long mw = __ballot(to_w);
+    if (mw == 0) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&qctl[QC_TAIL + QS_W], unsigned(__popcll(mw)));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (to_w) {
+      const unsigned slot = unsigned(QS_W * kQRing) + ((base + unsigned(__popcll(mw & ((1ull << lane) - 1ull)))) & (kQRing - 1));
       __atomic_store_n(&ring[slot], unsigned(id + 1), __ATOMIC_RELAXED);
     }
   };
@@ -180,19 +202,19 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   // bounded-spin bail-out: record where, raise the workgroup's abort flag, leave
   auto bail = [&](unsigned code, unsigned a, unsigned b) {
     __atomic_store_n(&qctl[QC_ABORT], 1u, __ATOMIC_RELAXED);
-    atomicAdd(&counters->section_cycles[15], 1ull);
-    counters->section_cycles[12] = code;
-    counters->section_cycles[13] = a;
-    counters->section_cycles[14] = b;
+    atomicAdd(&counters->bail_count, 1ull);
+    counters->bail_code = code;
+    counters->bail_a = a;
+    counters->bail_b = b;
   };
 
-  unsigned main_trips = 0;
+  // (No cap on the number of trips: a trip that finds work retires at least one stage of one path, and the
+  // work of a launch is finite; the trips that find none are bounded in wall-clock time below.)
+  unsigned long long idle_since = 0;
+  if (W.debug_force_bail && blockIdx.x == 0 && tid == 0) bail(7, 0, 0);  // test hook: the host must report this launch as failed
+  __syncthreads();
   while (true) {
     SEC_MARK(10);  // push + busy release
-    if (++main_trips > (1u << 26)) {  // safety net: a wave never loops unboundedly
-      if (lane == 0) bail(5, main_trips, 0);
-      break;
-    }
     // ---------------- pick a stage: the fullest queue (lane 0 decides, result broadcast) ----------------
     // All lanes read the same control words (LDS broadcast) and the values are made wave-uniform
     // (readfirstlane), so the decision itself is scalar code; only the atomics run on lane 0.
@@ -202,16 +224,27 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     {
       auto uload = [&](int w) -> unsigned { return __builtin_amdgcn_readfirstlane(lds_load(&qctl[w])); };
       const unsigned h_s = uload(QC_HEAD + QS_S), h_t = uload(QC_HEAD + QS_T);  // heads first: heads and tails
+      unsigned h_w = 0;
+      if constexpr (F & F_SSS) h_w = uload(QC_HEAD + QS_W);
       const unsigned t_s = uload(QC_TAIL + QS_S), t_t = uload(QC_TAIL + QS_T);  // only grow, so a count can only be over-estimated
+      unsigned t_w = 0;
+      if constexpr (F & F_SSS) t_w = uload(QC_TAIL + QS_W);
       const unsigned busy = uload(QC_BUSY);
-      const unsigned cnt_s = t_s - h_s, cnt_t = t_t - h_t;
-      const int best = cnt_t > cnt_s ? QS_T : QS_S;
-      const unsigned cnt_best = cnt_t > cnt_s ? cnt_t : cnt_s;
+      const unsigned cnt_s = t_s - h_s, cnt_t = t_t - h_t, cnt_w = t_w - h_w;
+      int best = cnt_t > cnt_s ? QS_T : QS_S;
+      unsigned cnt_best = cnt_t > cnt_s ? cnt_t : cnt_s;
+      unsigned h_best = cnt_t > cnt_s ? h_t : h_s;
+      if constexpr (F & F_SSS)
+        if (cnt_w > cnt_best) {
+          best = QS_W;
+          cnt_best = cnt_w;
+          h_best = h_w;
+        }
       if (cnt_best >= 64u || (cnt_best > 0u && (busy == 0u || spins >= 8u))) {
         // count ourselves busy BEFORE taking items out of the queue, so that "all queues empty and
         // nobody busy" really means no work can appear any more (idle pollers never touch the
         // counter: two of them must not keep each other alive)
-        const unsigned h0 = cnt_t > cnt_s ? h_t : h_s;
+        const unsigned h0 = h_best;
         const unsigned want = cnt_best < 64u ? cnt_best : 64u;
         unsigned got = 0;
         if (lane == 0) {
@@ -225,7 +258,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           h = h0;
         }
       } else {
-        finished = cnt_s == 0u && cnt_t == 0u && busy == 0u;
+        finished = cnt_s == 0u && cnt_t == 0u && cnt_w == 0u && busy == 0u;
       }
     }
     if (__builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_ABORT])) != 0u) break;
@@ -233,10 +266,15 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       SEC_MARK(11);  // idle poll
       if (finished) break;
       spins++;
-      if (++idle_polls > kQSpinLimit) {
+      // idle bound in wall-clock time (100 MHz s_memrealtime), not in polls: other waves of the workgroup
+      // may legitimately keep the last long paths of a launch for seconds
+      const unsigned long long now = wall_clock64();
+      if (idle_polls++ == 0) idle_since = now;
+      if (now - idle_since > W.idle_budget_ticks) {
         if (lane == 0)
           bail(1, lds_load(&qctl[QC_BUSY]),
-               (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 16));
+               (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 12) |
+                   ((lds_load(&qctl[QC_TAIL + 2]) - lds_load(&qctl[QC_HEAD + 2])) << 24));
         break;
       }
       __builtin_amdgcn_s_sleep(4);
@@ -268,7 +306,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
     if (stage == QS_S) {
       // ================= shade a non-terminal vertex (path.cpp:91-120) =================
-      bool to_shade = false, to_term = false;
+      bool to_shade = false, to_term = false, to_walk = false;
       if (valid) {
         const f3 ray_o{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
         const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
@@ -365,66 +403,60 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           bx.roughness = pmax(mp.roughness, min_roughness);
           bx.ior = mp.ior;
         } else if (is_sss) {
-          const float fr = FrDielectric(dot(wi, it.n), mat->ior);
-          if (sampler_get1d<kSM>(T, sampler) < fr) {
-            bx.kind = BX_REFRACTIVE;
-            bx.roughness = pmax(mat->roughness, min_roughness);
-            bx.ior = mat->ior;
-          } else if (diffused) {
-            bx.kind = BX_DIFFUSE;
-          } else {
+          if (st.walk() != kWalkNone) {  // second entry, after the walk: the lobe was chosen (and its draw made) the first time
             bx.kind = BX_BSSRDF;
             bx.ior = mat->ior;
+          } else {
+            const float fr = FrDielectric(dot(wi, it.n), mat->ior);
+            if (sampler_get1d<kSM>(T, sampler) < fr) {
+              bx.kind = BX_REFRACTIVE;
+              bx.roughness = pmax(mp.roughness, min_roughness);
+              bx.ior = mat->ior;
+            } else if (diffused) {
+              bx.kind = BX_DIFFUSE;
+            } else {
+              bx.kind = BX_BSSRDF;
+              bx.ior = mat->ior;
+            }
           }
         }
         bx.wi = mul(w2l, wi);
+        // ---- BSSRDF random walk (bxdf.cpp:329-353, :375-382): started here, stepped by stage W ----
         int beta_channel = 0;
-        bool do_walk = false;
-        if constexpr (F & F_SSS) do_walk = bx.kind == BX_BSSRDF;
-        if (do_walk) {
-          f3 p = it.p;
-          f3 w = -wi;
-          if (Refract(wi, it.n, bx.ior, w, nullptr)) {
-            DRng g = rng_load();
-            const int channel = int(rng_nextf(g) * 3);
-            rng_store(g);
-            const float sigma_t_inv = 1 / mat->sigma_s[channel];
-            const f3 n0 = it.n;
-            for (int i = 0;; i++) {
-              DRay wr = i == 0 ? spawn_ray_raw(p, n0, w) : DRay{p, w, 0.0f, kFloatMax};
-              DSurface sit;
-              sit.p = sit.n = mk3(0.0f);
-              bool hh;
-              bool walk_mesh = false;
-              if constexpr (F & F_MESH) walk_mesh = shape->kind == SHAPE_MESH;
-              if (walk_mesh) {
-                const DRayOct oct = make_oct(wr);
-                int wprim = 0;
-                hh = mesh_traverse<false, kQBlock>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
-                if (hh) tri_surface_info(V.tri_verts + size_t(wprim) * 9, ray_at(wr, wr.tmax), sit);
-              } else {
-                hh = shape_intersect<F>(shape, wr);
-              }
-              if (!hh) break;
-              const float t = -plog(1 - sampler_get1d<kSM>(T, sampler)) * sigma_t_inv;
-              if (wr.tmax < t) {
-                beta_channel = channel + 1;
-                it.p = sit.p;
-                it.n = sit.n;
-                l2w = coordinate_system(it.n);
-                w2l = transpose(l2w);
-                bx.wi = mul(w2l, -w);
-                break;
-              }
-              p = ray_at(wr, t);
-              w = uniform_sphere(sampler_get2d<kSM>(T, sampler));
-            }
+        bool start_walk = false;
+        if constexpr (F & F_SSS) {
+          if (bx.kind == BX_BSSRDF) {
+            float4* const cg4 = reinterpret_cast<float4*>(cg);
+            if (st.walk() == kWalkNone) {
+              f3 w = -wi;
+              if (Refract(wi, it.n, bx.ior, w, nullptr)) {
+                DRng g = rng_load();
+                const int channel = int(rng_nextf(g) * 3);
+                rng_store(g);
+                const DRay wr = spawn_ray_raw(it.p, it.n, w);  // (later steps start AT the scattering point, with tmax = float max)
+                cg4[2] = make_float4(wr.o.x, wr.o.y, wr.o.z, __int_as_float(channel));
+                cg4[3] = make_float4(wr.d.x, wr.d.y, wr.d.z, wr.tmax);
+                st.set_dim(sampler.dimension);
+                st.set_walk(kWalkRunning);
+                cstu[CF_ST * kQCtx + id] = st.v;
+                start_walk = true;
+              }  // else sample_p returns nullopt: nothing changes, the vertex is shaded where it was hit
+            } else if (st.walk() == kWalkExited) {
+              // the walk left the shape: bc.it.p / n move to the exit point, wi becomes the reversed last walk direction
+              const float4 a = cg4[2], b = cg4[3], c = cg4[4];
+              beta_channel = __float_as_int(a.w) + 1;
+              it.p = f3{a.x, a.y, a.z};
+              it.n = f3{c.x, c.y, c.z};
+              l2w = coordinate_system(it.n);
+              w2l = transpose(l2w);
+              bx.wi = mul(w2l, -f3{b.x, b.y, b.z});
+            }  // kWalkFailed: a walk ray found no surface (sample_p returns nullopt): nothing changes
           }
         }
         SEC_MARK(1);  // S: state load, surface, frame, material
         // ---- next-event estimation (path.cpp:98-113) ----
         f3 nee = mk3(0.0f);
-        if (!bxdf_is_delta<F>(bx)) {
+        if (!start_walk && !bxdf_is_delta<F>(bx)) {
           const f2 u2 = sampler_get2d<kSM>(T, sampler);  // g++ order: get2d first (lightsampler.h:27)
           float u1 = sampler_get1d<kSM>(T, sampler);
           if constexpr (F & F_LIGHTS) {
@@ -505,12 +537,18 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         bx.albedo = mp.albedo;
         bx.albedo_over_pi = mp.albedo_over_pi;
         DBsdfSample bs;
-        if (bxdf_sample<F, kSM>(bx, T, sampler, bs)) {
+        if (start_walk) {
+          to_walk = true;  // (state stored above; the context continues in stage W)
+        } else if (bxdf_sample<F, kSM>(bx, T, sampler, bs)) {
           const f3 wo_world = mul(l2w, bs.wo);
           const float cosine = absdot(wo_world, it.n);
           float4* q = fold_entry(id, pv_length);
           q[0] = make_float4(nee.x, nee.y, nee.z, bs.f.x);
           q[1] = make_float4(bs.f.y, bs.f.z, cosine / bs.pdf, bs.pdf);
+          if constexpr (F & F_SSS) {  // this level's BSSRDF beta channel (0 = none): 2 bits in the context's global record
+            const int word = pv_length >> 4, sh = 2 * (pv_length & 15);
+            cg[4 + word] = (cg[4 + word] & ~(3u << sh)) | (unsigned(beta_channel) << sh);
+          }
           const DRay nr = spawn_ray(it.p, it.n, wo_world, kFloatMax);
           st.set_dim(sampler.dimension);
           st.next_vertex(bs.is_delta);
@@ -533,6 +571,66 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       SEC_MARK(9);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       push2(to_shade, to_term, id);
+      if constexpr (F & F_SSS) push_w(to_walk, id);
+    } else if ((F & F_SSS) != 0 && stage == QS_W) {
+      // ================= one step of a BSSRDF random walk (bxdf.cpp:340-351) =================
+      bool to_walk = false, to_shade = false;
+      if constexpr (F & F_SSS) {
+        if (valid) {
+          float4* const cg4 = reinterpret_cast<float4*>(ctx_global(id));
+          const float4 a = cg4[2], b = cg4[3];
+          PackedState st{cstu[CF_ST * kQCtx + id]};
+          const unsigned pxy = cstu[CF_PXY * kQCtx + id];
+          const DShape* shape = &V.shapes[int(cstu[CF_GEOM * kQCtx + id]) & kPrimIndexMask];
+          const DMaterial* mat = &V.materials[shape->material];
+          const int channel = __float_as_int(a.w);
+          DRay wr{f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, 0.0f, b.w};
+          DSampler sampler;
+          sampler.px = int(pxy & 0xffffu);
+          sampler.py = int(pxy >> 16);
+          sampler.index = st.s_cur();
+          sampler.dimension = st.dim();
+          bool hh;
+          int wprim = 0;
+          bool walk_mesh = false;
+          if constexpr (F & F_MESH) walk_mesh = shape->kind == SHAPE_MESH;
+          if (walk_mesh) {
+            const DRayOct oct = make_oct(wr);
+            hh = mesh_traverse<false, kQBlock>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
+          } else {
+            hh = shape_intersect<F>(shape, wr);
+          }
+          SEC_MARK(12);  // W: closest hit inside the shape
+          if (!hh) {  // sample_p returns nullopt
+            st.set_walk(kWalkFailed);
+            to_shade = true;
+          } else {
+            const float t = -plog(1 - sampler_get1d<0>(S.tables, sampler)) * (1 / mat->sigma_s[channel]);
+            if (wr.tmax < t) {
+              // leaves the shape here: Shape::intersect filled it.p / it.n for meshes only
+              DSurface sit;
+              sit.p = sit.n = mk3(0.0f);
+              if (walk_mesh) tri_surface_info(V.tri_verts + size_t(wprim) * 9, ray_at(wr, wr.tmax), sit);
+              cg4[2] = make_float4(sit.p.x, sit.p.y, sit.p.z, a.w);
+              cg4[4] = make_float4(sit.n.x, sit.n.y, sit.n.z, 0.0f);
+              st.set_walk(kWalkExited);
+              to_shade = true;
+            } else {
+              const f3 p = ray_at(wr, t);
+              const f3 w = uniform_sphere(sampler_get2d<0>(S.tables, sampler));
+              cg4[2] = make_float4(p.x, p.y, p.z, a.w);
+              cg4[3] = make_float4(w.x, w.y, w.z, kFloatMax);
+              to_walk = true;
+            }
+          }
+          st.set_dim(sampler.dimension);
+          cstu[CF_ST * kQCtx + id] = st.v;
+        }
+      }
+      SEC_MARK(13);  // W: free flight, scatter / exit, state store
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      push2(to_shade, false, id);
+      push_w(to_walk, id);
     } else {
       // ================= terminal: result, backward fold, store, next sample / item =================
       bool need_item = false, have_path = false;
@@ -593,19 +691,32 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           }
           // backward fold (path.cpp:114-121)
           f3 Li = Lo;
-          auto fold_step = [&](const float4& a, const float4& b) {
+          unsigned long long beta_flags = 0;  // 2 bits per level: the BSSRDF beta channel (bxdf.cpp:335), dead code without F_SSS
+          if constexpr (F & F_SSS) {
+            const uint2 bf = *reinterpret_cast<const uint2*>(ctx_global(id) + 4);
+            beta_flags = (unsigned long long)bf.x | ((unsigned long long)bf.y << 32);
+          }
+          auto fold_step = [&](const float4& a, const float4& b, int level) {
             const f3 e_nee{a.x, a.y, a.z};
             const f3 e_f{a.w, b.x, b.y};
             const float e_cp = b.z, e_pdf = b.w;
             const float mis = lp_valid ? balance_heuristic(e_pdf, lp) : 1.0f;
             const f3 lo = e_nee + Li * e_f * (e_cp * mis);
-            Li = mk3(0.0f) + vmin(mk3(1.0f) * mk3(1.0f) * lo, mk3(8.0f));
+            f3 beta = mk3(1.0f);
+            if constexpr (F & F_SSS) {
+              const unsigned bc = unsigned(beta_flags >> (2 * level)) & 3u;
+              if (bc) {
+                beta = mk3(0.0f);
+                set(beta, int(bc) - 1, 3.0f);
+              }
+            }
+            Li = mk3(0.0f) + vmin(mk3(1.0f) * beta * lo, mk3(8.0f));
             lp_valid = false;
           };
           int level = pv_length - 1;
           for (; level >= 0; level--) {
             const float4* q = fold_entry(id, level);
-            fold_step(q[0], q[1]);
+            fold_step(q[0], q[1], level);
           }
           const int s_now = st.s_cur();
           sample_base = cstu[CF_SBASE * kQCtx + id];
@@ -646,6 +757,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             if (b >= W.total_items) {
               __atomic_store_n(&qctl[QC_EXHAUSTED], 1u, __ATOMIC_RELAXED);
             } else {
+              post_progress(W, b, 9);
               nx = b;
               en = b + kQPoolItems < W.total_items ? b + kQPoolItems : W.total_items;
             }

@@ -463,3 +463,62 @@ def test_c2_full_size_whole_image_md5_and_properties():
         f, _ = _render(sc, 256, 8, shard_rank=r, shard_world=2)
         tot += f
     assert_bit_equal(tot, film, "2 shards at full size")
+
+
+def test_kernel_bail_out_is_reported_by_every_entry_point(path_kernel):
+    """A protocol failure of the stage-queued kernel (bounded wait ran out) leaves an incomplete film: the
+    one-shot render, stats_get and plan_check must all FAIL with the bail-out code, never return that film.
+    PINE_GPU_FLAG_DEBUG_FORCE_BAIL raises the bail-out deterministically; the next ordinary launch is clean."""
+    import torch
+    import pine_amd as pa
+    from pine_amd import scenes, _lib
+    if path_kernel == "mega":
+        pytest.skip("the lane-owns-a-path kernel has no waits to bail out of")
+    sc = scenes.cbox((64, 64), "readme")
+    with pytest.raises(pa.PineError, match="bailed out.*code 7"):
+        pa.PathIntegrator(pa.BlueSampler(8), 4, flags=_lib.FLAG_DEBUG_FORCE_BAIL).render(sc)
+    plan = pa.Plan(sc, 8, 4, flags=_lib.FLAG_DEBUG_FORCE_BAIL)
+    film = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
+    plan.launch(film.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(pa.PineError, match="bailed out"):
+        plan.check()
+    with pytest.raises(pa.PineError, match="bailed out"):
+        plan.stats()
+    plan.close()
+    good = pa.Plan(sc, 8, 4)
+    good.launch(film.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    good.check()
+    ref = pa.PathIntegrator(pa.BlueSampler(8), 4).render(sc).pixels
+    assert_bit_equal(film.cpu().numpy(), ref, "launch after a bailed-out one")
+    good.close()
+
+
+def test_subsurface_runs_on_the_stage_queued_kernel(path_kernel):
+    """Subsurface scenes take the stage-queued kernel (walk stage W) by default: 1024-thread workgroups; the
+    film equals the megakernel's and the oracle's bit for bit (mesh walk; sphere walk, whose exit point is the
+    reference's zero vector -- SURVEY.md Appendix A5; a textured skin evaluated at the ENTRY point)."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    from oracle import oracle
+    cases = [scenes.sss((40, 40), 1), scenes.sss((40, 40), 2, skin=pa.Subsurface([0.9, 0.6, 0.4], 0.3, [12.0, 25.0, 40.0]))]
+    sph = scenes.cbox((36, 36), "readme", boxes=False)
+    sph.add("skin", pa.Subsurface([0.8, 0.8, 0.7], 0.2, [30.0, 30.0, 30.0]))
+    sph.add(pa.Sphere([0.1, 0.5, 1.0], 0.4), "skin")
+    cases.append(sph)
+    for i, sc in enumerate(cases):
+        w, h = sc.camera.film().size
+        f, st = _render(sc, 16, 8)
+        assert st.block_threads == (256 if path_kernel == "mega" else 1024)
+        assert st.samples_per_item == st.spp_effective  # in-path RNG draws: a pixel's samples stay sequential
+        ref, _ = oracle.render(sc.describe(), (w, h), 16, 8)
+        assert_bit_equal(f, ref, f"subsurface case {i} ({path_kernel})")
+
+
+def test_plan_limits_are_errors_not_wraparound():
+    """Pixel coordinates travel as 16 + 16 bits and a context's sample-buffer index as 32 bits: larger renders are refused."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    with pytest.raises(pa.PineError, match="65535"):
+        pa.Plan(scenes.cbox((70000, 8)), 1, 2)
+    with pytest.raises(pa.PineError, match="2\\^32"):
+        pa.Plan(scenes.cbox((4096, 4096)), pa.SobolSampler(512), 2)
