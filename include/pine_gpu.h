@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PINE_GPU_ABI_VERSION 1
+#define PINE_GPU_ABI_VERSION 2
 
 typedef struct pine_gpu_scene pine_gpu_scene; /* replaces pine::Scene, src/pine/core/scene.h:14-43 */
 typedef struct pine_gpu_plan pine_gpu_plan;   /* a PathIntegrator bound to a scene + device state */
@@ -230,6 +230,9 @@ typedef struct {
   int32_t block_threads;
   int32_t lds_bytes;
   int32_t timed_launches;    /* number of launches the three timings are averaged over        */
+  uint64_t walk_steps;       /* BSSRDF random-walk steps of the last launch (bxdf.cpp:340-351; stage-queued kernel) */
+  float accel_build_ms;      /* host: BVH build + flattening for this plan (0 if the scene's accel was already built) */
+  float upload_ms;           /* host: device allocation + upload of scene, tables and work buffers at plan creation  */
 } pine_gpu_plan_stats;
 /* Blocks until the last launch has finished (needed to read the device-side counters).  Fails (< 0) if the
  * path kernel of that launch bailed out of a bounded wait: its film is incomplete. */

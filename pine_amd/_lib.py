@@ -49,6 +49,9 @@ class PlanStats(C.Structure):
         ("block_threads", C.c_int32),
         ("lds_bytes", C.c_int32),
         ("timed_launches", C.c_int32),
+        ("walk_steps", C.c_uint64),
+        ("accel_build_ms", C.c_float),
+        ("upload_ms", C.c_float),
     ]
 
 

@@ -28,6 +28,8 @@ enum : unsigned {
   F_LIGHTS = 1u << 10,    // Point / Spot / Directional lights or an environment light are present
   F_XSHAPES = 1u << 11,   // Plane / Line / Cylinder / stand-alone Triangle
   F_SOBOL = 1u << 12,     // the sampler may be SobolSampler (DTables::kind) instead of BlueSampler
+  F_LDS_TOP = 1u << 13,   // scene in global memory, but the first DeviceScene::lds_nodes BVH nodes (breadth-first numbering:
+                          // the levels every ray visits) are staged in LDS, and the traversal stack holds 16-bit node ids
   F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES | F_SOBOL,
 };
 

@@ -560,6 +560,38 @@ DBvh build_one(std::vector<Prim> prims, std::vector<DNode>& nodes, std::vector<i
 }
 }  // namespace
 
+// Node numbering is free (the tree, its boxes and the stored primitive order are what the traversal's results
+// depend on): renumber level by level across the whole two-level structure -- the top-level BVH's root first, then
+// the mesh roots, then everybody's children in that order.  The nodes every ray visits get the lowest indices, which
+// the stage-queued kernel keeps in LDS (DeviceScene::lds_nodes); deeper down the two children of a node are
+// neighbours in memory, often in one 128-byte line.
+static void renumber_breadth_first(FlatAccel& A) {
+  const int n = int(A.nodes.size());
+  std::vector<int> order;  // new index -> old index
+  order.reserve(size_t(n));
+  for (auto& b : A.bvhs)
+    if (b.root_count == 0 && b.root >= 0) order.push_back(b.root);
+  for (size_t head = 0; head < order.size(); head++) {
+    const DNode& nd = A.nodes[size_t(order[head])];
+    for (int c = 0; c < 2; c++)
+      if (nd.count[c] == 0) order.push_back(nd.child[c]);
+  }
+  if (int(order.size()) != n) return;  // (cannot happen: every node hangs below exactly one root)
+  std::vector<int> new_of(size_t(n), -1);
+  for (int i = 0; i < n; i++) new_of[size_t(order[size_t(i)])] = i;
+  std::vector<DNode> nodes;
+  nodes.resize(size_t(n));
+  for (int i = 0; i < n; i++) {
+    DNode nd = A.nodes[size_t(order[size_t(i)])];
+    for (int c = 0; c < 2; c++)
+      if (nd.count[c] == 0) nd.child[c] = new_of[size_t(nd.child[c])];
+    nodes[size_t(i)] = nd;
+  }
+  A.nodes.swap(nodes);
+  for (auto& b : A.bvhs)
+    if (b.root_count == 0 && b.root >= 0) b.root = new_of[size_t(b.root)];
+}
+
 void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
   accel = FlatAccel();
   accel.bvhs.push_back(DBvh{-1, 0, 0, 0});  // slot 0 = top level, filled below
@@ -609,6 +641,31 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
   }
   accel.top_prim_begin = int(accel.prims.size());
   if (!top.empty()) accel.bvhs[0] = build_one(std::move(top), accel.nodes, accel.prims, 0, nullptr);
+  renumber_breadth_first(accel);
+  // leaf-ordered triangle records for the device (FlatAccel::tri_leaf)
+  accel.tri_leaf.assign(size_t(accel.top_prim_begin) * 12, 0.0f);
+  for (size_t b = 1; b < accel.bvhs.size(); b++) {
+    // the prims entries of mesh BVH b are those between its predecessor's and its own end: walk its nodes instead
+    std::vector<int> todo;
+    auto emit = [&](int start, int count) {
+      for (int i = start; i < start + count; i++) {
+        const int tri = accel.prims[size_t(i)] + accel.bvhs[b].prim_base;
+        float* r = &accel.tri_leaf[size_t(i) * 12];
+        memcpy(r, &accel.tri_verts[size_t(tri) * 9], 36);
+        memcpy(r + 9, &tri, 4);
+      }
+    };
+    if (accel.bvhs[b].root_count > 0) emit(accel.bvhs[b].root_start, accel.bvhs[b].root_count);
+    else todo.push_back(accel.bvhs[b].root);
+    while (!todo.empty()) {
+      const DNode nd = accel.nodes[size_t(todo.back())];
+      todo.pop_back();
+      for (int c = 0; c < 2; c++) {
+        if (nd.count[c] > 0) emit(nd.child[c], nd.count[c]);
+        else todo.push_back(nd.child[c]);
+      }
+    }
+  }
   accel.built = true;
 }
 

@@ -70,6 +70,10 @@ struct FlatAccel {
   int top_prim_begin = 0;  // prims[top_prim_begin ..) belong to the top-level BVH
   std::vector<DBvh> bvhs;  // [0] = top level, then one per mesh in lbvh order
   std::vector<float> tri_verts;    // all meshes: 9 floats per triangle (v0,v1,v2), mesh after mesh
+  // device traversal copy: 12 floats per entry of `prims` (mesh entries only): v0,v1,v2, the triangle's index into
+  // tri_verts (as int bits), 2 pad -- in LEAF order and 16-byte aligned, so that a leaf's triangles are consecutive
+  // 48-byte records read with three wide loads, without the prims[i] -> triangle indirection
+  std::vector<float> tri_leaf;
   bool built = false;
 };
 

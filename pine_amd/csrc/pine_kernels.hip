@@ -27,6 +27,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <dlfcn.h>
@@ -110,6 +111,8 @@ struct DeviceScene {
   int blob_bytes;
   int off_nodes, off_shapes, off_materials, off_bvhs, off_prims, off_lights, off_node_ops, off_leaf;  // byte offsets in the blob
   int top_prim_begin;  // prims[top_prim_begin ..) are the top-level BVH's entries
+  const float4* tri_leaf;  // mesh triangles in leaf order, 3 float4 per entry of `prims` (FlatAccel::tri_leaf)
+  int lds_nodes;           // F_LDS_TOP variants: nodes[0 .. lds_nodes) are copied to LDS by every workgroup
 };
 
 // What the traversal and shading code reads.  In the F_LDS_SCENE specialisation every pointer is
@@ -131,7 +134,34 @@ struct SceneView {
   const DNodeOp* node_ops;
   int stack_top;
   int num_shapes;
+  const float4* tri_leaf;
+  const DNode* lds_nodes;  // F_LDS_TOP: the workgroup's LDS copy of nodes[0 .. lds_node_count)
+  int lds_node_count;
 };
+
+// One BVH node into registers.  F_LDS_TOP: from the workgroup's LDS copy when the index is below the cached
+// count (four ds_read_b128), else from global memory (four global_load_dwordx4).  The LDS arm goes through an
+// address_space(3) pointer: with two generic pointers the compiler folds the branch into a pointer select and
+// emits flat loads, which occupy both memory pipes.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+template <unsigned F>
+__device__ __forceinline__ DNode fetch_node(const SceneView& S, int index) {
+  union {
+    DNode n;
+    u32x4 q[4];
+  } b;
+  if constexpr (F & F_LDS_TOP) {
+    if (index < S.lds_node_count) {
+      lds_u32x4* p = (lds_u32x4*)(S.lds_nodes) + size_t(index) * 4;
+      b.q[0] = p[0], b.q[1] = p[1], b.q[2] = p[2], b.q[3] = p[3];
+      return b.n;
+    }
+  }
+  const u32x4* g = reinterpret_cast<const u32x4*>(S.nodes + index);
+  b.q[0] = g[0], b.q[1] = g[1], b.q[2] = g[2], b.q[3] = g[3];
+  return b.n;
+}
 
 struct WorkParams {
   int tiles_x, tiles_y;
@@ -158,19 +188,21 @@ __device__ __forceinline__ void post_progress(const WorkParams& W, unsigned long
 // tested inline in stored primitive order, nearer-exit child first.  The stack lives in LDS,
 // lane-interleaved ([slot][thread]) so pushes/pops are bank-conflict free.
 // ------------------------------------------------------------------------------------------------
-template <bool ANY, int STRIDE = kBlock>
+template <bool ANY, int STRIDE = kBlock, unsigned F = 0, class StackT = int>
 __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh, DRay& ray,
-                                              const DRayOct& oct, int* stack, int sp0, int& prim_out) {
+                                              const DRayOct& oct, StackT* stack, int sp0, int& prim_out) {
   bool hit = false;
   auto leaf = [&](int start, int count) -> bool {
     for (int i = start; i < start + count; i++) {
-      const int tri = S.prims[i] + bvh.prim_base;
-      const float* v = S.tri_verts + size_t(tri) * 9;
+      // leaf-ordered 48-byte record: v0 v1 v2 | triangle index (FlatAccel::tri_leaf)
+      const float4* rec = S.tri_leaf + size_t(i) * 3;
+      const float4 a = rec[0], b = rec[1], c = rec[2];
+      const float v[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
       if (ANY) {
         if (tri_hit(v, ray)) return true;
       } else if (tri_intersect(v, ray)) {
         hit = true;
-        prim_out = tri;
+        prim_out = __float_as_int(c.y);
       }
     }
     return false;
@@ -182,7 +214,12 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
   int sp = sp0;
   int next = bvh.root;
   while (true) {
+    DNode nd_mesh;
     const DNode* node = &S.nodes[next];
+    if constexpr (F & F_LDS_TOP) {
+      nd_mesh = fetch_node<F>(S, next);
+      node = &nd_mesh;
+    }
     int l = -1, r = -1;
     float t0 = ray.tmax, t1 = ray.tmax;
     if (box_hit_oct(node->lo0, node->hi0, oct, ray.tmin, t0)) {
@@ -196,10 +233,10 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
     if (l != -1) {
       if (r != -1) {
         if (t0 > t1) {
-          stack[sp * STRIDE] = l;
+          stack[sp * STRIDE] = StackT(l);
           next = r;
         } else {
-          stack[sp * STRIDE] = r;
+          stack[sp * STRIDE] = StackT(r);
           next = l;
         }
         sp++;
@@ -207,7 +244,7 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
     } else if (r != -1) next = r;
     else {
       if (sp == sp0) break;
-      next = stack[(--sp) * STRIDE];
+      next = int(stack[(--sp) * STRIDE]);
     }
   }
   return hit;
@@ -216,8 +253,8 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
 // ANY: BVH::hit (bvh.cpp:497-511).  !ANY: BVH::intersect (bvh.cpp:513-548) minus the final
 // compute_surface_info, which the caller does once for the winning primitive.
 // geom_out receives the winning primitive's PACKED word (index | emissive bit | kind).
-template <bool ANY, unsigned F, int STRIDE = kBlock>
-__device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, int* stack, int& geom_out,
+template <bool ANY, unsigned F, int STRIDE = kBlock, class StackT = int>
+__device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, StackT* stack, int& geom_out,
                                                int& prim_out) {
   if (S.num_shapes == 0) return false;
   const DRayOct oct = make_oct(ray);
@@ -235,7 +272,7 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
         if constexpr (F & F_MESH) {
           const DBvh mb = S.bvhs[as_int(sh->f[2])];
           int prim = 0;
-          const bool h = mesh_traverse<ANY, STRIDE>(S, mb, ray, oct, stack, S.stack_top, prim);
+          const bool h = mesh_traverse<ANY, STRIDE, F>(S, mb, ray, oct, stack, S.stack_top, prim);
           if (ANY) {
             if (h) return true;
           } else if (h) {
@@ -274,7 +311,12 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
   int next = top.root;
   while (true) {
     REGION(ANY ? 4 : 1);  // top-level node visit
+    DNode nd_top;
     const DNode* node = &S.nodes[next];
+    if constexpr (F & F_LDS_TOP) {
+      nd_top = fetch_node<F>(S, next);
+      node = &nd_top;
+    }
     int l = -1, r = -1;
     float t0 = ray.tmax, t1 = ray.tmax;
 #ifdef PINE_DUP_NODES
@@ -298,10 +340,10 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
     if (l != -1) {
       if (r != -1) {
         if (t0 > t1) {
-          stack[sp * STRIDE] = l;
+          stack[sp * STRIDE] = StackT(l);
           next = r;
         } else {
-          stack[sp * STRIDE] = r;
+          stack[sp * STRIDE] = StackT(r);
           next = l;
         }
         sp++;
@@ -309,7 +351,7 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, in
     } else if (r != -1) next = r;
     else {
       if (sp == 0) break;
-      next = stack[(--sp) * STRIDE];
+      next = int(stack[(--sp) * STRIDE]);
     }
   }
   return hit;
@@ -383,7 +425,7 @@ struct Counters {
   // that synchronises (plan_check): a launch with bail_count != 0 has an incomplete film and FAILS.
   unsigned long long bail_count;
   unsigned long long bail_code, bail_a, bail_b;
-  unsigned long long pad;
+  unsigned long long walk_steps;  // BSSRDF random-walk steps (stage-queued kernel, F_SSS variants)
   unsigned long long section_cycles[16];  // diagnostic builds (-DPINE_PROFILE_SECTIONS) only
 };
 
@@ -459,6 +501,9 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   T.win_len = kLdsSamplerDims;
   SceneView V;
   V.tri_verts = S.tri_verts;
+  V.tri_leaf = S.tri_leaf;
+  V.lds_nodes = nullptr;
+  V.lds_node_count = 0;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
   if constexpr (F & F_LDS_SCENE) {
@@ -966,16 +1011,19 @@ static const QueueVariant kQueueVariants[] = {
     PINE_QV(kFBoxes | F_LDS_SCENE, PINE_QCTX, "queue: rect+box/diffuse, scene in LDS"),
 #ifndef PINE_ONLY_CBOX_VARIANT
     PINE_QV(kFAnalytic | F_LDS_SCENE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS"),
-    PINE_QV(kFAnalytic, PINE_QCTX, "queue: analytic shapes/uber"),
-    // the same analytic feature set with 1024 contexts, for BVHs whose traversal stack (4 KB of LDS per slot)
-    // leaves no room for 1536 (the 10 000-cone scene: depth 16)
-    PINE_QV(F_SPHERE | F_DISK | F_CONE | F_UBER, 1024, "queue: rect+sphere+disk+cone/uber, 1024 contexts (classic.pine's kinds exactly)"),
-    PINE_QV(kFAnalytic, 1024, "queue: analytic shapes/uber, 1024 contexts (deep BVH)"),
-    // everything except Subsurface (meshes, node-graph materials, every light kind); 1024 contexts so that
-    // a deep traversal stack (4 KB of LDS per slot, two BVH levels for meshes) fits
-    PINE_QV((F_ALL & ~F_SSS), 1024, "queue: all but SSS, 1024 contexts (deep BVH)"),
+    // scenes that do not fit LDS whole: the top of the BVH (breadth-first numbering) is cached in whatever LDS the
+    // contexts and the 16-bit traversal stack leave (F_LDS_TOP)
+    PINE_QV(kFAnalytic | F_LDS_TOP, PINE_QCTX, "queue: analytic shapes/uber, BVH top in LDS"),
+    // the same analytic feature set with 1024 contexts, for BVHs whose traversal stack (2 KB of LDS per slot)
+    // leaves no room for 1536 (the 10 000-cone scene: depth 15)
+    PINE_QV(F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP, 1024, "queue: rect+sphere+disk+cone/uber, 1024 contexts, BVH top in LDS (classic.pine's kinds exactly)"),
+    PINE_QV(kFAnalytic | F_LDS_TOP, 1024, "queue: analytic shapes/uber, 1024 contexts, BVH top in LDS"),
+    // everything except Subsurface (meshes, node-graph materials, every light kind)
+    PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP, 1024, "queue: all but SSS, 1024 contexts, BVH top in LDS"),
     // Subsurface: the BSSRDF random walk is a third stage (W) with its own queue
-    PINE_QV(F_MESH | F_SSS, 1024, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts"),
+    PINE_QV(F_MESH | F_SSS | F_LDS_TOP, 1024, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top in LDS"),
+    PINE_QV(F_ALL | F_LDS_TOP, 1024, "queue: all features, walk stage, 1024 contexts, BVH top in LDS"),
+    // BVHs of 65 536 nodes and more: 32-bit traversal stack, no node cache
     PINE_QV(F_ALL, 1024, "queue: all features, walk stage, 1024 contexts"),
 #endif
 };
@@ -1236,6 +1284,7 @@ struct pine_gpu_plan {
   // device buffers
   char* d_blob = nullptr;  // nodes | shapes | materials | bvhs | prims | lights
   float* d_tri = nullptr;
+  float* d_tri_leaf = nullptr;
   uint8_t* d_tables = nullptr;
   int variant = -1;
   int queue_variant = -1;   // >= 0: the stage-queued kernel is used instead of path_trace_kernel
@@ -1257,6 +1306,7 @@ struct pine_gpu_plan {
   bool launched = false;
   hipStream_t last_stream = nullptr;
   unsigned long long* h_progress = nullptr;  // host-mapped progress word (PINE_GPU_FLAG_PROGRESS)
+  float accel_build_ms = 0.0f, upload_ms = 0.0f;  // host-side cost of plan creation (reported by stats_get)
 };
 
 static int plan_check_counters(const Counters& c) {
@@ -1314,6 +1364,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_blob);
   (void)hipFree(p->d_tri);
+  (void)hipFree(p->d_tri_leaf);
   (void)hipFree(p->d_tables);
   (void)hipFree(p->d_ctxg);
   (void)hipFree(p->d_ckpt);
@@ -1372,7 +1423,10 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   HIP_OK(hipSetDevice(prm->device));
   p->device = prm->device;
   p->params = *prm;
+  const auto t_build0 = std::chrono::steady_clock::now();
   if (!H.accel.built) H.build_accel();
+  const auto t_build1 = std::chrono::steady_clock::now();
+  p->accel_build_ms = std::chrono::duration<float, std::milli>(t_build1 - t_build0).count();
   const FlatAccel& A = H.accel;
 
   std::vector<DShape> shapes;
@@ -1421,6 +1475,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   HIP_OK(hipMalloc((void**)&p->d_blob, blob.size()));
   HIP_OK(hipMemcpy(p->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (upload(p->d_tri, A.tri_verts)) return -1;
+  if (upload(p->d_tri_leaf, A.tri_leaf)) return -1;
   // tables: sobol + the selected spp variant
   int k = 0;
   while ((1 << k) < spp) k++;
@@ -1446,6 +1501,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.lights = reinterpret_cast<const DLight*>(p->d_blob + S.off_lights);
   S.node_ops = reinterpret_cast<const DNodeOp*>(p->d_blob + S.off_node_ops);
   S.tri_verts = p->d_tri;
+  S.tri_leaf = reinterpret_cast<const float4*>(p->d_tri_leaf);
+  S.lds_nodes = 0;
   S.num_lights = int(light_list.size());
   S.env_light = H.has_env ? int(light_list.size()) - 1 : -1;
   S.num_shapes = int(shapes.size());
@@ -1538,15 +1595,23 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     const char* ksel = getenv("PINE_GPU_KERNEL");
     const bool want_queue = !(ksel && std::string(ksel) == "mega");
     if (want_queue) {
+      const char* no_top = getenv("PINE_GPU_NO_LDS_TOP");  // (measurement aid: keep every node in global memory)
       for (int v = 0; v < kNumQueueVariants; v++) {
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
         if ((F & F_LDS_SCENE) && !lds_ok) continue;  // (a scene-in-global variant later in the table is the fallback when LDS is short)
-        const size_t lds = kQueueVariants[v].fixed_lds + size_t(S.stack_total) * kQBlock * sizeof(int) +
-                           ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0);
+        if ((F & F_LDS_TOP) && A.nodes.size() > 65535) continue;  // 16-bit stack entries
+        const size_t stack_bytes = size_t(S.stack_total) * kQBlock * ((F & F_LDS_TOP) ? sizeof(unsigned short) : sizeof(int));
+        const size_t lds = kQueueVariants[v].fixed_lds + stack_bytes + ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0);
         if (lds > 160 * 1024) continue;
         p->queue_variant = v;
         p->lds_bytes = lds;
+        S.lds_nodes = 0;
+        if (F & F_LDS_TOP) {
+          S.lds_nodes = int(std::min<size_t>(A.nodes.size(), (160 * 1024 - lds) / sizeof(DNode)));
+          if (no_top) S.lds_nodes = 0;
+          p->lds_bytes += size_t(S.lds_nodes) * sizeof(DNode);
+        }
         break;
       }
     }
@@ -1644,6 +1709,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (p->timed)
     for (auto& slot : p->ev)
       for (auto& e : slot) HIP_OK(hipEventCreate(&e));
+  HIP_OK(hipDeviceSynchronize());
+  p->upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build1).count();
   return 0;
 }
 
@@ -1765,6 +1832,8 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   out->grid_blocks = p->grid;
   out->block_threads = p->queue_variant >= 0 ? kQBlock : kBlock;
   out->lds_bytes = int(p->lds_bytes);
+  out->accel_build_ms = p->accel_build_ms;
+  out->upload_ms = p->upload_ms;
   if (p->launched) {
     HIP_OK(hipStreamSynchronize(p->last_stream));
     Counters c;
@@ -1772,6 +1841,7 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
     if (plan_check_counters(c)) return -1;
     out->vertices = c.vertices;
     out->shadow_rays = c.shadow_rays;
+    out->walk_steps = c.walk_steps;
     if (p->timed) {
       // mean over the launches since the previous read (at most the last kEvRing of them)
       unsigned long long first = p->stats_read_upto;

@@ -87,7 +87,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   unsigned* const ring = reinterpret_cast<unsigned*>(lds_raw + kQOffRing);
   float* const cstf = reinterpret_cast<float*>(lds_raw + kQOffState);
   unsigned* const cstu = reinterpret_cast<unsigned*>(lds_raw + kQOffState);
-  int* const stack = lds_raw + kQOffStack + tid;
+  // traversal stack: [slot][thread]; 16-bit node ids in the F_LDS_TOP variants (the host guarantees < 65536 nodes)
+  using StackT = typename std::conditional<(F & F_LDS_TOP) != 0, unsigned short, int>::type;
+  StackT* const stack = reinterpret_cast<StackT*>(lds_raw + kQOffStack) + tid;
 
   // ---- one-time staging ----
   {
@@ -97,9 +99,22 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   }
   SceneView V;
   V.tri_verts = S.tri_verts;
+  V.tri_leaf = S.tri_leaf;
+  V.lds_nodes = nullptr;
+  V.lds_node_count = 0;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
+  if constexpr (F & F_LDS_TOP) {
+    // the first S.lds_nodes nodes (breadth-first numbering: the top levels of the top-level BVH and of the mesh
+    // BVHs) live in LDS behind the traversal stack
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds_raw + kQOffStack) + size_t(S.stack_total) * kQBlock * sizeof(StackT));
+    const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
+    for (int i = tid; i < S.lds_nodes * 4; i += kQBlock) dst[i] = src[i];
+    V.lds_nodes = reinterpret_cast<const DNode*>(dst);
+    V.lds_node_count = S.lds_nodes;
+  }
   if constexpr (F & F_LDS_SCENE) {
+    static_assert(!(F & F_LDS_TOP), "F_LDS_SCENE already has every node in LDS");
     uint4* dst = reinterpret_cast<uint4*>(lds_raw + kQOffStack + S.stack_total * kQBlock);
     const int n16 = S.blob_bytes >> 4;
     for (int i = tid; i < n16; i += kQBlock) dst[i] = S.blob[i];
@@ -196,7 +211,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     to_term = terminal;
   };
 
-  unsigned shadow_count = 0;
+  unsigned shadow_count = 0, walk_count = 0;
   unsigned spins = 0;
   unsigned idle_polls = 0;
   // bounded-spin bail-out: record where, raise the workgroup's abort flag, leave
@@ -585,6 +600,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           const DMaterial* mat = &V.materials[shape->material];
           const int channel = __float_as_int(a.w);
           DRay wr{f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, 0.0f, b.w};
+          walk_count++;
           DSampler sampler;
           sampler.px = int(pxy & 0xffffu);
           sampler.py = int(pxy >> 16);
@@ -596,7 +612,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           if constexpr (F & F_MESH) walk_mesh = shape->kind == SHAPE_MESH;
           if (walk_mesh) {
             const DRayOct oct = make_oct(wr);
-            hh = mesh_traverse<false, kQBlock>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
+            hh = mesh_traverse<false, kQBlock, F>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
           } else {
             hh = shape_intersect<F>(shape, wr);
           }
@@ -834,6 +850,11 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   unsigned long long sc = shadow_count;
   for (int off = 32; off > 0; off >>= 1) sc += __shfl_down(sc, off);
   if (lane == 0) atomicAdd(&counters->shadow_rays, sc);
+  if constexpr (F & F_SSS) {
+    unsigned long long wc = walk_count;
+    for (int off = 32; off > 0; off >>= 1) wc += __shfl_down(wc, off);
+    if (lane == 0) atomicAdd(&counters->walk_steps, wc);
+  }
 }
 
 }  // namespace pine_gpu

@@ -25,7 +25,8 @@ if queue:
              "closest trav", "T:result+fold", "T:items", "state store", "push", "idle", "W:walk step", "W:store"]
 out = (C.c_uint64 * 16)()
 _lib.check(_lib.lib.pine_gpu_plan_debug_sections(plan._h, out))
-tot = sum(out[:len(names)])
-print(f"{cfg}: {'queue' if queue else 'mega'} kernel  trace_ms {st.trace_ms:.2f} vertices/sample {st.vertices/st.camera_samples:.3f} lds {st.lds_bytes} grid {st.grid_blocks}")
+tot = max(1, sum(out[:len(names)]))
+print(f"{cfg}: {'queue' if queue else 'mega'} kernel  trace_ms {st.trace_ms:.2f} vertices/sample {st.vertices/st.camera_samples:.3f} walk steps/sample {st.walk_steps/st.camera_samples:.3f} "
+      f"lds {st.lds_bytes} grid {st.grid_blocks} accel_build_ms {st.accel_build_ms:.2f} upload_ms {st.upload_ms:.2f}")
 for n, v in zip(names, out):
     print(f"  {n:26s} {v/tot*100:6.2f}%")
