@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configs.
 
 metric   : Msamples/s = W*H*spp_effective / t   
-workload : configs[1] = cbox 640x640, BlueSampler(256), depth 8, as-committed camera
-step     : one full render of that film (prepass + path kernel + ordered resolve [+ RCCL film
-           reduce when N > 1]); scene, BVH, sampler tables and work buffers are resident in HBM
+workload : --config c2 (default) = configs[1] = cbox 640x640, BlueSampler(256), depth 8, as-committed camera;
+           c3 = cbox 1920x1080, BlueSampler(1024 -> 256 effective), depth 8 (BASELINE's 8-GPU workload);
+           c4 = classic.pine + 10 000 cones 720x360, BlueSampler(64), depth 6;
+           c5 = Subsurface icosphere in the Rect-only cbox 640x640, BlueSampler(512 -> 256 effective), depth 8.
+step     : one full render of that film (prepass + path kernel + ordered resolve [+ RCCL slab gather and
+           unpack on rank 0 when N > 1]); scene, BVH, sampler tables and work buffers are resident in HBM
            before the timed region.
-N > 1    : 8x8-pixel tiles dealt round-robin to ranks (strong scaling: the film is fixed), each rank
-           renders its tiles into a zero-initialised full-size film, one RCCL reduce(sum) to rank 0
-           per step (exact: x + 0).
+N > 1    : 8x8-pixel tiles dealt round-robin to ranks (strong scaling: the film is fixed); every rank writes
+           only its own tiles into a slab, the slabs are gathered to rank 0 (direct xGMI sends) and scattered
+           into the row-major film there.  The gather + unpack of step i runs on a second stream while the path
+           kernel of step i+1 runs (double-buffered slabs).
+At N = 1 the default line also carries a `configs` array: C3 / C4 / C5 measured the same way at reduced
+steps, each with its own roofline entry and its film's md5 checked against the reference's
+(tests/golden/stats_640.json).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -22,27 +30,51 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, SPP, DEPTH = 640, 640, 256, 8
 B_VERTEX = 192.0  # algorithmic bytes per radiance() invocation
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(scene, budget_s=12.0):
+def _configs():
+    from pine_amd import scenes
+    return {
+        # name: (scene builder, requested spp, depth, workload text, key in tests/golden/stats_640.json)
+        "c2": (lambda: scenes.cbox((640, 640), "committed"), 256, 8,
+               "cbox 640x640 256spp depth=8, as-committed camera, BlueSampler, pine-BVH order", "C2_cbox_640_s256_d8_committed"),
+        "c3": (lambda: scenes.cbox((1920, 1080), "committed"), 1024, 8,
+               "cbox 1920x1080 BlueSampler(1024) = 256 effective spp depth=8, as-committed camera, pine-BVH order",
+               "C3_cbox_1920x1080_s1024_d8"),
+        "c4": (lambda: scenes.classic_cones((720, 360), 100), 64, 6,
+               "classic.pine + 10 000 procedurally placed cones 720x360 64spp depth=6", "C4_classic_10k_cones_720x360_s64_d6"),
+        "c5": (lambda: scenes.sss((640, 640), 3), 512, 8,
+               "Subsurface icosphere (1280 triangles) + emissive Rect in the Rect-only cbox 640x640 BlueSampler(512) = 256 effective spp depth=8",
+               "C5_sss_640_s512_d8"),
+    }
+
+
+def golden_md5(key):
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "stats_640.json")))[key]["md5"]
+    except Exception:
+        return None
+
+
+def cpu_baseline(scene, size, spp, depth, budget_s=12.0):
     """The oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded,
     stratified sample of the same workload: 8-row bands spread evenly over the film."""
     from oracle import oracle
+    W, H = size
     ps = scene.describe()
     threads = os.cpu_count() or 1
-    # calibrate on two bands (one in the empty lower half, one in the lit upper half)
+    # calibrate on two bands (one in the lower half, one in the upper half)
     t0 = time.time()
     n = 0
-    for y in (160, 480):
-        _, st = oracle.render(ps, (W, H), SPP, DEPTH, threads, rows=(y, y + 8))
+    for y in (H // 4 // 8 * 8, 3 * H // 4 // 8 * 8):
+        _, st = oracle.render(ps, (W, H), spp, depth, threads, rows=(y, y + 8))
         n += st.camera_samples
     rate = n / max(time.time() - t0, 1e-6)
-    total = W * H * SPP
+    total = W * H * min(spp, 256)
     bands_all = H // 8
-    nb = int(max(2, min(bands_all, budget_s * rate / (8 * W * SPP))))
+    nb = int(max(2, min(bands_all, budget_s * rate / (8 * W * min(spp, 256)))))
     nb -= nb % 2  # keep the two halves of the film equally represented
     nb = max(nb, 2)
     step = bands_all / nb
@@ -51,28 +83,29 @@ def cpu_baseline(scene, budget_s=12.0):
     secs = 0.0
     verts = 0
     for y in ys:
-        _, st = oracle.render(ps, (W, H), SPP, DEPTH, threads, rows=(y, y + 8))
+        _, st = oracle.render(ps, (W, H), spp, depth, threads, rows=(y, y + 8))
         samples += st.camera_samples
         secs += st.seconds
         verts += st.vertices
     return {
         "value": samples / secs * 1e-6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-        "sample": f"{len(ys)} of {bands_all} 8-row bands of the same 640x640x256spp depth-8 render "
+        "sample": f"{len(ys)} of {bands_all} 8-row bands of the same {W}x{H} render "
                   f"({samples / total:.3f} of the workload, {secs:.1f} s), evenly spaced over the film",
         "vertices_per_sample": verts / samples,
     }
 
 
-def cpu_baseline_reference(scene, gpu_md5, budget_s=40.0):
+def cpu_baseline_reference(scene, size, spp, depth, gpu_md5, budget_s=40.0):
     """The REAL reference timed beside the GPU: oracle/_ref/pine_ref is pine's own PathIntegrator + BVH,
     compiled from the reference's sources by oracle/Makefile in the build container (the binary travels,
-    the sources do not).  Renders the same scene description; the whole C2 workload when a 16-spp
+    the sources do not).  Renders the same scene description; the whole workload when a 16-spp
     calibration run says it fits the budget, else the largest power-of-two spp that does.  Returns None when
     the binary is absent or fails (the caller then reports the CPU restatement, kind "port")."""
-    import hashlib
     import subprocess
     import tempfile
-    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "pine_ref")
+    W, H = size
+    spp_full = min(spp, 256)
+    exe = os.path.join(ROOT, "oracle", "_ref", "pine_ref")
     if not os.access(exe, os.X_OK):
         return None
     try:
@@ -80,25 +113,24 @@ def cpu_baseline_reference(scene, gpu_md5, budget_s=40.0):
             sp, fp = os.path.join(tmp, "s.pscene"), os.path.join(tmp, "s.film")
             open(sp, "w").write(scene.describe())
 
-            def run(spp, limit):
-                r = subprocess.run([exe, "render", sp, str(spp), str(DEPTH), fp], capture_output=True, text=True,
+            def run(n, limit):
+                r = subprocess.run([exe, "render", sp, str(n), str(depth), fp], capture_output=True, text=True,
                                    timeout=limit)
                 if r.returncode != 0:
                     raise RuntimeError(r.stderr[-300:])
                 return json.loads(r.stdout.strip().splitlines()[-1])
-            cal = run(16, 120)
-            spp = SPP
-            while spp > 16 and cal["seconds"] * spp / 16 > budget_s:
-                spp //= 2
-            res = cal if spp == 16 else run(spp, 4 * budget_s + 60)
+            cal = run(16, 240)
+            n = spp_full
+            while n > 16 and cal["seconds"] * n / 16 > budget_s:
+                n //= 2
+            res = cal if n == 16 else run(n, 4 * budget_s + 60)
             md5 = hashlib.md5(open(fp, "rb").read()).hexdigest()
-        whole = spp == SPP
+        whole = n == spp_full
+        what = "oracle/_ref/pine_ref = the reference's own PathIntegrator(BVH, BlueSampler, UniformLightSampler)"
         return {
             "value": res["msamples_per_s"], "unit": "Msamples/s", "cores": res["threads"], "kind": "reference",
-            "sample": (f"the whole workload (640x640x{spp}spp depth {DEPTH}) rendered by oracle/_ref/pine_ref = the reference's own "
-                       f"PathIntegrator(BVH, BlueSampler, UniformLightSampler) in {res['seconds']:.1f} s" if whole else
-                       f"640x640x{spp}spp depth {DEPTH} ({spp}/{SPP} of the samples per pixel, {res['seconds']:.1f} s) rendered by "
-                       f"oracle/_ref/pine_ref = the reference's own PathIntegrator(BVH, BlueSampler, UniformLightSampler)"),
+            "sample": (f"the whole workload ({W}x{H}x{n}spp depth {depth}) rendered by {what} in {res['seconds']:.1f} s" if whole else
+                       f"{W}x{H}x{n}spp depth {depth} ({n}/{spp_full} of the samples per pixel, {res['seconds']:.1f} s) rendered by {what}"),
             "film_md5": md5,
             "film_equals_gpu": (md5 == gpu_md5) if whole else None,
         }
@@ -107,18 +139,87 @@ def cpu_baseline_reference(scene, gpu_md5, budget_s=40.0):
         return None
 
 
+def roofline_entry(st, local_samples, verts, traffic=None):
+    """Roofline of the dominant kernel (the path kernel) on this rank: algorithmic bytes per launch =
+    192 B x radiance() invocations + 16 B x pixels of this rank's shard, over the kernel's average launch
+    duration from HIP events recorded on the launch stream inside the library."""
+    k_ms = st.trace_ms
+    kernel = "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel"
+    alg_bytes = B_VERTEX * verts + 16.0 * local_samples / st.spp_effective
+    achieved = alg_bytes / (k_ms * 1e-3) * 1e-9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_unit": "bytes per launch (rocprofv3 2*FETCH_SIZE+WRITE_SIZE, fabric side incl. Infinity-Cache hits)",
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel": kernel, "kernel_ms": k_ms,
+            "bytes_per_vertex": B_VERTEX, "note": "algorithmic bytes of the streaming formulation (SURVEY.md 8(d)); the kernel keeps path state in LDS and the fold stack in L2/Infinity Cache, so it is latency/VALU bound, not HBM bound"}
+
+
+def measured_traffic(name, kernel, world):
+    """HBM-side traffic of the path kernel per launch: measured off-line with rocprofv3 PMC passes
+    (tools/profile_round.sh -> profiles/rNN_traffic[_cX].json, latest round); None if not measured."""
+    if world != 1:
+        return None
+    pat = "r*_traffic.json" if name == "c2" else f"r*_traffic_{name}.json"
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+    if tfiles:
+        tj = json.load(open(tfiles[-1]))
+        if tj.get("kernel", "").startswith(kernel):
+            return tj["traffic_bytes_per_launch"]
+    return None
+
+
+def side_config(name, steps, warmup, device):
+    """One of the other BASELINE configs on this GPU, measured like the headline (N = 1): K timed renders
+    bracketed by synchronisation, kernel time from the library's HIP events, md5 against the reference's."""
+    import torch
+    import pine_amd
+    build, spp, depth, text, key = _configs()[name]
+    scene = build()
+    W, H = scene.camera.film().size
+    plan = pine_amd.Plan(scene, spp, depth, device=device, timing=True)
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        plan.launch(film.data_ptr(), stream)
+    torch.cuda.synchronize()
+    plan.stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.launch(film.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = plan.stats()
+    md5 = hashlib.md5(film.cpu().numpy().tobytes()).hexdigest()
+    want = golden_md5(key)
+    rl = roofline_entry(st, st.camera_samples, st.vertices, measured_traffic(name, "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel", 1))
+    out = {"config": name, "workload": text, "film": [W, H], "spp_effective": st.spp_effective, "max_path_length": depth,
+           "value": st.camera_samples * steps / dt * 1e-6, "unit": "Msamples/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "vertices_per_sample": st.vertices / st.camera_samples,
+           "walk_steps_per_sample": st.walk_steps / st.camera_samples,
+           "samples_per_item": st.samples_per_item, "roofline": rl,
+           "kernels_ms": {"prepass": st.prepass_ms, "path_trace": st.trace_ms, "resolve": st.resolve_ms},
+           "plan_ms": {"accel_build_host": st.accel_build_ms, "upload": st.upload_ms},
+           "film_md5": md5, "reference_md5": want, "film_equals_reference": (md5 == want) if want else None}
+    plan.close()
+    del film
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"], help="the workload (default: BASELINE configs[1])")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 entries of the default line")
     ap.add_argument("--spi", type=int, default=0, help="samples per work item (0 = auto)")
     args = ap.parse_args()
 
     import torch
     import pine_amd
-    from pine_amd import scenes
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,30 +245,51 @@ def main():
             dist.init_process_group(backend)
     cdev = "cuda" if backend == "nccl" else "cpu"  # where collective buffers live
 
-    scene = scenes.cbox((W, H), "committed")
+    build, SPP, DEPTH, workload, stats_key = _configs()[args.config]
+    scene = build()
+    W, H = scene.camera.film().size
     plan = pine_amd.Plan(scene, SPP, DEPTH, device=local_rank, shard_rank=rank, shard_world=world,
                          samples_per_item=args.spi, timing=True)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    main_stream = torch.cuda.current_stream()
+    stream = main_stream.cuda_stream
     # N > 1: every rank writes only its own tiles, tile-major, into a slab (1/N of the film); the
-    # slabs are gathered to rank 0 (direct sends over xGMI, 6.55/N MB each) and scattered into the
-    # row-major film there.  PINE_BENCH_COLLECTIVE=reduce selects the simpler form instead: full-size
-    # zero-initialised films summed to rank 0 (exact: x + 0), 6.55 MB per rank.
+    # slabs are gathered to rank 0 (direct sends over xGMI) and scattered into the row-major film there.
+    # Slabs are double-buffered and the gather + unpack run on a second stream, so that they overlap the next
+    # step's path kernel (PINE_BENCH_OVERLAP=0 puts everything back on one stream).
+    # PINE_BENCH_COLLECTIVE=reduce selects the simpler form instead: full-size zero-initialised films summed to
+    # rank 0 (exact: x + 0), a whole film per rank.
     collective = os.environ.get("PINE_BENCH_COLLECTIVE", "gather") if use_dist else "none"
+    overlap = collective == "gather" and cdev == "cuda" and os.environ.get("PINE_BENCH_OVERLAP", "1") != "0"
     if collective == "gather":
-        slab = torch.empty(plan.slab_floats(), dtype=torch.float32, device="cuda")
-        slabs = torch.empty((world, plan.slab_floats()), dtype=torch.float32, device="cuda") if rank == 0 else None
-        slabs_c = slabs if cdev == "cuda" else (torch.empty(slabs.shape, dtype=torch.float32) if rank == 0 else None)
-        slab_list = list(slabs_c.unbind(0)) if rank == 0 else None
+        nbuf = 2 if overlap else 1
+        slab = [torch.empty(plan.slab_floats(), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        slabs = [torch.empty((world, plan.slab_floats()), dtype=torch.float32, device="cuda") if rank == 0 else None for _ in range(nbuf)]
+        slabs_c = [s if cdev == "cuda" else (torch.empty(s.shape, dtype=torch.float32) if rank == 0 else None) for s in slabs]
+        slab_list = [list(s.unbind(0)) if rank == 0 else None for s in slabs_c]
+        comm_stream = torch.cuda.Stream() if overlap else main_stream
+        rendered = [torch.cuda.Event() for _ in range(nbuf)]
+        consumed = [torch.cuda.Event() for _ in range(nbuf)]
+    step_no = [0]
 
     def step():
         if collective == "gather":
-            plan.launch_packed(slab.data_ptr(), stream)
-            dist.gather(slab if cdev == "cuda" else slab.cpu(), slab_list, dst=0)
-            if rank == 0:
-                if cdev != "cuda":
-                    slabs.copy_(slabs_c)
-                pine_amd.film_unpack((W, H), world, slabs.data_ptr(), film.data_ptr(), local_rank, stream)
+            b = step_no[0] % len(slab)
+            step_no[0] += 1
+            if overlap:
+                main_stream.wait_event(consumed[b])  # (the gather that read this slab two steps ago; a no-op the first time)
+            plan.launch_packed(slab[b].data_ptr(), stream)
+            if overlap:
+                rendered[b].record(main_stream)
+                comm_stream.wait_event(rendered[b])
+            with torch.cuda.stream(comm_stream):
+                dist.gather(slab[b] if cdev == "cuda" else slab[b].cpu(), slab_list[b], dst=0)
+                if rank == 0:
+                    if cdev != "cuda":
+                        slabs[b].copy_(slabs_c[b])
+                    pine_amd.film_unpack((W, H), world, slabs[b].data_ptr(), film.data_ptr(), local_rank, comm_stream.cuda_stream)
+                if overlap:
+                    consumed[b].record(comm_stream)
         else:
             plan.launch(film.data_ptr(), stream)
             if collective == "reduce":
@@ -179,6 +301,7 @@ def main():
                     film.copy_(host)
 
     def barrier():
+        torch.cuda.synchronize()  # every stream of this device, the second one included
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -214,42 +337,37 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_samples * args.steps / dt * 1e-6
         vbar = total_verts / total_samples
-        # roofline of the dominant kernel (path_trace_kernel) on this rank: algorithmic bytes per
-        # launch = (192 B * vertices + 16 B * pixels) of this rank's shard / average launch duration
-        k_ms = st.trace_ms
         kernel = "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel"
-        # HBM-side traffic of that kernel per launch: measured off-line with rocprofv3 PMC passes
-        # (tools/profile_round.sh -> profiles/rNN_traffic.json, latest round); null if not measured
-        # for this kernel / this GPU count
-        traffic = None
-        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
-        if tfiles and world == 1:
-            tj = json.load(open(tfiles[-1]))
-            if tj.get("kernel", "").startswith(kernel):
-                traffic = tj["traffic_bytes_per_launch"]
-        alg_bytes = B_VERTEX * verts + 16.0 * local_samples / spp_eff
-        achieved = alg_bytes / (k_ms * 1e-3) * 1e-9
+        film_md5 = hashlib.md5(film.cpu().numpy().tobytes()).hexdigest()
+        want = golden_md5(stats_key)
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (scenes/cbox.pine geometry rebuilt through the API; sampler tables are the published BlueSobol data)",
-            "config": {"workload": "cbox 640x640 256spp depth=8, as-committed camera, BlueSampler, pine-BVH order",
+            "data": "synthetic (the reference's scene geometry rebuilt through the API; sampler tables are the published BlueSobol data)",
+            "config": {"workload": workload, "name": args.config,
                        "film": [W, H], "spp_effective": spp_eff, "max_path_length": DEPTH,
-                       "parallelism": f"tiles8x8-roundrobin x{world}", "collective": collective, "samples_per_item": st.samples_per_item,
+                       "parallelism": f"tiles8x8-roundrobin x{world}", "collective": collective,
+                       "overlap_gather_with_next_render": bool(overlap) if use_dist else None,
+                       "samples_per_item": st.samples_per_item,
                        "grid_blocks": st.grid_blocks, "vertices_per_sample": vbar},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 2*FETCH_SIZE+WRITE_SIZE, fabric side incl. Infinity-Cache hits)",
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel": kernel, "kernel_ms": k_ms,
-                         "bytes_per_vertex": B_VERTEX, "note": "algorithmic bytes of the streaming formulation (SURVEY.md 8(d)); the kernel keeps path state in LDS and the fold stack in L2/Infinity Cache, so it is latency/VALU bound, not HBM bound"},
-            "film_md5": __import__("hashlib").md5(film.cpu().numpy().tobytes()).hexdigest(),
-            "kernels_ms": {"prepass": st.prepass_ms, "path_trace": k_ms, "resolve": st.resolve_ms, "launches_averaged": st.timed_launches},
+            "roofline": roofline_entry(st, local_samples, verts, measured_traffic(args.config, kernel, world)),
+            "film_md5": film_md5, "reference_md5": want, "film_equals_reference": (film_md5 == want) if want else None,
+            "kernels_ms": {"prepass": st.prepass_ms, "path_trace": st.trace_ms, "resolve": st.resolve_ms, "launches_averaged": st.timed_launches},
+            "plan_ms": {"accel_build_host": st.accel_build_ms, "upload": st.upload_ms,
+                        "note": "one-time host cost of plan creation, outside the timed region (scene resident before it starts)"},
         }
+        if world == 1 and not args.no_configs and args.config == "c2":
+            plan.close()
+            out["configs"] = []
+            for name, k, w in (("c3", 3, 1), ("c4", 5, 1), ("c5", 2, 1)):
+                try:
+                    out["configs"].append(side_config(name, k, w, local_rank))
+                except Exception as e:  # report, keep the headline
+                    out["configs"].append({"config": name, "error": str(e)[:300]})
         if world == 1 and not args.no_cpu:
-            port = cpu_baseline(scene)
-            ref = cpu_baseline_reference(scene, out["film_md5"])
+            port = cpu_baseline(scene, (W, H), SPP, DEPTH)
+            ref = cpu_baseline_reference(scene, (W, H), SPP, DEPTH, film_md5)
             cb = ref if ref else port
             out["cpu_baseline"] = cb
             if ref:

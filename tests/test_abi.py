@@ -186,9 +186,8 @@ def test_bench_reference_baseline_reports_the_real_binary(oracle):
     spec.loader.exec_module(bench)
     from pine_amd import scenes
     sc = scenes.cbox((640, 640), "committed")
-    bench.SPP = 16  # (the function renders bench.SPP samples per pixel when the calibration run says they fit)
-    port, _ = oracle.render(sc.describe(), (640, 640), 16, bench.DEPTH)
+    port, _ = oracle.render(sc.describe(), (640, 640), 16, 8)
     md5 = hashlib.md5(port.tobytes()).hexdigest()
-    out = bench.cpu_baseline_reference(sc, gpu_md5=md5, budget_s=1e9)
+    out = bench.cpu_baseline_reference(sc, (640, 640), 16, 8, gpu_md5=md5, budget_s=1e9)
     assert out and out["kind"] == "reference" and out["cores"] >= 1 and out["value"] > 0
     assert out["film_md5"] == md5 and out["film_equals_gpu"] is True

@@ -79,9 +79,39 @@ HALTON_FILMS = {
 }
 
 
+OTHER_CONFIGS = (
+    # the BASELINE configs other than C1 / C2 at full size (whole-image statistics; too big to commit as films)
+    ("C3_cbox_1920x1080_s1024_d8", lambda: scenes.cbox((1920, 1080), "committed"), 1024, 8),
+    ("C4_classic_10k_cones_720x360_s64_d6", lambda: scenes.classic_cones((720, 360), 100), 64, 6),
+    ("C5_sss_320_s512_d8", lambda: scenes.sss((320, 320), 3), 512, 8),
+    ("C5_sss_640_s512_d8", lambda: scenes.sss((640, 640), 3), 512, 8),  # BASELINE's size: minutes of the reference on 8 threads
+)
+
+
+def other_config_stats(tmp, stats, only=None):
+    for name, build, spp, depth in OTHER_CONFIGS:
+        if only and name not in only:
+            continue
+        ps, film, info = ref_film(build(), spp, depth, tmp)
+        stats[name] = {"spp": spp, "depth": depth,
+                       "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
+                       "md5": hashlib.md5(film.tobytes()).hexdigest(),
+                       "ref_seconds": info["seconds"], "ref_threads": info["threads"],
+                       "ref_msamples_per_s": info["msamples_per_s"]}
+        print(name, stats[name], flush=True)
+
+
 def main():
     full = "--full" in sys.argv
     os.makedirs(OUT, exist_ok=True)
+    only = next((a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--stats-only=")), None)
+    if only:  # just (re)render the named whole-image statistics entries with the real reference
+        stats_path = os.path.join(OUT, "stats_640.json")
+        stats = json.load(open(stats_path))
+        with tempfile.TemporaryDirectory() as tmp:
+            other_config_stats(tmp, stats, only)
+        json.dump(stats, open(stats_path, "w"), indent=1)
+        return
     with tempfile.TemporaryDirectory() as tmp:
         # 1. sampler / rng / host-math known answers
         for spp in (1, 16, 256):
@@ -173,18 +203,7 @@ def main():
                                "ref_seconds": info["seconds"], "ref_threads": info["threads"],
                                "ref_msamples_per_s": info["msamples_per_s"]}
                 print(name, stats[name])
-            # the other BASELINE configs at full size (C5 at a quarter of the film: the reference needs minutes for it)
-            for name, build, spp, depth in (
-                    ("C3_cbox_1920x1080_s1024_d8", lambda: scenes.cbox((1920, 1080), "committed"), 1024, 8),
-                    ("C4_classic_10k_cones_720x360_s64_d6", lambda: scenes.classic_cones((720, 360), 100), 64, 6),
-                    ("C5_sss_320_s512_d8", lambda: scenes.sss((320, 320), 3), 512, 8)):
-                ps, film, info = ref_film(build(), spp, depth, tmp)
-                stats[name] = {"spp": spp, "depth": depth,
-                               "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
-                               "md5": hashlib.md5(film.tobytes()).hexdigest(),
-                               "ref_seconds": info["seconds"], "ref_threads": info["threads"],
-                               "ref_msamples_per_s": info["msamples_per_s"]}
-                print(name, stats[name], flush=True)
+            other_config_stats(tmp, stats)
             json.dump(stats, open(stats_path, "w"), indent=1)
         json.dump(meta, open(os.path.join(OUT, "films.json"), "w"), indent=1)
 
