@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "liboracle.so")
+LIB = os.environ.get("PINE_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # (the override: the sanitizer build, tools/sanitize)
 REF_BIN = os.path.join(_HERE, "_ref", "pine_ref")
 TABLES = os.path.join(os.path.dirname(_HERE), "pine_amd", "data", "bluesobol_u8.bin")
 

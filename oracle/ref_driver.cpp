@@ -12,9 +12,12 @@
 //   pine_ref rng     <out.bin>           hash()/RNG known answers (fixture 1)
 //   pine_ref host    <out.bin>           host-side math known answers (matrices, look_at, ctors)
 //   pine_ref shapes  <scene.pscene> <rays.bin> <out.bin>   per-shape hit/intersect records
+//   pine_ref finalize <film.bin> <W> <H> <tonemapper> <out.u8> [out.png]   Film::finalize + flip + gamma + x256 (film.save)
 //   pine_ref prl     <literal>...        psl::stof / stoi / to_string of each literal, and the constant
 //                                        expressions of a cbox-class script evaluated with psl::stof values
 //                                        (pins the PRL front-end's literal and vector arithmetic)
+#include <pine/core/fileio.h>
+#include <pine/core/film.h>
 #include <pine/core/lightsampler.h>
 #include <pine/core/sampler.h>
 #include <pine/core/scene.h>
@@ -32,6 +35,10 @@
 #include <thread>
 #include <vector>
 
+namespace pine {
+// defined (with external linkage) in the reference's src/pine/core/fileio.cpp:42-54; no header declares it
+psl::vector<uint8_t> to_uint8_array(vec2i size, int nchannel, const float* data, bool flip_y, bool apply_gamma);
+}
 using namespace pine;
 
 static float rdf(std::istream& in) {
@@ -477,6 +484,25 @@ int main(int argc, char** argv) {
       }
     }
     write_file(argv[4], out.data(), out.size() * 4);
+    return 0;
+  }
+  if (cmd == "finalize" && (argc == 7 || argc == 8)) {
+    // finalize <film.bin> <W> <H> <tonemapper 0|1> <out.u8> [out.png]: what scene.camera.film().save(path) does to a
+    // rendered film -- Film::finalize (film.cpp:19-25: scale, w = 1, tone mapping), the y flip of save_image(...,
+    // true) (fileio.h:33-38,52-55), gamma 1/2.2 and x 256 clamp (fileio.cpp:42-54) -- through the reference's own functions
+    const int w = atoi(argv[3]), h = atoi(argv[4]), tm = atoi(argv[5]);
+    Film film(vec2i(w, h), tm == 1 ? ToneMapper(ACESToneMapper()) : ToneMapper(Uncharted2ToneMapper()));
+    FILE* f = fopen(argv[2], "rb");
+    if (!f || fread(film.data(), 16, size_t(w) * h, f) != size_t(w) * h) {
+      fprintf(stderr, "cannot read %s\n", argv[2]);
+      return 2;
+    }
+    fclose(f);
+    if (argc == 8) save_film_as_image(argv[7], film);  // (takes the film by value: finalizes a copy)
+    film.finalize();
+    auto flipped = invert_y(film.pixels);
+    auto u8 = to_uint8_array(flipped.size(), 4, &flipped.data()[0][0], false, true);
+    write_file(argv[6], u8.data(), u8.size());
     return 0;
   }
   fprintf(stderr, "usage: see header of oracle/ref_driver.cpp\n");

@@ -30,6 +30,8 @@ enum : unsigned {
   F_SOBOL = 1u << 12,     // the sampler may be SobolSampler (DTables::kind) instead of BlueSampler
   F_LDS_TOP = 1u << 13,   // scene in global memory, but the first DeviceScene::lds_nodes BVH nodes (breadth-first numbering:
                           // the levels every ray visits) are staged in LDS, and the traversal stack holds 16-bit node ids
+  F_LDS_REST = 1u << 14,  // with F_LDS_TOP: everything of the scene blob except the BVH nodes (shape / leaf / material / light records:
+                          // small when the geometry count is, whatever the meshes' sizes) is staged in LDS as well
   F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES | F_SOBOL,
 };
 

@@ -174,6 +174,7 @@ struct WorkParams {
   unsigned long long total_items;  // num_local_tiles * items_per_pixel * 64
   unsigned long long idle_budget_ticks;  // stage-queued kernel: a wave that finds no work for this long (100 MHz wall clock) bails out
   int debug_force_bail;  // test hook (PINE_GPU_FLAG_DEBUG_FORCE_BAIL): the first wave bails out at once
+  int trav_min_lanes, trav_min_trips;  // resumable traversal (pine_trav.h): park when fewer lanes than this still travel after this many trips
   unsigned long long* progress;  // host-mapped word (or null): work items claimed so far, stored now and then (get_progress)
 };
 // get_progress() (integrator.cpp:17-19): every 16th / 64th pool claim posts the claimed-item count to host memory
@@ -516,7 +517,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.shapes = reinterpret_cast<const DShape*>(base + S.off_shapes);
     V.materials = reinterpret_cast<const DMaterial*>(base + S.off_materials);
     V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
-    V.prims = reinterpret_cast<const int*>(base + S.off_prims);
+    V.prims = nullptr;
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
@@ -527,7 +528,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.shapes = S.shapes;
     V.materials = S.materials;
     V.bvhs = S.bvhs;
-    V.prims = S.prims;
+    V.prims = nullptr;
     V.lights = S.lights;
     V.node_ops = S.node_ops;
   }
@@ -972,6 +973,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 }
 
 }  // namespace pine_gpu
+#include "pine_trav.h"
 #include "pine_queue_kernel.h"
 namespace pine_gpu {
 
@@ -1002,26 +1004,29 @@ struct QueueVariant {
   unsigned features;
   int ctx;             // path contexts per workgroup
   size_t fixed_lds;    // LDS bytes before the traversal stack
+  size_t min_stack;    // least size of the stack region (it also holds the sampler window in the F_LDS_TOP variants)
   QueueKernelFn fn;
   const char* name;
 };
-#define PINE_QV(F, CTX, NAME) {F, CTX, QLayout<CTX, ((F) & F_SSS) ? 3 : 2>::fixed_bytes, path_queue_kernel<F, CTX>, NAME}
+#define PINE_QV(F, CTX, NAME) \
+  {F, CTX, QLayout<CTX, q_num_queues(F), ((F) & F_LDS_TOP) != 0>::fixed_bytes, QLayout<CTX, q_num_queues(F), ((F) & F_LDS_TOP) != 0>::min_stack_bytes, path_queue_kernel<F, CTX>, NAME}
 static const QueueVariant kQueueVariants[] = {
     PINE_QV(F_OBB | F_LDS_SCENE, PINE_QCTX, "queue: rect+transformed box/diffuse, scene in LDS"),  // cbox exactly
     PINE_QV(kFBoxes | F_LDS_SCENE, PINE_QCTX, "queue: rect+box/diffuse, scene in LDS"),
 #ifndef PINE_ONLY_CBOX_VARIANT
     PINE_QV(kFAnalytic | F_LDS_SCENE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS"),
-    // scenes that do not fit LDS whole: the top of the BVH (breadth-first numbering) is cached in whatever LDS the
-    // contexts and the 16-bit traversal stack leave (F_LDS_TOP)
-    PINE_QV(kFAnalytic | F_LDS_TOP, PINE_QCTX, "queue: analytic shapes/uber, BVH top in LDS"),
-    // the same analytic feature set with 1024 contexts, for BVHs whose traversal stack (2 KB of LDS per slot)
-    // leaves no room for 1536 (the 10 000-cone scene: depth 15)
+    // scenes that do not fit LDS whole (F_LDS_TOP): 1024 contexts; the top of the BVH (breadth-first numbering) is cached
+    // in whatever LDS the contexts and the 16-bit traversal stack (2 KB per slot) leave; traversals are resumable and
+    // regrouped through the XS / XC queues (pine_trav.h)
     PINE_QV(F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP, 1024, "queue: rect+sphere+disk+cone/uber, 1024 contexts, BVH top in LDS (classic.pine's kinds exactly)"),
     PINE_QV(kFAnalytic | F_LDS_TOP, 1024, "queue: analytic shapes/uber, 1024 contexts, BVH top in LDS"),
-    // everything except Subsurface (meshes, node-graph materials, every light kind)
+    // everything except Subsurface (meshes, node-graph materials, every light kind); F_LDS_REST: few geometries (big
+    // meshes or not): their shape / leaf / material / light records are staged in LDS too
+    PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP | F_LDS_REST, 1024, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS"),
     PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP, 1024, "queue: all but SSS, 1024 contexts, BVH top in LDS"),
     // Subsurface: the BSSRDF random walk is a third stage (W) with its own queue
-    PINE_QV(F_MESH | F_SSS | F_LDS_TOP, 1024, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top in LDS"),
+    PINE_QV(F_MESH | F_SSS | F_LDS_TOP | F_LDS_REST, 1024, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top + scene records in LDS"),
+    PINE_QV(F_ALL | F_LDS_TOP | F_LDS_REST, 1024, "queue: all features, walk stage, 1024 contexts, BVH top + scene records in LDS"),
     PINE_QV(F_ALL | F_LDS_TOP, 1024, "queue: all features, walk stage, 1024 contexts, BVH top in LDS"),
     // BVHs of 65 536 nodes and more: 32-bit traversal stack, no node cache
     PINE_QV(F_ALL, 1024, "queue: all features, walk stage, 1024 contexts"),
@@ -1458,7 +1463,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     const DShape& sh = shapes[size_t(g)];
     packed_prims[i] = g | (H.materials[size_t(sh.material)].kind == MAT_EMISSIVE ? kPrimEmissiveBit : 0) | (sh.kind << kPrimKindShift);
   }
-  S.off_prims = put(packed_prims.data(), packed_prims.size() * sizeof(int));
+  S.off_prims = 0;  // (the primitive index list stays on the host: the leaf-ordered record copies below replace it)
   std::vector<DShape> leaf_shapes;  // SceneView::leaf
   for (size_t i = size_t(A.top_prim_begin); i < packed_prims.size(); i++) {
     DShape c = shapes[size_t(packed_prims[i] & kPrimIndexMask)];
@@ -1496,7 +1501,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.shapes = reinterpret_cast<const DShape*>(p->d_blob + S.off_shapes);
   S.materials = reinterpret_cast<const DMaterial*>(p->d_blob + S.off_materials);
   S.bvhs = reinterpret_cast<const DBvh*>(p->d_blob + S.off_bvhs);
-  S.prims = reinterpret_cast<const int*>(p->d_blob + S.off_prims);
+  S.prims = nullptr;
   S.leaf = reinterpret_cast<const DShape*>(p->d_blob + S.off_leaf) - S.top_prim_begin;
   S.lights = reinterpret_cast<const DLight*>(p->d_blob + S.off_lights);
   S.node_ops = reinterpret_cast<const DNodeOp*>(p->d_blob + S.off_node_ops);
@@ -1600,9 +1605,13 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
         if ((F & F_LDS_SCENE) && !lds_ok) continue;  // (a scene-in-global variant later in the table is the fallback when LDS is short)
-        if ((F & F_LDS_TOP) && A.nodes.size() > 65535) continue;  // 16-bit stack entries
-        const size_t stack_bytes = size_t(S.stack_total) * kQBlock * ((F & F_LDS_TOP) ? sizeof(unsigned short) : sizeof(int));
-        const size_t lds = kQueueVariants[v].fixed_lds + stack_bytes + ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0);
+        if ((F & F_LDS_TOP) && (A.nodes.size() > 65535 || S.stack_total > kTravMaxStack)) continue;  // 16-bit stack entries; a parked record holds 32
+        const size_t rest_bytes = size_t(S.blob_bytes - S.off_shapes);
+        if ((F & F_LDS_REST) && rest_bytes > 12 * 1024) continue;
+        const size_t stack_bytes = std::max(kQueueVariants[v].min_stack,
+                                            size_t(S.stack_total) * kQBlock * ((F & F_LDS_TOP) ? sizeof(unsigned short) : sizeof(int)));
+        const size_t lds = kQueueVariants[v].fixed_lds + stack_bytes + ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0) +
+                           ((F & F_LDS_REST) ? rest_bytes : 0);
         if (lds > 160 * 1024) continue;
         p->queue_variant = v;
         p->lds_bytes = lds;
@@ -1671,6 +1680,12 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     W.idle_budget_ticks = (unsigned long long)(budget_s * 100e6);  // wall_clock64(): 100 MHz
   }
   W.debug_force_bail = (prm->flags & PINE_GPU_FLAG_DEBUG_FORCE_BAIL) ? 1 : 0;
+  // Parking is OFF by default: measured on the MI355X it removes a quarter of the VALU instructions of the
+  // mesh scene but the kernels wait on memory, and a parked traversal costs extra round trips.
+  W.trav_min_lanes = 0;
+  W.trav_min_trips = 8;
+  if (const char* e = getenv("PINE_GPU_TRAV_MIN_LANES")) W.trav_min_lanes = atoi(e);  // (0 = never park: measurement aid)
+  if (const char* e = getenv("PINE_GPU_TRAV_MIN_TRIPS")) W.trav_min_trips = atoi(e) > 0 ? atoi(e) : 1;
   W.progress = nullptr;
   if (prm->flags & PINE_GPU_FLAG_PROGRESS) {
     HIP_OK(hipHostMalloc((void**)&p->h_progress, sizeof(unsigned long long), hipHostMallocMapped));

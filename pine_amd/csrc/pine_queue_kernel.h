@@ -31,19 +31,24 @@ constexpr int kQBlock = PINE_QBLOCK;  // threads per workgroup (one workgroup pe
 #endif
 constexpr int kQFields = 12;   // dwords of context state
 constexpr int kQPoolItems = 512;
-enum : int { QS_S = 0, QS_T = 1, QS_W = 2 };  // the walk queue W exists in the Subsurface (F_SSS) variants only
+// queues: S shade, T terminal; W walk step (Subsurface variants); XS / XC parked shadow / closest-hit traversals
+// (F_LDS_TOP variants: pine_trav.h)
+enum : int { QS_S = 0, QS_T = 1, QS_W = 2, QS_XS = 3, QS_XC = 4, QS_MAX = 5 };
+constexpr int q_num_queues(unsigned F) { return (F & F_LDS_TOP) ? 5 : (F & F_SSS) ? 3 : 2; }
 // context state fields (SoA in LDS: cst[field * kQCtx + id])
 enum : int { CF_OX, CF_OY, CF_OZ, CF_DX, CF_DY, CF_DZ, CF_TMAX, CF_ST, CF_PXY, CF_SBASE, CF_GEOM, CF_PRIM };
 constexpr unsigned kStFresh = 0xffffffffu;  // context has no path yet
-// control words: heads at 0..2; the S and T tails are ONE u64 (4..5) so that a stage reserves slots in both with one
-// atomic; the W tail at 6
-enum : int { QC_HEAD = 0, QC_TAIL = 4, QC_BUSY = 7, QC_LOCK = 8, QC_EXHAUSTED = 9, QC_PNEXT = 10, QC_PEND = 12, QC_ABORT = 14, QC_WORDS = 16 };
+// control words: heads at 0..4; tails at 8..12 -- the S and T tails are ONE u64 (8..9) so that a stage reserves
+// slots in both with one atomic
+enum : int { QC_HEAD = 0, QC_TAIL = 8, QC_BUSY = 13, QC_LOCK = 14, QC_EXHAUSTED = 15, QC_PNEXT = 16, QC_PEND = 18, QC_ABORT = 20, QC_WORDS = 24 };
 constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a protocol bug must end the kernel, not hang the GPU
 constexpr int kQWinDwords = 5;  // per-thread sampler window: 3 dwords of ranking bytes (12 dimensions) + 2 of scrambling bytes
 
 // LDS layout (dword offsets) for CTX path contexts per workgroup: the default is 1.5 contexts per thread;
 // scenes whose BVH needs a deep traversal stack (4 KB of LDS per stack slot) use the 1024-context layout.
-template <int CTX, int NQ = 2>
+// ALIAS: the per-thread sampler window shares its LDS with the traversal stack (variants whose stage S makes all its
+// draws before it traces: the F_LDS_TOP ones)
+template <int CTX, int NQ = 2, bool ALIAS = false>
 struct QLayout {
   static constexpr int ctx = CTX;
   static constexpr int ring = CTX <= 1024 ? 1024 : 2048;  // ring capacity (power of two >= CTX)
@@ -52,8 +57,9 @@ struct QLayout {
   static constexpr int off_state = off_ring + NQ * ring;
   static constexpr int off_sobol = off_state + kQFields * CTX;
   static constexpr int off_win = off_sobol + kLdsSamplerDims * 256 / 4;
-  static constexpr int off_stack = off_win + kQWinDwords * kQBlock;
+  static constexpr int off_stack = ALIAS ? off_win : off_win + kQWinDwords * kQBlock;
   static constexpr size_t fixed_bytes = size_t(off_stack) * 4;
+  static constexpr size_t min_stack_bytes = ALIAS ? size_t(kQWinDwords) * kQBlock * 4 : 0;  // the stack region also holds the window
 };
 
 // per-context global record (L2-resident): the pixel's RNG state (2 x u64); in the Subsurface variants also
@@ -62,8 +68,10 @@ struct QLayout {
 // the 256 KB tables (L2-resident, shared by every context).
 //   float4 0: RNG            1: beta flags lo, hi, -, -
 //   float4 2: walk ray origin (at exit: the exit point) | channel    3: walk direction | tmax    4: exit normal
+//   F_LDS_TOP variants, after those: the record of a parked traversal (pine_trav.h): shadow ray + flags, state, stack
 constexpr int kQCtxGlobalDwordsPlain = 4, kQCtxGlobalDwordsSss = 20;
-constexpr int q_ctx_global_dwords(unsigned F) { return (F & F_SSS) ? kQCtxGlobalDwordsSss : kQCtxGlobalDwordsPlain; }
+constexpr int q_ctx_trav_offset(unsigned F) { return (F & F_SSS) ? kQCtxGlobalDwordsSss : kQCtxGlobalDwordsPlain; }
+constexpr int q_ctx_global_dwords(unsigned F) { return q_ctx_trav_offset(F) + ((F & F_LDS_TOP) ? kTravRecordDwords : 0); }
 
 // Subsurface (F_SSS): the BSSRDF random walk (bxdf.cpp:329-353) is a stage of its own, W -- ONE free-flight
 // step per pass (closest hit inside the shape, exponential free flight, exit or uniform-sphere scatter), the
@@ -74,9 +82,12 @@ template <unsigned F, int CTX = PINE_QCTX>
 __global__ void __launch_bounds__(kQBlock, kQBlock / 256)
 path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
-  constexpr int kNQ = (F & F_SSS) ? 3 : 2;
+  constexpr int kNQ = q_num_queues(F);
+  constexpr bool kX = (F & F_LDS_TOP) != 0;  // resumable traversals + the XS / XC queues
+  static_assert(!(F & F_LDS_REST) || kX, "F_LDS_REST is an option of the F_LDS_TOP variants");
   constexpr int kQCtxGlobalDwords = q_ctx_global_dwords(F);
-  using L = QLayout<CTX, kNQ>;
+  constexpr int kQCtxTravOffset = q_ctx_trav_offset(F);
+  using L = QLayout<CTX, kNQ, kX>;
   constexpr int kQCtx = L::ctx, kQRing = L::ring, kQOffCtl = L::off_ctl, kQOffRing = L::off_ring, kQOffState = L::off_state,
                 kQOffSobol = L::off_sobol, kQOffWin = L::off_win, kQOffStack = L::off_stack;
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -104,10 +115,15 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   V.lds_node_count = 0;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
+  char* lds_after_stack = nullptr;
   if constexpr (F & F_LDS_TOP) {
+    size_t stack_bytes = size_t(S.stack_total) * kQBlock * sizeof(StackT);
+    if (stack_bytes < L::min_stack_bytes) stack_bytes = L::min_stack_bytes;
+    lds_after_stack = reinterpret_cast<char*>(lds_raw + kQOffStack) + stack_bytes;
+    if constexpr (F & F_LDS_REST) lds_after_stack += S.blob_bytes - S.off_shapes;  // (the records staged below)
     // the first S.lds_nodes nodes (breadth-first numbering: the top levels of the top-level BVH and of the mesh
     // BVHs) live in LDS behind the traversal stack
-    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds_raw + kQOffStack) + size_t(S.stack_total) * kQBlock * sizeof(StackT));
+    uint4* dst = reinterpret_cast<uint4*>(lds_after_stack);
     const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
     for (int i = tid; i < S.lds_nodes * 4; i += kQBlock) dst[i] = src[i];
     V.lds_nodes = reinterpret_cast<const DNode*>(dst);
@@ -123,7 +139,24 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.shapes = reinterpret_cast<const DShape*>(base + S.off_shapes);
     V.materials = reinterpret_cast<const DMaterial*>(base + S.off_materials);
     V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
-    V.prims = reinterpret_cast<const int*>(base + S.off_prims);
+    V.prims = nullptr;
+    V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
+    V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
+    V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
+  } else if constexpr (F & F_LDS_REST) {
+    // blob = nodes | shapes | materials | node programs | bvhs | leaf records | lights: everything after the nodes
+    size_t stack_bytes = size_t(S.stack_total) * kQBlock * sizeof(StackT);
+    if (stack_bytes < L::min_stack_bytes) stack_bytes = L::min_stack_bytes;
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds_raw + kQOffStack) + stack_bytes);
+    const uint4* src = S.blob + (S.off_shapes >> 4);
+    const int n16 = (S.blob_bytes - S.off_shapes) >> 4;
+    for (int i = tid; i < n16; i += kQBlock) dst[i] = src[i];
+    const char* base = reinterpret_cast<const char*>(dst) - S.off_shapes;
+    V.nodes = S.nodes;
+    V.shapes = reinterpret_cast<const DShape*>(base + S.off_shapes);
+    V.materials = reinterpret_cast<const DMaterial*>(base + S.off_materials);
+    V.bvhs = reinterpret_cast<const DBvh*>(base + S.off_bvhs);
+    V.prims = nullptr;
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
@@ -133,7 +166,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.shapes = S.shapes;
     V.materials = S.materials;
     V.bvhs = S.bvhs;
-    V.prims = S.prims;
+    V.prims = nullptr;
     V.lights = S.lights;
     V.node_ops = S.node_ops;
   }
@@ -173,42 +206,84 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       __atomic_store_n(&ring[slot], unsigned(id + 1), __ATOMIC_RELAXED);
     }
   };
-  // the walk queue has its own tail word (F_SSS variants)
-  auto push_w = [&](bool to_w, int id) {
-    const unsigned long long mw = __ballot(to_w);
-    if (mw == 0) return;
+  // the other queues have one tail word each
+  auto push_q = [&](int q, bool flag, int id) {
+    const unsigned long long m = __ballot(flag);
+    if (m == 0) return;
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&qctl[QC_TAIL + QS_W], unsigned(__popcll(mw)));
+    if (lane == 0) base = atomicAdd(&qctl[QC_TAIL + q], unsigned(__popcll(m)));
     base = __builtin_amdgcn_readfirstlane(base);
-    if (to_w) {
-      const unsigned slot = unsigned(QS_W * kQRing) + ((base + unsigned(__popcll(mw & ((1ull << lane) - 1ull)))) & (kQRing - 1));
+    if (flag) {
+      const unsigned slot = unsigned(q * kQRing) + ((base + unsigned(__popcll(m & ((1ull << lane) - 1ull)))) & (kQRing - 1));
       __atomic_store_n(&ring[slot], unsigned(id + 1), __ATOMIC_RELAXED);
     }
   };
+  auto push_w = [&](bool to_w, int id) { push_q(QS_W, to_w, id); };
 
   SEC_DECL;
-  // trace the context's new ray (closest hit), record the hit, classify the vertex it reaches:
+  // record a finished closest-hit query in the context and classify the vertex it reaches:
   // emissive / miss / path-length limit -> terminal queue, otherwise -> shade queue
-  auto extend = [&](int id, f3 o, f3 d, float tmax, PackedState st, bool& to_shade, bool& to_term) {
-    DRay ray{o, d, 0.0f, tmax};
-    int geom = -1, prim = 0;
-    SEC_MARK(5);  // S: BSDF sample + fold store + spawn  /  T: camera ray
-    const bool hit = scene_traverse<false, F, kQBlock>(V, ray, stack, geom, prim);
-    SEC_MARK(6);  // closest-hit traversal
-    cstf[CF_OX * kQCtx + id] = o.x;
-    cstf[CF_OY * kQCtx + id] = o.y;
-    cstf[CF_OZ * kQCtx + id] = o.z;
-    cstf[CF_DX * kQCtx + id] = d.x;
-    cstf[CF_DY * kQCtx + id] = d.y;
-    cstf[CF_DZ * kQCtx + id] = d.z;
-    cstf[CF_TMAX * kQCtx + id] = ray.tmax;
-    cstu[CF_ST * kQCtx + id] = st.v;
+  auto finish_hit = [&](int id, bool hit, float tmax, int geom, int prim, PackedState st, bool& to_shade, bool& to_term) {
+    cstf[CF_TMAX * kQCtx + id] = tmax;
     cstu[CF_GEOM * kQCtx + id] = unsigned(hit ? geom : -1);
     cstu[CF_PRIM * kQCtx + id] = unsigned(prim);
     // (geom is the packed primitive word: the emissive flag rides along, no record fetch needed)
     const bool terminal = !hit || (geom & kPrimEmissiveBit) != 0 || st.length() + 1 >= S.max_path_length;
     to_shade = !terminal;
     to_term = terminal;
+  };
+  // When does a wave stop a traversal and park the lanes still travelling?  When fewer than trav_min_lanes of them are
+  // left after trav_min_trips trips AND the workgroup has other work queued (otherwise they may as well finish here).
+  const int trav_min_lanes = W.trav_min_lanes, trav_min_trips = W.trav_min_trips;
+  auto other_work = [&]() -> bool {
+    unsigned n = 0;
+#pragma unroll
+    for (int q = 0; q < kNQ; q++) n += lds_load(&qctl[QC_TAIL + q]) - lds_load(&qctl[QC_HEAD + q]);
+    return __builtin_amdgcn_readfirstlane(n) >= 48u;
+  };
+  auto run_trav = [&](auto any_tag, DRay& ray, TravState& ts) {
+    constexpr bool ANY = decltype(any_tag)::value;
+    // (the policy check reads the queue counters, so it runs between bursts of trips, not in every trip)
+    int min_trips = trav_min_trips;
+    while (true) {
+      trav_run<ANY, F, kQBlock>(V, ray, ts, stack, trav_min_lanes, min_trips);
+      const unsigned long long left = __ballot(ts.done == 0);
+      if (left == 0 || other_work()) break;
+      min_trips = 8;  // nothing else to do: keep going, look again in a few trips
+      if (__popcll(left) >= trav_min_lanes) min_trips = trav_min_trips;
+    }
+  };
+  auto trav_record = [&](int id) -> uint32_t* { return ctxg + (ctx_base + size_t(id)) * kQCtxGlobalDwords + kQCtxTravOffset; };
+  // trace the context's new ray (closest hit), record the hit, classify (finish_hit).  X variants: a lane whose
+  // traversal is stopped parks it and the context goes to XC.
+  auto extend = [&](int id, f3 o, f3 d, float tmax, PackedState st, bool& to_shade, bool& to_term, bool& to_xc) {
+    DRay ray{o, d, 0.0f, tmax};
+    SEC_MARK(5);  // S: BSDF sample + fold store + spawn  /  T: camera ray
+    cstf[CF_OX * kQCtx + id] = o.x;
+    cstf[CF_OY * kQCtx + id] = o.y;
+    cstf[CF_OZ * kQCtx + id] = o.z;
+    cstf[CF_DX * kQCtx + id] = d.x;
+    cstf[CF_DY * kQCtx + id] = d.y;
+    cstf[CF_DZ * kQCtx + id] = d.z;
+    cstu[CF_ST * kQCtx + id] = st.v;
+    if constexpr (kX) {
+      TravState ts;
+      trav_begin(V, ts);
+      run_trav(std::false_type{}, ray, ts);
+      SEC_MARK(6);  // closest-hit traversal
+      if (!ts.done) {
+        cstf[CF_TMAX * kQCtx + id] = ray.tmax;
+        trav_park<kQBlock>(trav_record(id), ts, stack);
+        to_xc = true;
+      } else {
+        finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
+      }
+    } else {
+      int geom = -1, prim = 0;
+      const bool hit = scene_traverse<false, F, kQBlock>(V, ray, stack, geom, prim);
+      SEC_MARK(6);  // closest-hit traversal
+      finish_hit(id, hit, ray.tmax, geom, prim, st, to_shade, to_term);
+    }
   };
 
   unsigned shadow_count = 0, walk_count = 0;
@@ -238,23 +313,24 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     bool finished = false;
     {
       auto uload = [&](int w) -> unsigned { return __builtin_amdgcn_readfirstlane(lds_load(&qctl[w])); };
-      const unsigned h_s = uload(QC_HEAD + QS_S), h_t = uload(QC_HEAD + QS_T);  // heads first: heads and tails
-      unsigned h_w = 0;
-      if constexpr (F & F_SSS) h_w = uload(QC_HEAD + QS_W);
-      const unsigned t_s = uload(QC_TAIL + QS_S), t_t = uload(QC_TAIL + QS_T);  // only grow, so a count can only be over-estimated
-      unsigned t_w = 0;
-      if constexpr (F & F_SSS) t_w = uload(QC_TAIL + QS_W);
+      // heads first, then tails: heads and tails only grow, so a count can only be over-estimated
+      unsigned hq[kNQ], cq[kNQ];
+#pragma unroll
+      for (int q = 0; q < kNQ; q++) hq[q] = uload(QC_HEAD + q);
+#pragma unroll
+      for (int q = 0; q < kNQ; q++) cq[q] = uload(QC_TAIL + q) - hq[q];
       const unsigned busy = uload(QC_BUSY);
-      const unsigned cnt_s = t_s - h_s, cnt_t = t_t - h_t, cnt_w = t_w - h_w;
-      int best = cnt_t > cnt_s ? QS_T : QS_S;
-      unsigned cnt_best = cnt_t > cnt_s ? cnt_t : cnt_s;
-      unsigned h_best = cnt_t > cnt_s ? h_t : h_s;
-      if constexpr (F & F_SSS)
-        if (cnt_w > cnt_best) {
-          best = QS_W;
-          cnt_best = cnt_w;
-          h_best = h_w;
+      int best = cq[QS_T] > cq[QS_S] ? QS_T : QS_S;
+      unsigned cnt_best = cq[best], h_best = hq[best], cnt_all = cq[QS_S] + cq[QS_T];
+#pragma unroll
+      for (int q = 2; q < kNQ; q++) {
+        cnt_all += cq[q];
+        if (cq[q] > cnt_best) {
+          best = q;
+          cnt_best = cq[q];
+          h_best = hq[q];
         }
+      }
       if (cnt_best >= 64u || (cnt_best > 0u && (busy == 0u || spins >= 8u))) {
         // count ourselves busy BEFORE taking items out of the queue, so that "all queues empty and
         // nobody busy" really means no work can appear any more (idle pollers never touch the
@@ -273,7 +349,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           h = h0;
         }
       } else {
-        finished = cnt_s == 0u && cnt_t == 0u && cnt_w == 0u && busy == 0u;
+        finished = cnt_all == 0u && busy == 0u;
       }
     }
     if (__builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_ABORT])) != 0u) break;
@@ -288,8 +364,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       if (now - idle_since > W.idle_budget_ticks) {
         if (lane == 0)
           bail(1, lds_load(&qctl[QC_BUSY]),
-               (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 12) |
-                   ((lds_load(&qctl[QC_TAIL + 2]) - lds_load(&qctl[QC_HEAD + 2])) << 24));
+               (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 16));
         break;
       }
       __builtin_amdgcn_s_sleep(4);
@@ -321,7 +396,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
     if (stage == QS_S) {
       // ================= shade a non-terminal vertex (path.cpp:91-120) =================
-      bool to_shade = false, to_term = false, to_walk = false;
+      bool to_shade = false, to_term = false, to_walk = false, to_xs = false, to_xc = false;
       if (valid) {
         const f3 ray_o{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
         const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
@@ -470,6 +545,23 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         }
         SEC_MARK(1);  // S: state load, surface, frame, material
         // ---- next-event estimation (path.cpp:98-113) ----
+        // The visibility test: traced here and now, or (X variants) deferred until the BSDF has been sampled -- then
+        // nothing but a handful of values is live across the traversal, and a parked shadow ray has a trivial
+        // continuation (clear the direct term it gated).  No draw depends on the result, so the sample streams are
+        // the same either way.
+        bool have_shadow = false;
+        DRay shadow_ray{};
+        auto shadow_test = [&](const DRay& sr) -> bool {
+          if constexpr (kX) {
+            have_shadow = true;
+            shadow_ray = sr;
+            return false;  // evaluated as if visible; cleared below when the ray turns out occluded
+          } else {
+            DRay r = sr;
+            int g2, p2;
+            return scene_traverse<true, F, kQBlock>(V, r, stack, g2, p2);
+          }
+        };
         f3 nee = mk3(0.0f);
         if (!start_walk && !bxdf_is_delta<F>(bx)) {
           const f2 u2 = sampler_get2d<kSM>(T, sampler);  // g++ order: get2d first (lightsampler.h:27)
@@ -501,9 +593,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               if (lvalid) {
                 const float ls_pdf = S.num_lights != 1 ? lpdf / float(S.num_lights) : lpdf;
                 shadow_count++;
-                DRay sr = spawn_ray(it.p, it.n, lw, ldist);
-                int g2, p2;
-                if (!scene_traverse<true, F, kQBlock>(V, sr, stack, g2, p2)) {
+                const DRay sr = spawn_ray(it.p, it.n, lw, ldist);
+                if (!shadow_test(sr)) {
                   bx.albedo = mp.albedo;
                   bx.albedo_over_pi = mp.albedo_over_pi;
                   const float cosine = absdot(lw, it.n);
@@ -528,11 +619,10 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               if (!is_zero(material_le(lmat, gs.n, -gs.w))) {
                 const float ls_pdf = S.num_lights != 1 ? gs.pdf / float(S.num_lights) : gs.pdf;
                 shadow_count++;
-                DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
-                int g2, p2;
+                const DRay sr = spawn_ray(it.p, it.n, gs.w, gs.distance);
                 SEC_MARK(2);  // S: sampler draws + light sampling
-                const bool occluded = scene_traverse<true, F, kQBlock>(V, sr, stack, g2, p2);
-                SEC_MARK(3);  // S: shadow traversal
+                const bool occluded = shadow_test(sr);
+                SEC_MARK(3);  // S: shadow traversal (the not-X variants)
                 if (!occluded) {
                   const f3 le = ld3(lmat->color);
                   bx.albedo = mp.albedo;
@@ -552,11 +642,27 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         bx.albedo = mp.albedo;
         bx.albedo_over_pi = mp.albedo_over_pi;
         DBsdfSample bs;
+        bs.f = mk3(0.0f);
+        bs.wo = mk3(0.0f);
+        bs.pdf = 1.0f;
+        bs.is_delta = false;
+        const bool continues = !start_walk && bxdf_sample<F, kSM>(bx, T, sampler, bs);
+        const f3 wo_world = mul(l2w, bs.wo);
+        const float cosine = absdot(wo_world, it.n);
+        // ---- X variants: the deferred shadow ray (resumable; a lane stopped in it parks and goes to XS) ----
+        bool parked_shadow = false;
+        TravState sts;
+        if constexpr (kX) {
+          sts.done = 1;
+          if (have_shadow) trav_begin(V, sts);
+          run_trav(std::true_type{}, shadow_ray, sts);
+          SEC_MARK(3);  // S: shadow traversal
+          parked_shadow = have_shadow && !sts.done;
+          if (have_shadow && sts.done && sts.hit_geom >= 0) nee = mk3(0.0f);  // occluded
+        }
         if (start_walk) {
           to_walk = true;  // (state stored above; the context continues in stage W)
-        } else if (bxdf_sample<F, kSM>(bx, T, sampler, bs)) {
-          const f3 wo_world = mul(l2w, bs.wo);
-          const float cosine = absdot(wo_world, it.n);
+        } else if (continues) {
           float4* q = fold_entry(id, pv_length);
           q[0] = make_float4(nee.x, nee.y, nee.z, bs.f.x);
           q[1] = make_float4(bs.f.y, bs.f.z, cosine / bs.pdf, bs.pdf);
@@ -567,7 +673,20 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           const DRay nr = spawn_ray(it.p, it.n, wo_world, kFloatMax);
           st.set_dim(sampler.dimension);
           st.next_vertex(bs.is_delta);
-          extend(id, nr.o, nr.d, nr.tmax, st, to_shade, to_term);
+          if (kX && parked_shadow) {
+            // the fold entry above holds the direct term as if visible; stage XS clears it if the ray is occluded, then
+            // traces the new ray, which waits in the context
+            cstf[CF_OX * kQCtx + id] = nr.o.x;
+            cstf[CF_OY * kQCtx + id] = nr.o.y;
+            cstf[CF_OZ * kQCtx + id] = nr.o.z;
+            cstf[CF_DX * kQCtx + id] = nr.d.x;
+            cstf[CF_DY * kQCtx + id] = nr.d.y;
+            cstf[CF_DZ * kQCtx + id] = nr.d.z;
+            cstf[CF_TMAX * kQCtx + id] = nr.tmax;
+            cstu[CF_ST * kQCtx + id] = st.v;
+          } else {
+            extend(id, nr.o, nr.d, nr.tmax, st, to_shade, to_term, to_xc);
+          }
         } else {
           // no continuation: the vertex resolves with lo = nee (path.cpp:121); stage T folds it
           f3 beta = mk3(1.0f);
@@ -580,13 +699,105 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           cstf[CF_DY * kQCtx + id] = Lo.y;
           cstf[CF_DZ * kQCtx + id] = Lo.z;
           cstu[CF_GEOM * kQCtx + id] = unsigned(-2);
-          to_term = true;
+          to_term = !(kX && parked_shadow);
+        }
+        if constexpr (kX) {
+          if (parked_shadow) {
+            uint32_t* rec = trav_record(id);
+            float4* r4 = reinterpret_cast<float4*>(rec);
+            r4[0] = make_float4(shadow_ray.o.x, shadow_ray.o.y, shadow_ray.o.z, shadow_ray.d.x);
+            r4[1] = make_float4(shadow_ray.d.y, shadow_ray.d.z, shadow_ray.tmax, __uint_as_float(continues ? 0u : kTravTerminalAfterShadow));
+            trav_park<kQBlock>(rec, sts, stack);
+            to_xs = true;
+          }
         }
       }
       SEC_MARK(9);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       push2(to_shade, to_term, id);
       if constexpr (F & F_SSS) push_w(to_walk, id);
+      if constexpr (kX) {
+        push_q(QS_XS, to_xs, id);
+        push_q(QS_XC, to_xc, id);
+      }
+    } else if (kX && (stage == QS_XS || stage == QS_XC)) {
+      // ================= parked traversals, regrouped (pine_trav.h) =================
+      bool to_shade = false, to_term = false, to_xs = false, to_xc = false;
+      if constexpr (kX) {
+        TravState ts;
+        ts.done = 1;
+        DRay ray{mk3(0.0f), mk3(1.0f), 0.0f, 0.0f};
+        PackedState st{0};
+        uint32_t* rec = nullptr;
+        bool closest = false;  // this lane has a closest-hit traversal to run in the second phase
+        auto context_ray = [&]() {
+          ray.o = f3{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
+          ray.d = f3{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
+          ray.tmin = 0.0f;
+          ray.tmax = cstf[CF_TMAX * kQCtx + id];
+        };
+        if (valid) {
+          rec = trav_record(id);
+          st.v = cstu[CF_ST * kQCtx + id];
+          trav_unpark<kQBlock>(rec, ts, stack);
+        }
+        if (stage == QS_XS) {
+          unsigned flags = 0;
+          if (valid) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec);
+            const float4 a = r4[0], b = r4[1];
+            ray = DRay{f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, 0.0f, b.z};
+            flags = __float_as_uint(b.w);
+          }
+          run_trav(std::true_type{}, ray, ts);
+          SEC_MARK(3);
+          if (valid) {
+            if (!ts.done) {
+              trav_park<kQBlock>(rec, ts, stack);  // (an any-hit query leaves the ray as it was)
+              to_xs = true;
+              ts.done = 1;
+            } else {
+              const bool occluded = ts.hit_geom >= 0;
+              if (flags & kTravTerminalAfterShadow) {
+                if (occluded) {  // Lo = min(beta * 0, 8) = 0
+                  cstf[CF_DX * kQCtx + id] = 0.0f;
+                  cstf[CF_DY * kQCtx + id] = 0.0f;
+                  cstf[CF_DZ * kQCtx + id] = 0.0f;
+                }
+                to_term = true;
+              } else {
+                if (occluded) {  // the vertex that cast this ray is one level up: its direct term is zero
+                  float4* q = fold_entry(id, st.length() - 1);
+                  const float4 e = q[0];
+                  q[0] = make_float4(0.0f, 0.0f, 0.0f, e.w);
+                }
+                context_ray();
+                trav_begin(V, ts);
+                closest = true;
+              }
+            }
+          }
+        } else if (valid) {
+          context_ray();  // (CF_TMAX holds the nearest hit so far)
+          closest = true;
+        }
+        run_trav(std::false_type{}, ray, ts);
+        SEC_MARK(6);
+        if (closest) {
+          if (!ts.done) {
+            cstf[CF_TMAX * kQCtx + id] = ray.tmax;
+            trav_park<kQBlock>(rec, ts, stack);
+            to_xc = true;
+          } else {
+            finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
+          }
+        }
+      }
+      SEC_MARK(9);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      push2(to_shade, to_term, id);
+      push_q(QS_XS, to_xs, id);
+      push_q(QS_XC, to_xc, id);
     } else if ((F & F_SSS) != 0 && stage == QS_W) {
       // ================= one step of a BSSRDF random walk (bxdf.cpp:340-351) =================
       bool to_walk = false, to_shade = false;
@@ -650,7 +861,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     } else {
       // ================= terminal: result, backward fold, store, next sample / item =================
       bool need_item = false, have_path = false;
-      bool to_shade2 = false, to_term2 = false;
+      bool to_shade2 = false, to_term2 = false, to_xc2 = false;
       bool fresh_rng = false;  // the context took a new work item this round: its RNG state is in item_rng, not yet in memory
       DRng item_rng{0, 0};
       unsigned pxy = 0, sample_base = 0;
@@ -837,11 +1048,12 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         st.start_sample(s_next);
         cstu[CF_PXY * kQCtx + id] = pxy;
         cstu[CF_SBASE * kQCtx + id] = sample_base;
-        extend(id, r.o, r.d, r.tmax, st, to_shade2, to_term2);
+        extend(id, r.o, r.d, r.tmax, st, to_shade2, to_term2, to_xc2);
       }
       SEC_MARK(9);  // state store + classification
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       push2(to_shade2, to_term2, id);
+      if constexpr (kX) push_q(QS_XC, to_xc2, id);
     }
     if (lane == 0) atomicSub(&qctl[QC_BUSY], 1u);
   }

@@ -1,0 +1,201 @@
+// pine_amd/csrc/pine_trav.h -- resumable BVH traversal for the stage-queued kernel (included by
+// pine_kernels.hip after SceneView / fetch_node; used by the F_LDS_TOP variants of pine_queue_kernel.h).
+//
+// Why: in scenes with a real BVH (10 000 cones, triangle meshes) the rays of one wave need wildly
+// different numbers of node visits; with one traversal per stage pass the wave runs until its longest ray
+// is done.  Measured on the round-1 structure: 12.8 % VALU lane utilisation on the Subsurface-icosphere
+// scene, 27.6 % on the 10 000-cone scene.  Here a traversal is an explicit per-lane state machine -- ONE
+// step per loop trip (a node visit, one leaf primitive, or a pop) -- that can stop at any trip boundary:
+// when too few lanes of the wave are still travelling, those lanes park their state (a few registers and
+// their stack entries) in the context's global record and the contexts go to a traversal queue, where
+// they are regrouped, 64 at a time, with the stragglers of other waves.
+//
+// The order of operations per ray is pine's exactly (src/pine/impl/accel/bvh.cpp:321-451, :497-548):
+// both child boxes are tested against the tmax captured when the node is visited, leaf children are
+// tested in stored order before the next node, the child with the larger exit distance is pushed.
+// Suspending and resuming does not change it: the state that continues is the state that stopped.
+#pragma once
+
+namespace pine_gpu {
+
+struct TravState {
+  int next;      // node to visit, -1 = none (pop)
+  int sp;        // entries of this lane on its LDS stack
+  int pa, pan;   // pending leaf primitives [pa, pa + pan), tested before anything else
+  int pb, pbn;   // ... then these
+  int mesh_base; // -1: in the top-level BVH; >= 0: inside a mesh BVH whose stack entries start here
+  int mesh_word; // packed primitive word of that mesh (reported as the hit geometry)
+  int r_next, r_pa, r_pan, r_pb, r_pbn;  // the top-level state that continues after the mesh
+  int hit_geom;  // closest hit so far: packed primitive word, -1 = none
+  int hit_prim;  // triangle index of a mesh hit
+  int done;      // 0 travelling, 1 finished
+};
+constexpr int kTravStateInts = 16;
+constexpr int kTravMaxStack = 32;                                   // entries a suspended record can hold
+constexpr int kTravRecordDwords = 8 + kTravStateInts + kTravMaxStack / 2;  // shadow ray 7 + flags | state | packed stack
+// flags word of a suspended record
+enum : unsigned { kTravTerminalAfterShadow = 1u };  // the vertex has no continuation: after the shadow ray the context goes to stage T
+
+__device__ __forceinline__ void trav_begin(const SceneView& S, TravState& ts) {
+  ts.next = -1;
+  ts.sp = 0;
+  ts.pa = ts.pan = ts.pb = ts.pbn = 0;
+  ts.mesh_base = -1;
+  ts.mesh_word = 0;
+  ts.r_next = -1;
+  ts.r_pa = ts.r_pan = ts.r_pb = ts.r_pbn = 0;
+  ts.hit_geom = -1;
+  ts.hit_prim = 0;
+  ts.done = 0;
+  if (S.num_shapes == 0) {
+    ts.done = 1;
+    return;
+  }
+  const DBvh top = S.bvhs[0];
+  if (top.root_count > 0) {  // the root itself is a leaf (bvh.cpp:331-334)
+    ts.pa = top.root_start;
+    ts.pan = top.root_count;
+  } else if (top.root >= 0) {
+    ts.next = top.root;
+  } else {
+    ts.done = 1;  // geometries exist but none has primitives
+  }
+}
+
+// Run the lanes whose `ts.done == 0` until every one is finished, or until fewer than `min_lanes` of the
+// wave are still travelling after at least `min_trips` trips (then the remaining lanes keep done == 0 and
+// the caller parks them).  ANY: BVH::hit (first hit ends the ray, hit_geom = 0); else BVH::intersect.
+template <bool ANY, unsigned F, int STRIDE, class StackT>
+__device__ __forceinline__ void trav_run(const SceneView& S, DRay& ray, TravState& ts, StackT* stack, int min_lanes, int min_trips) {
+  const DRayOct oct = make_oct(ray);
+  for (int trip = 0;; trip++) {
+    const unsigned long long travelling = __ballot(ts.done == 0);
+    if (travelling == 0) break;
+    if (trip >= min_trips && __popcll(travelling) < min_lanes) break;
+    if (ts.done) continue;
+    if (ts.pan > 0) {
+      // ---- one pending leaf primitive ----
+      const int i = ts.pa++;
+      ts.pan--;
+      if (ts.mesh_base >= 0) {
+        if constexpr (F & F_MESH) {
+          const float4* rec = S.tri_leaf + size_t(i) * 3;
+          const float4 a = rec[0], b = rec[1], c = rec[2];
+          const float v[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
+          if (ANY) {
+            if (tri_hit(v, ray)) {
+              ts.hit_geom = 0;
+              ts.done = 1;
+            }
+          } else if (tri_intersect(v, ray)) {
+            ts.hit_geom = ts.mesh_word;
+            ts.hit_prim = __float_as_int(c.y);
+          }
+        }
+      } else {
+        const DShape* sh = &S.leaf[i];
+        const int word = sh->kind;  // (the packed word rides in the copy's kind field)
+        const int kind = word >> kPrimKindShift;
+        bool is_mesh = false;
+        if constexpr (F & F_MESH) is_mesh = kind == SHAPE_MESH;
+        if (is_mesh) {
+          if constexpr (F & F_MESH) {
+            // descend into the mesh's BVH; the top-level traversal continues when it is exhausted
+            const DBvh mb = S.bvhs[as_int(sh->f[2])];
+            ts.r_next = ts.next, ts.r_pa = ts.pa, ts.r_pan = ts.pan, ts.r_pb = ts.pb, ts.r_pbn = ts.pbn;
+            ts.mesh_base = ts.sp;
+            ts.mesh_word = word;
+            ts.pb = ts.pbn = 0;
+            if (mb.root_count > 0) {
+              ts.next = -1;
+              ts.pa = mb.root_start;
+              ts.pan = mb.root_count;
+            } else {
+              ts.next = mb.root;
+              ts.pa = ts.pan = 0;
+            }
+          }
+        } else if (ANY) {
+          if (shape_hit<F>(kind, sh, ray)) {
+            ts.hit_geom = 0;
+            ts.done = 1;
+          }
+        } else if (shape_intersect<F>(kind, sh, ray)) {
+          ts.hit_geom = word;
+        }
+      }
+    } else if (ts.pbn > 0) {
+      ts.pa = ts.pb, ts.pan = ts.pbn;
+      ts.pbn = 0;
+    } else if (ts.next >= 0) {
+      // ---- one node: both child boxes against the tmax of this moment (bvh.cpp:405-446) ----
+      const DNode nd = fetch_node<F>(S, ts.next);
+      int l = -1, r = -1;
+      float t0 = ray.tmax, t1 = ray.tmax;
+      if (box_hit_oct(nd.lo0, nd.hi0, oct, ray.tmin, t0)) {
+        if (nd.count[0] == 0) l = nd.child[0];
+        else ts.pa = nd.child[0], ts.pan = nd.count[0];
+      }
+      if (box_hit_oct(nd.lo1, nd.hi1, oct, ray.tmin, t1)) {
+        if (nd.count[1] == 0) r = nd.child[1];
+        else if (ts.pan > 0) ts.pb = nd.child[1], ts.pbn = nd.count[1];
+        else ts.pa = nd.child[1], ts.pan = nd.count[1];
+      }
+      if (l != -1) {
+        if (r != -1) {
+          if (t0 > t1) {
+            stack[ts.sp * STRIDE] = StackT(l);
+            ts.next = r;
+          } else {
+            stack[ts.sp * STRIDE] = StackT(r);
+            ts.next = l;
+          }
+          ts.sp++;
+        } else ts.next = l;
+      } else ts.next = r;  // (-1 when neither child is an inner node to visit)
+    } else if (ts.sp > (ts.mesh_base >= 0 ? ts.mesh_base : 0)) {
+      ts.next = int(stack[(--ts.sp) * STRIDE]);
+    } else if (ts.mesh_base >= 0) {
+      // mesh exhausted: back to the top-level leaf it was a primitive of
+      ts.next = ts.r_next, ts.pa = ts.r_pa, ts.pan = ts.r_pan, ts.pb = ts.r_pb, ts.pbn = ts.r_pbn;
+      ts.mesh_base = -1;
+    } else {
+      ts.done = 1;
+    }
+  }
+}
+
+// Park / restore a travelling lane: the state words and the lane's stack entries to / from the context's
+// global record (dwords [8, 8 + kTravStateInts) and the packed stack after them).
+template <int STRIDE, class StackT>
+__device__ __forceinline__ void trav_park(uint32_t* rec, const TravState& ts, const StackT* stack) {
+  uint4* q = reinterpret_cast<uint4*>(rec + 8);
+  q[0] = make_uint4(unsigned(ts.next), unsigned(ts.sp), unsigned(ts.pa), unsigned(ts.pan));
+  q[1] = make_uint4(unsigned(ts.pb), unsigned(ts.pbn), unsigned(ts.mesh_base), unsigned(ts.mesh_word));
+  q[2] = make_uint4(unsigned(ts.r_next), unsigned(ts.r_pa), unsigned(ts.r_pan), unsigned(ts.r_pb));
+  q[3] = make_uint4(unsigned(ts.r_pbn), unsigned(ts.hit_geom), unsigned(ts.hit_prim), 0u);
+  uint32_t* sw = rec + 8 + kTravStateInts;
+  for (int i = 0; i < ts.sp; i += 2) {
+    const unsigned lo = unsigned(stack[i * STRIDE]) & 0xffffu;
+    const unsigned hi = i + 1 < ts.sp ? unsigned(stack[(i + 1) * STRIDE]) & 0xffffu : 0u;
+    sw[i >> 1] = lo | (hi << 16);
+  }
+}
+template <int STRIDE, class StackT>
+__device__ __forceinline__ void trav_unpark(const uint32_t* rec, TravState& ts, StackT* stack) {
+  const uint4* q = reinterpret_cast<const uint4*>(rec + 8);
+  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  ts.next = int(a.x), ts.sp = int(a.y), ts.pa = int(a.z), ts.pan = int(a.w);
+  ts.pb = int(b.x), ts.pbn = int(b.y), ts.mesh_base = int(b.z), ts.mesh_word = int(b.w);
+  ts.r_next = int(c.x), ts.r_pa = int(c.y), ts.r_pan = int(c.z), ts.r_pb = int(c.w);
+  ts.r_pbn = int(d.x), ts.hit_geom = int(d.y), ts.hit_prim = int(d.z);
+  ts.done = 0;
+  const uint32_t* sw = rec + 8 + kTravStateInts;
+  for (int i = 0; i < ts.sp; i += 2) {
+    const unsigned w = sw[i >> 1];
+    stack[i * STRIDE] = StackT(w & 0xffffu);
+    if (i + 1 < ts.sp) stack[(i + 1) * STRIDE] = StackT(w >> 16);
+  }
+}
+
+}  // namespace pine_gpu

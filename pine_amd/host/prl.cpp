@@ -48,14 +48,16 @@ struct Error {
 // psl number conversions (src/psl/string.cpp:158-201, :118-136) -- restated, binary32 arithmetic
 // ------------------------------------------------------------------------------------------------
 static int psl_stoi(const std::string& str) {
-  int number = 0;
+  // (the reference accumulates in a signed int; a literal beyond 2^31 overflows it -- undefined in C++, two's-complement
+  //  wrap-around in the reference's x86-64 build, which is what the unsigned arithmetic here defines and reproduces)
+  unsigned number = 0;
   bool neg = false;
   for (size_t j = 0; j < str.size(); j++) {
     if (str[j] == '.') break;
     if (j == 0 && str[j] == '-') neg = true;
-    else number = number * 10 + str[j] - '0';
+    else number = number * 10u + unsigned(int(str[j])) - unsigned('0');
   }
-  return neg ? -number : number;
+  return int(neg ? 0u - number : number);
 }
 static float psl_stof(const std::string& str) {
   float number = 0.0f;

@@ -136,6 +136,63 @@ def test_film_finalize_u8():
     assert tuple(out[0, 1, :3]) == (0, 0, 0)
 
 
+def _decode_png_rgba8(path):
+    """Minimal PNG reader for the files this repo writes (RGBA8, filter type 0 on every row)."""
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(b):
+        n, tag = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        if tag == b"IHDR":
+            w, h, depth, colour = struct.unpack(">IIBB", data[:10])
+            assert (depth, colour) == (8, 6)
+        elif tag == b"IDAT":
+            idat += data
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + 4 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.parametrize("tag", ["hdr", "cbox"])
+@pytest.mark.parametrize("tm", ["uncharted2", "aces"])
+def test_film_finalize_equals_the_reference_byte_for_byte(tag, tm, tmp_path):
+    """pine_gpu_film_finalize_u8 against what the REAL reference's film.save() produces
+    (Film::finalize film.cpp:19-25, tone mappers color.cpp:6-23, y flip fileio.h:33-38, gamma + x256 clamp
+    fileio.cpp:42-54; tests/golden/finalize.npz is made by `pine_ref finalize`, whose PNG decodes to the same
+    bytes): an HDR film with values far above 1, exact zeros, denormal-small values, w != 1 and a ragged size,
+    and a rendered cbox film.  Then the PNG round trip of this repo's two writers."""
+    import subprocess
+    import pine_amd as pa
+    d = np.load(os.path.join(ROOT, "tests", "golden", "finalize.npz"))
+    film = d[tag + "_film"]
+    h, w = film.shape[:2]
+    f = pa.Film([w, h], pa.ACES() if tm == "aces" else pa.Uncharted2())
+    f.pixels = film.copy()
+    out = f.finalize_u8()
+    want = d[f"{tag}_{tm}_u8"]
+    assert out.shape == want.shape and np.array_equal(out, want)
+    path = str(tmp_path / "a.png")
+    f.save(path)
+    assert np.array_equal(_decode_png_rgba8(path), want)
+    # the C++ writer (pine_amd/host/png_writer.hpp) through a tiny program
+    src = tmp_path / "w.cpp"
+    src.write_text('#include "png_writer.hpp"\n#include <cstdio>\n#include <vector>\nint main(int c, char** v) { int w = atoi(v[2]), h = atoi(v[3]); '
+                   'std::vector<unsigned char> p(size_t(w) * h * 4); FILE* f = fopen(v[1], "rb"); if (!f || fread(p.data(), 1, p.size(), f) != p.size()) return 2; '
+                   'fclose(f); return png_writer::write_rgba8(v[4], w, h, p.data()) ? 0 : 1; }\n')
+    exe = tmp_path / "w"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "pine_amd", "host"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want.tofile(tmp_path / "in.u8")
+    assert subprocess.run([str(exe), str(tmp_path / "in.u8"), str(w), str(h), str(tmp_path / "b.png")]).returncode == 0
+    assert np.array_equal(_decode_png_rgba8(str(tmp_path / "b.png")), want)
+
+
 def test_no_gpu_means_loud_failure():
     """The product never falls back to a CPU path: without a device, rendering raises."""
     import torch

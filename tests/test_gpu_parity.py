@@ -525,3 +525,29 @@ def test_plan_limits_are_errors_not_wraparound():
         pa.Plan(scenes.cbox((70000, 8)), 1, 2)
     with pytest.raises(pa.PineError, match="2\\^32"):
         pa.Plan(scenes.cbox((4096, 4096)), pa.SobolSampler(512), 2)
+
+
+@pytest.mark.parametrize("min_lanes,min_trips", [(24, 8), (64, 1)])
+def test_parked_and_regrouped_traversals_change_nothing(oracle, monkeypatch, path_kernel, min_lanes, min_trips):
+    """pine_trav.h: a traversal that is stopped, parked in the context's global record and resumed in another
+    wave (stages XS / XC) continues exactly where it stopped.  Off by default; (64, 1) parks every lane after
+    every trip -- each node visit and each leaf primitive of each ray in a different wave."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    if path_kernel == "mega":
+        pytest.skip("the stage-queued kernel's machinery")
+    monkeypatch.setenv("PINE_GPU_TRAV_MIN_LANES", str(min_lanes))
+    monkeypatch.setenv("PINE_GPU_TRAV_MIN_TRIPS", str(min_trips))
+    cases = [(scenes.classic_cones((96, 48), 40), 16, 6),
+             (scenes.sss((48, 48), 2), 16, 8),
+             (scenes.sss((40, 40), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True), 16, 6),
+             (scenes.lights_zoo((40, 40)), 8, 5)]
+    # lights_zoo is a cbox-class scene (whole scene in LDS: no resumable traversal) unless LDS staging is refused
+    for i, (sc, spp, depth) in enumerate(cases):
+        if i == 3:
+            monkeypatch.setenv("PINE_GPU_NO_LDS_SCENE", "1")
+        w, h = sc.camera.film().size
+        f, st = _render(sc, spp, depth)
+        assert st.block_threads == 1024
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
+        assert_bit_equal(f, ref, f"parked traversals, case {i}")

@@ -1,0 +1,28 @@
+"""CPU: the AddressSanitizer + UndefinedBehaviorSanitizer leg.  tools/sanitize builds the host code
+that handles caller-supplied data -- pine_amd/csrc/pine_host.cpp (scene building, BVH build, node folding, film
+finalize), pine_amd/host/prl.cpp (the parser / interpreter of untrusted script text) -- and the oracle with
+-fsanitize=address,undefined, and runs CPU tests and a mutation fuzzer of the PRL front-end against those
+libraries.  A sanitizer report aborts the child process, so a zero exit status means there was none.
+(GPU AddressSanitizer is not available on this pool: the device entry points of the sanitizer build fail as on a
+host without a GPU, tools/sanitize/nogpu_entry_points.cpp.)"""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(os.environ.get("PINE_SANITIZER_RUN") == "1", reason="already inside the sanitizer run")
+def test_host_code_is_clean_under_asan_and_ubsan():
+    if not shutil.which("g++") or not os.path.exists(subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()):
+        pytest.skip("no g++ / libasan here")
+    env = dict(os.environ, PINE_FUZZ_MUTANTS="120")
+    r = subprocess.run([os.path.join(ROOT, "tools", "sanitize", "run.sh"), "tests/test_prl.py", "tests/test_abi.py", "-m", "not gpu",
+                        "-k", "not bench and not product_does_not"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "0 crashes" in r.stdout and " passed" in r.stdout, tail
+    assert "runtime error" not in tail and "AddressSanitizer" not in tail

@@ -101,8 +101,45 @@ def other_config_stats(tmp, stats, only=None):
         print(name, stats[name], flush=True)
 
 
+def finalize_fixture(tmp):
+    """(f)2 film finalize + save: the reference's own Film::finalize / invert_y / to_uint8_array / stb PNG on a
+    synthetic HDR film (values above 1, exact zeros, tiny values, a ragged size) and on a rendered golden film, for
+    both tone mappers -> tests/golden/finalize.npz (inputs, expected RGBA8, and the reference's PNG decoded)."""
+    from PIL import Image
+    rng = np.random.default_rng(2025)
+    w, h = 37, 23
+    hdr = np.zeros((h, w, 4), dtype=np.float32)
+    hdr[..., :3] = (10.0 ** rng.uniform(-4, 2.5, (h, w, 3))).astype(np.float32)
+    hdr[..., 3] = 1.0
+    hdr[0, :5, :3] = 0.0          # exact zeros
+    hdr[1, :5, :3] = 600.0        # a visible light source
+    hdr[2, :5, :3] = np.float32(1e-30)
+    hdr[3, :5, 3] = 7.0           # finalize overwrites w
+    rendered = np.load(os.path.join(OUT, "film_cbox_readme_64_s16_d4.npz"))
+    rendered = rendered["film"].astype(np.float32).reshape(64, 64, 4)
+    out = {}
+    for tag, film in (("hdr", hdr), ("cbox", rendered)):
+        fh, fw = film.shape[:2]
+        fin = os.path.join(tmp, "f.bin")
+        film.tofile(fin)
+        out[tag + "_film"] = film
+        for tm, tmname in ((0, "uncharted2"), (1, "aces")):
+            u8p, pngp = os.path.join(tmp, "o.u8"), os.path.join(tmp, "o.png")
+            run_ref("finalize", fin, fw, fh, tm, u8p, pngp)
+            u8 = np.fromfile(u8p, dtype=np.uint8).reshape(fh, fw, 4)
+            png = np.asarray(Image.open(pngp).convert("RGBA"))
+            assert np.array_equal(png, u8), "the reference's PNG must decode to its own uint8 array"
+            out[f"{tag}_{tmname}_u8"] = u8
+    np.savez_compressed(os.path.join(OUT, "finalize.npz"), **out)
+    print("finalize.npz", {k: v.shape for k, v in out.items()})
+
+
 def main():
     full = "--full" in sys.argv
+    if "--finalize-only" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            finalize_fixture(tmp)
+        return
     os.makedirs(OUT, exist_ok=True)
     only = next((a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--stats-only=")), None)
     if only:  # just (re)render the named whole-image statistics entries with the real reference
@@ -206,6 +243,7 @@ def main():
             other_config_stats(tmp, stats)
             json.dump(stats, open(stats_path, "w"), indent=1)
         json.dump(meta, open(os.path.join(OUT, "films.json"), "w"), indent=1)
+        finalize_fixture(tmp)
 
 
 if __name__ == "__main__":
