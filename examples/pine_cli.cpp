@@ -19,11 +19,12 @@ int main(int argc, char** argv) {
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--dry-run")) flags |= PINE_PRL_DRY_RUN;
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--devices") && i + 1 < argc) setenv("PINE_GPU_DEVICES", argv[++i], 1);  // e.g. 0,1,2,3,4,5,6,7
     else if (!strcmp(argv[i], "--tables") && i + 1 < argc) pine_gpu_set_table_path(argv[++i]);
     else path = argv[i];
   }
   if (!path) {
-    fprintf(stderr, "Usage: pine-mi355x [--dry-run] [--device N] [--tables bluesobol_u8.bin] [filename]\n");
+    fprintf(stderr, "Usage: pine-mi355x [--dry-run] [--device N | --devices 0,1,...] [--tables bluesobol_u8.bin] [filename]\n");
     return 2;
   }
   std::ifstream f(path);

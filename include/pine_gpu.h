@@ -199,6 +199,16 @@ int pine_gpu_set_table_path(const char* path);
  * Array2d<vec4>, src/pine/core/array.h:51-55); includes upload + download.  Fails if no GPU. */
 int pine_gpu_path_render(pine_gpu_scene*, const pine_gpu_render_params*, float* film_out_host);
 
+/* The same on several devices of one node from ONE process (`pine_gpu_path_render(..., device_mask, ...)`):
+ * shard r of n -- 8x8-pixel tiles dealt round-robin, SURVEY.md 8(e) -- renders on the r-th selected device; the per-device
+ * tile slabs travel to the first device with peer copies (xGMI), are scattered into the film there and downloaded.  The film
+ * is bit-identical to the one-device film.  `prm->device / shard_rank / shard_world` are ignored.  The reference's
+ * counterpart is its thread pool over one shared film (src/pine/core/parallel.h:19-67, path.cpp:31-39).
+ * _multi: bit d of `device_mask` selects HIP device d.  _devices: an explicit list (a device may appear more than once). */
+int pine_gpu_path_render_multi(pine_gpu_scene*, const pine_gpu_render_params*, uint64_t device_mask, float* film_out_host);
+int pine_gpu_path_render_devices(pine_gpu_scene*, const pine_gpu_render_params*, const int* devices, int num_devices,
+                                 float* film_out_host);
+
 /* Resident form (bench / multi-GPU): build device state once, launch many times.
  * `film_dev` is a DEVICE pointer to W*H float4; `stream` is a hipStream_t (0 = default stream).
  * Pixels outside this rank's shard are written as zeros, so a sum-reduce over ranks is exact. */

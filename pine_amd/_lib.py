@@ -117,6 +117,8 @@ SIGNATURES = {
     "pine_gpu_shard_of_pixel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pine_gpu_set_table_path": (C.c_int, [C.c_char_p]),
     "pine_gpu_path_render": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), c_f_p]),
+    "pine_gpu_path_render_multi": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint64, c_f_p]),
+    "pine_gpu_path_render_devices": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.POINTER(C.c_int), C.c_int, c_f_p]),
     "pine_gpu_plan_create": (C.c_void_p, [C.c_void_p, C.POINTER(RenderParams)]),
     "pine_gpu_plan_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pine_gpu_plan_launch_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -601,10 +601,13 @@ class PathIntegrator:
     """PathIntegrator(sampler, max_path_length).render(scene) -- the convenience overload a .pine
     script uses (program_context.cpp:79-81); pine-BVH traversal order, UniformLightSampler."""
 
-    def __init__(self, sampler, max_path_length, device=0, flags=0):
+    def __init__(self, sampler, max_path_length, device=0, flags=0, devices=None):
+        """devices: a list of HIP device ordinals -- the film is rendered by all of them from this one process
+        (pine_gpu_path_render_devices); default: the single `device`."""
         if max_path_length <= 0:  # path.cpp:12-13
             raise PineError(f"`PathIntegrator` expect `max_path_length` to be positive, get {max_path_length}")
         self.sampler, self.max_path_length, self.device, self.flags = sampler, int(max_path_length), device, int(flags)
+        self.devices = list(devices) if devices else None
 
     def render(self, scene):
         if scene.camera is None:
@@ -613,6 +616,12 @@ class PathIntegrator:
         prm = _lib.RenderParams(self.sampler.requested, self.max_path_length, self.device, 0, 1, 0, self.flags,
                                 getattr(self.sampler, "kind", 0))
         out = np.zeros((film.size[1], film.size[0], 4), dtype=np.float32)
+        if self.devices:
+            arr = (C.c_int * len(self.devices))(*self.devices)
+            check(lib.pine_gpu_path_render_devices(scene._h, C.byref(prm), arr, len(self.devices), out.ctypes.data_as(_lib.c_f_p)),
+                  "PathIntegrator.render")
+            film.pixels = out
+            return film
         check(lib.pine_gpu_path_render(scene._h, C.byref(prm), out.ctypes.data_as(_lib.c_f_p)), "PathIntegrator.render")
         film.pixels = out
         return film

@@ -1276,6 +1276,62 @@ static int bvh_depth(const std::vector<DNode>& nodes, int node) {
   return d + 1;
 }
 
+// Everything the kernels index with comes from these host arrays: check every index against its array BEFORE anything
+// is uploaded or launched (an out-of-range access on the device can take the whole GPU down, for everyone on it).
+static int validate_device_scene(const FlatAccel& A, const std::vector<DShape>& shapes, size_t num_materials,
+                                 const std::vector<DLight>& lights, int stack_top, int stack_total) {
+  const int n_nodes = int(A.nodes.size()), n_prims = int(A.prims.size()), n_tris = int(A.tri_verts.size() / 9);
+  auto bad = [](const std::string& what) {
+    set_error("internal: inconsistent acceleration structure (" + what + ")");
+    return -1;
+  };
+  if (A.bvhs.empty()) return bad("no top-level BVH");
+  if (A.top_prim_begin < 0 || A.top_prim_begin > n_prims) return bad("top_prim_begin");
+  if (A.tri_leaf.size() != size_t(A.top_prim_begin) * 12) return bad("tri_leaf size");
+  for (size_t b = 0; b < A.bvhs.size(); b++) {
+    const DBvh& v = A.bvhs[b];
+    const int lo = b == 0 ? A.top_prim_begin : 0, hi = b == 0 ? n_prims : A.top_prim_begin;
+    if (v.root_count > 0) {
+      if (v.root_start < lo || v.root_start + v.root_count > hi) return bad("root leaf range");
+    } else if (v.root >= n_nodes || (v.root < 0 && b != 0)) return bad("root node");
+    // depth-first walk of this BVH: child indices, leaf ranges, depth against the stack the kernels get
+    std::vector<std::pair<int, int>> todo;
+    if (v.root_count == 0 && v.root >= 0) todo.push_back({v.root, 1});
+    size_t visited = 0;
+    while (!todo.empty()) {
+      const auto [node, depth] = todo.back();
+      todo.pop_back();
+      if (++visited > size_t(n_nodes)) return bad("cycle in the node graph");
+      if (depth > (b == 0 ? stack_top : stack_total - stack_top) + 1) return bad("tree deeper than the traversal stack");
+      for (int c = 0; c < 2; c++) {
+        const int ch = A.nodes[size_t(node)].child[c], cnt = A.nodes[size_t(node)].count[c];
+        if (cnt > 0) {
+          if (ch < lo || ch + cnt > hi) return bad("leaf range");
+        } else if (cnt < 0 || ch < 0 || ch >= n_nodes) return bad("child index");
+        else todo.push_back({ch, depth + 1});
+      }
+    }
+  }
+  for (int i = 0; i < A.top_prim_begin; i++) {
+    int tri;
+    memcpy(&tri, &A.tri_leaf[size_t(i) * 12 + 9], 4);
+    if (tri < 0 || tri >= n_tris) return bad("triangle index of a leaf record");
+  }
+  for (int i = A.top_prim_begin; i < n_prims; i++)
+    if (A.prims[size_t(i)] < 0 || A.prims[size_t(i)] >= int(shapes.size())) return bad("geometry index of a top-level primitive");
+  for (const DShape& sh : shapes) {
+    if (sh.material < 0 || size_t(sh.material) >= num_materials) return bad("material index");
+    if (sh.kind == SHAPE_MESH) {
+      int first, count, bvh;
+      memcpy(&first, &sh.f[0], 4), memcpy(&count, &sh.f[1], 4), memcpy(&bvh, &sh.f[2], 4);
+      if (count > 0 && (bvh < 1 || bvh >= int(A.bvhs.size()) || first < 0 || first + count > n_tris)) return bad("mesh record");
+    }
+  }
+  for (const DLight& L : lights)
+    if (L.kind == LIGHT_AREA && (L.geom < 0 || L.geom >= int(shapes.size()))) return bad("area light geometry");
+  return 0;
+}
+
 }  // namespace pine_gpu
 
 using namespace pine_gpu;
@@ -1545,6 +1601,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   S.stack_top = d_top;
   S.stack_total = std::max(1, d_top + d_mesh);
+  if (validate_device_scene(A, shapes, dev_materials.size(), light_list, S.stack_top, S.stack_total)) return -1;
   p->lds_bytes = kLdsFixedBytes + size_t(S.stack_total) * kBlock * sizeof(int);
   if (p->lds_bytes > 64 * 1024) {
     set_error("BVH too deep for the LDS traversal stack");
@@ -1966,6 +2023,119 @@ int pine_gpu_path_render(pine_gpu_scene* scene, const pine_gpu_render_params* pr
   pine_gpu_plan_destroy(p);
   if (rc) set_error(keep);
   return rc;
+}
+
+/* One process, several devices: shard r of n (8x8-pixel tiles dealt round-robin) renders on devices[r];
+ * every device writes its tiles into a packed slab, the slabs are copied device-to-device (peer copies over xGMI) into
+ * one [rank][slab] buffer on devices[0], scattered into the row-major film there and downloaded.  Bit-identical to the
+ * one-device film for any list (the same device may appear more than once).  This is what the C++ facade and the PRL
+ * command line use to drive a whole node without torch.distributed. */
+int pine_gpu_path_render_devices(pine_gpu_scene* scene, const pine_gpu_render_params* prm, const int* devices, int num_devices,
+                                 float* film_out) {
+  if (!scene || !prm || !devices || !film_out || num_devices < 1 || num_devices > 64) {
+    set_error("bad argument");
+    return -1;
+  }
+  if (num_devices == 1) {
+    pine_gpu_render_params one = *prm;
+    one.device = devices[0];
+    one.shard_rank = 0;
+    one.shard_world = 1;
+    return pine_gpu_path_render(scene, &one, film_out);
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    set_error("no HIP device available: the PathIntegrator hot path requires an AMD GPU (no CPU fallback)");
+    return -1;
+  }
+  for (int r = 0; r < num_devices; r++)
+    if (devices[r] < 0 || devices[r] >= ndev) {
+      set_error("device ordinal out of range");
+      return -1;
+    }
+  std::vector<pine_gpu_plan*> plans(size_t(num_devices), nullptr);
+  std::vector<void*> slabs(size_t(num_devices), nullptr);
+  std::vector<hipStream_t> streams(size_t(num_devices), nullptr);
+  void *gathered = nullptr, *d_film = nullptr;
+  int rc = -1;
+  std::string err;
+  do {
+    bool ok = true;
+    for (int r = 0; r < num_devices && ok; r++) {
+      pine_gpu_render_params p = *prm;
+      p.device = devices[r];
+      p.shard_rank = r;
+      p.shard_world = num_devices;
+      plans[size_t(r)] = pine_gpu_plan_create(scene, &p);
+      ok = plans[size_t(r)] != nullptr;
+    }
+    if (!ok) break;
+    const int w = plans[0]->film_w, h = plans[0]->film_h;
+    const int64_t slab_floats = pine_gpu_packed_slab_floats(w, h, num_devices);
+    const size_t slab_bytes = size_t(slab_floats) * 4, film_bytes = size_t(w) * h * 16;
+    if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&gathered, slab_bytes * size_t(num_devices)) != hipSuccess ||
+        hipMalloc(&d_film, film_bytes) != hipSuccess) {
+      set_error("device allocation failed");
+      break;
+    }
+    for (int r = 0; r < num_devices && ok; r++) {
+      ok = hipSetDevice(devices[r]) == hipSuccess && hipStreamCreateWithFlags(&streams[size_t(r)], hipStreamNonBlocking) == hipSuccess &&
+           hipMalloc(&slabs[size_t(r)], slab_bytes) == hipSuccess;
+      if (ok && devices[r] != devices[0]) {
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, devices[r], devices[0]);
+        if (can) (void)hipDeviceEnablePeerAccess(devices[0], 0);  // (already enabled is fine; without peer access the copy is staged)
+        (void)hipGetLastError();
+      }
+    }
+    if (!ok) {
+      set_error("per-device setup failed");
+      break;
+    }
+    // all devices render concurrently; each slab goes to devices[0] on the rendering device's own stream as soon as it is ready
+    for (int r = 0; r < num_devices && ok; r++) {
+      ok = pine_gpu_plan_launch_packed(plans[size_t(r)], slabs[size_t(r)], streams[size_t(r)]) == 0 &&
+           hipMemcpyPeerAsync(static_cast<char*>(gathered) + size_t(r) * slab_bytes, devices[0], slabs[size_t(r)], devices[r], slab_bytes,
+                              streams[size_t(r)]) == hipSuccess;
+    }
+    if (!ok) {
+      if (err.empty()) set_error(std::string("launch failed: ") + pine_gpu_last_error());
+      break;
+    }
+    for (int r = 0; r < num_devices && ok; r++) ok = pine_gpu_plan_check(plans[size_t(r)]) == 0;  // waits for the stream, reports bail-outs
+    if (!ok) break;
+    if (pine_gpu_film_unpack(w, h, num_devices, devices[0], gathered, d_film, nullptr)) break;
+    if (hipMemcpy(film_out, d_film, film_bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      set_error("film download failed");
+      break;
+    }
+    rc = 0;
+  } while (0);
+  const std::string keep = rc ? pine_gpu_last_error() : "";
+  for (int r = 0; r < num_devices; r++) {
+    (void)hipSetDevice(devices[r]);
+    if (plans[size_t(r)]) pine_gpu_plan_destroy(plans[size_t(r)]);
+    if (slabs[size_t(r)]) (void)hipFree(slabs[size_t(r)]);
+    if (streams[size_t(r)]) (void)hipStreamDestroy(streams[size_t(r)]);
+  }
+  (void)hipSetDevice(devices[0]);
+  if (gathered) (void)hipFree(gathered);
+  if (d_film) (void)hipFree(d_film);
+  if (rc) set_error(keep);
+  return rc;
+}
+
+/* SURVEY.md 8(b)'s form: bit d of device_mask selects HIP device d; shards are dealt to the selected devices in
+ * ascending order. */
+int pine_gpu_path_render_multi(pine_gpu_scene* scene, const pine_gpu_render_params* prm, uint64_t device_mask, float* film_out) {
+  int list[64], n = 0;
+  for (int d = 0; d < 64; d++)
+    if (device_mask & (1ull << d)) list[n++] = d;
+  if (n == 0) {
+    set_error("empty device mask");
+    return -1;
+  }
+  return pine_gpu_path_render_devices(scene, prm, list, n, film_out);
 }
 
 // ---- device unit-test hooks -------------------------------------------------------------------

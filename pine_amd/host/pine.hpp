@@ -219,6 +219,11 @@ class PathIntegrator {
       : sampler_(sampler), max_path_length_(max_path_length), device_(device) {
     if (max_path_length <= 0) throw Error("`PathIntegrator` expect `max_path_length` to be positive");
   }
+  // render on several devices of the node from this one process (tiles dealt round-robin, slabs gathered with peer copies)
+  PathIntegrator& on_devices(std::vector<int> devices) {
+    devices_ = std::move(devices);
+    return *this;
+  }
   void render(Scene& scene) {
     pine_gpu_render_params p{};
     p.spp = sampler_.requested;
@@ -227,12 +232,17 @@ class PathIntegrator {
     p.shard_rank = 0;
     p.shard_world = 1;
     p.sampler = sampler_.kind;
-    check(pine_gpu_path_render(scene.handle(), &p, scene.camera.film_.pixels.data()), "PathIntegrator::render");
+    if (devices_.size() > 1)
+      check(pine_gpu_path_render_devices(scene.handle(), &p, devices_.data(), int(devices_.size()), scene.camera.film_.pixels.data()),
+            "PathIntegrator::render");
+    else
+      check(pine_gpu_path_render(scene.handle(), &p, scene.camera.film_.pixels.data()), "PathIntegrator::render");
   }
 
  private:
   Sampler sampler_;
   int max_path_length_, device_;
+  std::vector<int> devices_;
 };
 
 inline float get_progress() { return pine_gpu_progress(); }

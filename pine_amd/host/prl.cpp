@@ -1884,7 +1884,21 @@ Interp::Interp() {
     prm.shard_world = 1;
     prm.sampler = p->sampler;
     f->pixels.assign(size_t(f->w) * f->h * 4, 0.0f);
-    gpu_check(pine_gpu_path_render(s->h, &prm, f->pixels.data()), "PathIntegrator.render");
+    // $PINE_GPU_DEVICES = "0,1,2,...": render on those devices of the node from this one process (pine-mi355x --devices)
+    std::vector<int> devices;
+    if (const char* e = getenv("PINE_GPU_DEVICES")) {
+      for (const char* q = e; *q;) {
+        char* end = nullptr;
+        const long d = strtol(q, &end, 10);
+        if (end == q) break;
+        devices.push_back(int(d));
+        q = *end == ',' ? end + 1 : end;
+      }
+    }
+    if (devices.size() > 1)
+      gpu_check(pine_gpu_path_render_devices(s->h, &prm, devices.data(), int(devices.size()), f->pixels.data()), "PathIntegrator.render");
+    else
+      gpu_check(pine_gpu_path_render(s->h, &prm, f->pixels.data()), "PathIntegrator.render");
     in.last_film = f;
     return Value();
   });

@@ -551,3 +551,23 @@ def test_parked_and_regrouped_traversals_change_nothing(oracle, monkeypatch, pat
         assert st.block_threads == 1024
         ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
         assert_bit_equal(f, ref, f"parked traversals, case {i}")
+
+
+def test_one_process_several_devices_entry_point(oracle):
+    """pine_gpu_path_render_devices / _multi (SURVEY.md 8(b)'s device_mask form): shards on a list of devices, slabs
+    gathered with peer copies, one film -- bit-identical to the one-device render.  On the 1-GPU box the list names
+    device 0 three times (three plans, three streams, three slabs); ragged film: border tiles and an empty shard."""
+    import ctypes as C
+    import pine_amd as pa
+    from pine_amd import scenes, _lib
+    for sc, spp, depth in ((scenes.cbox((77, 45), "readme"), 16, 5), (scenes.sss((24, 24), 1), 8, 6), (scenes.cbox((9, 7)), 4, 3)):
+        one = pa.PathIntegrator(pa.BlueSampler(spp), depth).render(sc).pixels.copy()
+        for devs in ([0, 0], [0, 0, 0], [0] * 5):
+            many = pa.PathIntegrator(pa.BlueSampler(spp), depth, devices=devs).render(sc).pixels
+            assert_bit_equal(many, one, f"{len(devs)} shards in one process")
+        prm = _lib.RenderParams(spp, depth, 0, 0, 1, 0, 0, 0)
+        out = np.zeros_like(one)
+        _lib.check(_lib.lib.pine_gpu_path_render_multi(sc._h, C.byref(prm), 1, out.ctypes.data_as(_lib.c_f_p)))
+        assert_bit_equal(out, one, "device_mask = 1")
+        assert _lib.lib.pine_gpu_path_render_multi(sc._h, C.byref(prm), 0, out.ctypes.data_as(_lib.c_f_p)) < 0
+        assert _lib.lib.pine_gpu_path_render_multi(sc._h, C.byref(prm), 1 << 40, out.ctypes.data_as(_lib.c_f_p)) < 0

@@ -24,6 +24,8 @@ extern "C" {
 float pine_gpu_progress(void) { return 0.0f; }
 int pine_gpu_set_table_path(const char* path) { return path ? 0 : fail(); }
 int pine_gpu_path_render(pine_gpu_scene*, const pine_gpu_render_params*, float*) { return fail(); }
+int pine_gpu_path_render_multi(pine_gpu_scene*, const pine_gpu_render_params*, uint64_t, float*) { return fail(); }
+int pine_gpu_path_render_devices(pine_gpu_scene*, const pine_gpu_render_params*, const int*, int, float*) { return fail(); }
 pine_gpu_plan* pine_gpu_plan_create(pine_gpu_scene*, const pine_gpu_render_params*) {
   fail();
   return nullptr;
