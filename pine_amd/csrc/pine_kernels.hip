@@ -2094,9 +2094,19 @@ int pine_gpu_path_render_devices(pine_gpu_scene* scene, const pine_gpu_render_pa
     }
     // all devices render concurrently; each slab goes to devices[0] on the rendering device's own stream as soon as it is ready
     for (int r = 0; r < num_devices && ok; r++) {
-      ok = pine_gpu_plan_launch_packed(plans[size_t(r)], slabs[size_t(r)], streams[size_t(r)]) == 0 &&
-           hipMemcpyPeerAsync(static_cast<char*>(gathered) + size_t(r) * slab_bytes, devices[0], slabs[size_t(r)], devices[r], slab_bytes,
-                              streams[size_t(r)]) == hipSuccess;
+      char* dst = static_cast<char*>(gathered) + size_t(r) * slab_bytes;
+      ok = pine_gpu_plan_launch_packed(plans[size_t(r)], slabs[size_t(r)], streams[size_t(r)]) == 0;
+      if (!ok) break;
+      // (a peer copy between a device and itself is refused: "invalid device ordinal")
+      const hipError_t e = devices[r] == devices[0]
+                               ? hipMemcpyAsync(dst, slabs[size_t(r)], slab_bytes, hipMemcpyDeviceToDevice, streams[size_t(r)])
+                               : hipMemcpyPeerAsync(dst, devices[0], slabs[size_t(r)], devices[r], slab_bytes, streams[size_t(r)]);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error(std::string("slab copy to the first device failed: ") + hipGetErrorString(e));
+        err = "copy";
+        ok = false;
+      }
     }
     if (!ok) {
       if (err.empty()) set_error(std::string("launch failed: ") + pine_gpu_last_error());

@@ -98,9 +98,20 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   unsigned* const ring = reinterpret_cast<unsigned*>(lds_raw + kQOffRing);
   float* const cstf = reinterpret_cast<float*>(lds_raw + kQOffState);
   unsigned* const cstu = reinterpret_cast<unsigned*>(lds_raw + kQOffState);
-  // traversal stack: [slot][thread]; 16-bit node ids in the F_LDS_TOP variants (the host guarantees < 65536 nodes)
+  // Traversal stack: [slot][thread].  F_LDS_TOP variants: 16-bit node ids (the host guarantees < 65536 nodes), and both the
+  // stack and the sampler window are laid out PER WAVE ([wave][slot or row][lane]) in one region that the two share: a
+  // wave is in one stage at a time and stage S makes all its draws before it traces, so within a wave the window is dead
+  // when the stack is live.  (Sharing [row][thread] arrays of the whole workgroup is NOT safe: another wave's stack
+  // slots cover this wave's window rows while it still draws -- that version corrupted node ids and faulted.)
   using StackT = typename std::conditional<(F & F_LDS_TOP) != 0, unsigned short, int>::type;
-  StackT* const stack = reinterpret_cast<StackT*>(lds_raw + kQOffStack) + tid;
+  constexpr int kStride = (F & F_LDS_TOP) ? 64 : kQBlock;  // element stride between stack slots / window rows of one thread
+  size_t wave_region_bytes = 0;
+  if constexpr (F & F_LDS_TOP) {
+    wave_region_bytes = size_t(S.stack_total) * 64 * sizeof(StackT);
+    if (wave_region_bytes < size_t(kQWinDwords) * 64 * 4) wave_region_bytes = size_t(kQWinDwords) * 64 * 4;
+  }
+  char* const wave_region = reinterpret_cast<char*>(lds_raw + kQOffStack) + size_t(tid >> 6) * wave_region_bytes;
+  StackT* const stack = (F & F_LDS_TOP) ? reinterpret_cast<StackT*>(wave_region) + lane : reinterpret_cast<StackT*>(lds_raw + kQOffStack) + tid;
 
   // ---- one-time staging ----
   {
@@ -246,7 +257,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     // (the policy check reads the queue counters, so it runs between bursts of trips, not in every trip)
     int min_trips = trav_min_trips;
     while (true) {
-      trav_run<ANY, F, kQBlock>(V, ray, ts, stack, trav_min_lanes, min_trips);
+      trav_run<ANY, F, kStride>(V, ray, ts, stack, trav_min_lanes, min_trips);
       const unsigned long long left = __ballot(ts.done == 0);
       if (left == 0 || other_work()) break;
       min_trips = 8;  // nothing else to do: keep going, look again in a few trips
@@ -273,14 +284,14 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       SEC_MARK(6);  // closest-hit traversal
       if (!ts.done) {
         cstf[CF_TMAX * kQCtx + id] = ray.tmax;
-        trav_park<kQBlock>(trav_record(id), ts, stack);
+        trav_park<kStride>(trav_record(id), ts, stack);
         to_xc = true;
       } else {
         finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
       }
     } else {
       int geom = -1, prim = 0;
-      const bool hit = scene_traverse<false, F, kQBlock>(V, ray, stack, geom, prim);
+      const bool hit = scene_traverse<false, F, kStride>(V, ray, stack, geom, prim);
       SEC_MARK(6);  // closest-hit traversal
       finish_hit(id, hit, ray.tmax, geom, prim, st, to_shade, to_term);
     }
@@ -412,23 +423,23 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         // (one L2 round trip instead of one per draw), and parked in this thread's LDS slots; draws
         // outside the window fall back to the byte-wise table path.
         const int wbase = (st.dim() >> 2) < 9 ? (st.dim() >> 2) : 9;  // (the device table has 64 bytes of wrap-around padding)
-        unsigned* const win = reinterpret_cast<unsigned*>(lds_raw + kQOffWin) + tid;
+        unsigned* const win = (F & F_LDS_TOP) ? reinterpret_cast<unsigned*>(wave_region) + lane : reinterpret_cast<unsigned*>(lds_raw + kQOffWin) + tid;
         {
           const int pix = int(pxy & 127u) + int((pxy >> 16) & 127u) * 128;
           const uint32_t* rk = reinterpret_cast<const uint32_t*>(S.tables.rank + size_t(pix) * 8) + wbase;
           const uint32_t w0 = rk[0], w1 = rk[1], w2 = rk[2];
           const uint2 sc = *reinterpret_cast<const uint2*>(S.tables.scramble + size_t(pix) * 8);
           win[0] = w0;
-          win[kQBlock] = w1;
-          win[2 * kQBlock] = w2;
-          win[3 * kQBlock] = sc.x;
-          win[4 * kQBlock] = sc.y;
+          win[kStride] = w1;
+          win[2 * kStride] = w2;
+          win[3 * kStride] = sc.x;
+          win[4 * kStride] = sc.y;
         }
         DTables T = S.tables;
         T.lds_sobol = reinterpret_cast<const uint8_t*>(lds_raw + kQOffSobol);
-        T.lds_tile = win - wbase * kQBlock;
-        T.lds_scr = win + 3 * kQBlock;
-        T.tile_stride = kQBlock;
+        T.lds_tile = win - wbase * kStride;
+        T.lds_scr = win + 3 * kStride;
+        T.tile_stride = kStride;
         T.win_lo = wbase * 4;
         T.win_len = (wbase * 4 + 12 <= kLdsSamplerDims ? 12 : kLdsSamplerDims - wbase * 4);
         DSampler sampler;
@@ -559,7 +570,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           } else {
             DRay r = sr;
             int g2, p2;
-            return scene_traverse<true, F, kQBlock>(V, r, stack, g2, p2);
+            return scene_traverse<true, F, kStride>(V, r, stack, g2, p2);
           }
         };
         f3 nee = mk3(0.0f);
@@ -707,7 +718,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             float4* r4 = reinterpret_cast<float4*>(rec);
             r4[0] = make_float4(shadow_ray.o.x, shadow_ray.o.y, shadow_ray.o.z, shadow_ray.d.x);
             r4[1] = make_float4(shadow_ray.d.y, shadow_ray.d.z, shadow_ray.tmax, __uint_as_float(continues ? 0u : kTravTerminalAfterShadow));
-            trav_park<kQBlock>(rec, sts, stack);
+            trav_park<kStride>(rec, sts, stack);
             to_xs = true;
           }
         }
@@ -739,7 +750,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         if (valid) {
           rec = trav_record(id);
           st.v = cstu[CF_ST * kQCtx + id];
-          trav_unpark<kQBlock>(rec, ts, stack);
+          trav_unpark<kStride>(rec, ts, stack);
         }
         if (stage == QS_XS) {
           unsigned flags = 0;
@@ -753,7 +764,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           SEC_MARK(3);
           if (valid) {
             if (!ts.done) {
-              trav_park<kQBlock>(rec, ts, stack);  // (an any-hit query leaves the ray as it was)
+              trav_park<kStride>(rec, ts, stack);  // (an any-hit query leaves the ray as it was)
               to_xs = true;
               ts.done = 1;
             } else {
@@ -786,7 +797,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         if (closest) {
           if (!ts.done) {
             cstf[CF_TMAX * kQCtx + id] = ray.tmax;
-            trav_park<kQBlock>(rec, ts, stack);
+            trav_park<kStride>(rec, ts, stack);
             to_xc = true;
           } else {
             finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
@@ -823,7 +834,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           if constexpr (F & F_MESH) walk_mesh = shape->kind == SHAPE_MESH;
           if (walk_mesh) {
             const DRayOct oct = make_oct(wr);
-            hh = mesh_traverse<false, kQBlock, F>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
+            hh = mesh_traverse<false, kStride, F>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
           } else {
             hh = shape_intersect<F>(shape, wr);
           }
