@@ -24,6 +24,9 @@
 #include <pine/core/rng.h>
 #include <pine/impl/integrator/path.h>
 #include <pine/impl/accel/bvh.h>
+#ifdef PINE_REF_WITH_EMBREE
+#include <pine/impl/accel/embree.h>
+#endif
 
 #include <chrono>
 #include <cstdio>
@@ -297,7 +300,21 @@ int main(int argc, char** argv) {
     // zero the film first: PathIntegrator::render does not clear it (path.cpp:38 plain store)
     L.scene.camera.film().clear();
     const bool halton = argc == 7 && std::string(argv[6]) == "halton";  // HaltonSampler(spp)
-    auto integ = PathIntegrator(Accel(BVH()),
+    // $PINE_REF_ACCEL=embree (the pine_ref_embree build only): EmbreeAccel, the accel a `.pine` script gets
+    // (program_context.cpp:79-81) -- SURVEY.md's oracle variant O-gcc-embree; default: pine's own BVH (O-gcc-bvh)
+    const char* accel_env = getenv("PINE_REF_ACCEL");
+    const bool embree = accel_env && std::string(accel_env) == "embree";
+#ifndef PINE_REF_WITH_EMBREE
+    if (embree) {
+      fprintf(stderr, "this binary was built without Embree (make -C oracle embree)\n");
+      return 2;
+    }
+#endif
+    auto integ = PathIntegrator(
+#ifdef PINE_REF_WITH_EMBREE
+                                embree ? Accel(EmbreeAccel()) :
+#endif
+                                Accel(BVH()),
                                 sobol ? Sampler(SobolSampler(spp)) : halton ? Sampler(HaltonSampler(spp)) : Sampler(BlueSobolSampler(spp)),
                                 UniformLightSampler(), depth);
     auto t0 = std::chrono::steady_clock::now();

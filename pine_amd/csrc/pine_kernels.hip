@@ -1808,6 +1808,7 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
   }
   hipStream_t stream = (hipStream_t)stream_;
   HIP_OK(hipSetDevice(p->device));
+  (void)hipGetLastError();  // (HIP's last error is sticky: what the check at the end reports must come from THIS launch's calls)
   g_progress.store(0.0f);
   const size_t film_bytes = size_t(p->film_w) * p->film_h * sizeof(float4);
   if (p->W.shard_world > 1 && !packed) HIP_OK(hipMemsetAsync(film_dev, 0, film_bytes, stream));

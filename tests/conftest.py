@@ -42,6 +42,30 @@ def assert_bit_equal(a, b, what=""):
     assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} values differ; first at {np.argwhere(bad)[0].tolist()}: {a[tuple(np.argwhere(bad)[0])]} vs {b[tuple(np.argwhere(bad)[0])]}"
 
 
+def film_distance(a, b):
+    """SURVEY.md 8(d)'s film metrics of `a` against the oracle film `b` (radiance clamped to 8, as the per-level
+    clamp bounds every non-emissive contribution): share of bit-identical pixels, share of pixels with per-pixel
+    relative L2 <= 1e-4, whole-image RMSE."""
+    a3 = np.minimum(np.asarray(a, dtype=np.float64)[..., :3], 8.0)
+    b3 = np.minimum(np.asarray(b, dtype=np.float64)[..., :3], 8.0)
+    identical = float((bits(a)[..., :3] == bits(b)[..., :3]).all(axis=-1).mean())
+    rel = np.linalg.norm(a3 - b3, axis=-1) / (np.linalg.norm(b3, axis=-1) + 1e-3)
+    return {"identical": identical, "within_1e-4": float((rel <= 1e-4).mean()), "rmse": float(np.sqrt(((a3 - b3) ** 2).mean()))}
+
+
+EMBREE_FILM_NAMES = ["embree_cbox_committed_64_s16_d4", "embree_cbox_readme_64_s16_d4", "embree_cbox_readme_64_s256_d8",
+                     "embree_cbox_rect_readme_64_s64_d5"]
+# What separates pine's own BVH order (reproduced here bit for bit) from EmbreeAccel (the `.pine` default) on each of
+# those films: measured once with the two real reference builds (tools/make_golden.py --embree; DESIGN.md 1).  The
+# Rect-only scene has no order-dependent shape: the two accels agree to the last bit.
+EMBREE_EXPECTED = {
+    "embree_cbox_committed_64_s16_d4": {"identical": (0.80, 0.86), "rmse": (0.02, 0.2)},
+    "embree_cbox_readme_64_s16_d4": {"identical": (0.35, 0.42), "rmse": (0.05, 0.3)},
+    "embree_cbox_readme_64_s256_d8": {"identical": (0.0, 0.01), "rmse": (0.05, 0.3)},  # (at 256 spp every pixel has a path that meets a box)
+    "embree_cbox_rect_readme_64_s64_d5": {"identical": (1.0, 1.0), "rmse": (0.0, 0.0)},
+}
+
+
 def load_film(name):
     z = np.load(os.path.join(GOLDEN, f"film_{name}.npz"))
     return z["film"], str(z["pscene"]), int(z["spp"]), int(z["depth"])

@@ -571,3 +571,24 @@ def test_one_process_several_devices_entry_point(oracle):
         assert_bit_equal(out, one, "device_mask = 1")
         assert _lib.lib.pine_gpu_path_render_multi(sc._h, C.byref(prm), 0, out.ctypes.data_as(_lib.c_f_p)) < 0
         assert _lib.lib.pine_gpu_path_render_multi(sc._h, C.byref(prm), 1 << 40, out.ctypes.data_as(_lib.c_f_p)) < 0
+
+
+@pytest.mark.parametrize("name", ["embree_cbox_readme_64_s16_d4", "embree_cbox_committed_64_s16_d4", "embree_cbox_rect_readme_64_s64_d5"])
+def test_gpu_film_against_both_oracles(name):
+    """the GPU film against BOTH oracles -- bit-equal to the reference with pine's own BVH (the order
+    this build reproduces), at the reference's own BVH-vs-Embree distance from the EmbreeAccel oracle,
+    and bit-equal to both on the Rect-only scene."""
+    from conftest import EMBREE_EXPECTED, film_distance
+    from pine_amd import scenes
+    emb, _, spp, depth = load_film(name)
+    bvh, _, _, _ = load_film(name.replace("embree_", ""))
+    sc = {"embree_cbox_readme_64_s16_d4": lambda: scenes.cbox((64, 64), "readme"),
+          "embree_cbox_committed_64_s16_d4": lambda: scenes.cbox((64, 64), "committed"),
+          "embree_cbox_rect_readme_64_s64_d5": lambda: scenes.cbox((64, 64), "readme", False)}[name]()
+    film, _ = _render(sc, spp, depth)
+    assert_bit_equal(film, bvh, "GPU vs O-gcc-bvh")
+    d = film_distance(film, emb)
+    lo, hi = EMBREE_EXPECTED[name]["identical"]
+    assert lo <= d["identical"] <= hi, d
+    if "rect" in name:
+        assert_bit_equal(film, emb, "GPU vs O-gcc-embree on the Rect-only scene")

@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, FILM_NAMES, SOBOL_FILM_NAMES, HALTON_FILM_NAMES, assert_bit_equal, load_film
+from conftest import (GOLDEN, FILM_NAMES, SOBOL_FILM_NAMES, HALTON_FILM_NAMES, EMBREE_FILM_NAMES, EMBREE_EXPECTED, assert_bit_equal,
+                      film_distance, load_film)
 
 
 @pytest.mark.parametrize("spp", [1, 16, 256])
@@ -153,3 +154,26 @@ def test_random_scenes_oracle_equals_the_reference_binary(oracle):
                            check=True, capture_output=True, timeout=120)
             ref = np.fromfile(fp, dtype=np.float32).reshape(h, w, 4)
         assert_bit_equal(mine, ref, f"random scene {seed}")
+
+
+@pytest.mark.parametrize("name", EMBREE_FILM_NAMES)
+def test_distance_to_the_embree_oracle(oracle, name):
+    """the second oracle, O-gcc-embree -- pine built with g++ and its EmbreeAccel, which is what a
+    `.pine` script gets (program_context.cpp:79-81).  This build reproduces pine's own BVH order (O-gcc-bvh) bit for
+    bit; against Embree's order the result is bit-identical on scenes without order-dependent shapes (Rect-only
+    cbox) and measurably different where a scaled Box(AABB, mat4) is clipped by the world tmax (bbox.cpp:144-172,
+    SURVEY.md Appendix A3).  The numbers pinned here are the reference's own BVH-vs-Embree distance."""
+    emb, ps, spp, depth = load_film(name)
+    h, w = emb.shape[:2]
+    film, _ = oracle.render(ps, (w, h), spp, depth)
+    bvh_name = name.replace("embree_", "")
+    ref_bvh, ps2, _, _ = load_film(bvh_name)
+    assert ps2 == ps  # the same scene description went to both reference builds
+    assert_bit_equal(film, ref_bvh, f"{bvh_name}: restatement vs the reference with pine's BVH")
+    d = film_distance(film, emb)
+    lo, hi = EMBREE_EXPECTED[name]["identical"]
+    assert lo <= d["identical"] <= hi, d
+    lo, hi = EMBREE_EXPECTED[name]["rmse"]
+    assert lo <= d["rmse"] <= hi, d
+    if "rect" in name:
+        assert_bit_equal(film, emb, "Rect-only cbox: both accels, both oracles, one film")

@@ -134,8 +134,39 @@ def finalize_fixture(tmp):
     print("finalize.npz", {k: v.shape for k, v in out.items()})
 
 
+EMBREE_FILMS = {
+    # SURVEY.md oracle variant O-gcc-embree (what a `.pine` script gets: program_context.cpp:79-81).  Rendered by
+    # oracle/_ref/pine_ref_embree (make -C oracle embree) with PINE_REF_ACCEL=embree.
+    "embree_cbox_committed_64_s16_d4": (lambda: scenes.cbox((64, 64), "committed"), 16, 4),
+    "embree_cbox_readme_64_s16_d4": (lambda: scenes.cbox((64, 64), "readme"), 16, 4),
+    "embree_cbox_readme_64_s256_d8": (lambda: scenes.cbox((64, 64), "readme"), 256, 8),
+    "embree_cbox_rect_readme_64_s64_d5": (lambda: scenes.cbox((64, 64), "readme", False), 64, 5),
+}
+
+
+def embree_fixtures(tmp):
+    global REF
+    exe = os.path.join(ROOT, "oracle", "_ref", "pine_ref_embree")
+    if not os.access(exe, os.X_OK):
+        raise SystemExit("oracle/_ref/pine_ref_embree missing: make -C oracle embree (about 8 minutes)")
+    keep, REF = REF, exe
+    os.environ["PINE_REF_ACCEL"] = "embree"
+    try:
+        for name, (build, spp, depth) in EMBREE_FILMS.items():
+            ps, film, info = ref_film(build(), spp, depth, tmp)
+            np.savez_compressed(os.path.join(OUT, f"film_{name}.npz"), film=film, pscene=ps, spp=spp, depth=depth)
+            print(name, film[..., :3].mean(axis=(0, 1)))
+    finally:
+        REF = keep
+        del os.environ["PINE_REF_ACCEL"]
+
+
 def main():
     full = "--full" in sys.argv
+    if "--embree" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            embree_fixtures(tmp)
+        return
     if "--finalize-only" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             finalize_fixture(tmp)
