@@ -57,6 +57,7 @@ class PlanStats(C.Structure):
 
 FLAG_TIMING = 1
 FLAG_PROGRESS = 2
+FLAG_FAST = 4
 FLAG_DEBUG_FORCE_BAIL = 0x100
 
 # every symbol include/pine_gpu.h declares, with its signature

@@ -31,8 +31,14 @@ PINE_HD float pabs(float v) { return fabsf(v); }
 // guards below are strictly inside those ranges; anything else (zero, denormal, huge, inf, NaN)
 // redoes the operation with the full expansion in a rarely taken branch.
 // (-DPINE_NO_SHORT_FORMS: plain expansions everywhere, for A/B runs.)
+// PINE_FAST_MATH (pine_kernels_fast.hip only -- the declared-tolerance variants behind PINE_GPU_FLAG_FAST): the hardware's
+// 1-ulp v_sqrt_f32 / v_rcp_f32 without refinement or range guards, the device's native sin / cos / pow / log instead of
+// the glibc-exact binary64 restatements, and (by that file's compile flags) contracted multiply-adds and reciprocal
+// division.  Never defined in the parity build.
 PINE_HD float psqrt(float v) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PINE_NO_SHORT_FORMS)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PINE_FAST_MATH)
+  return __builtin_amdgcn_sqrtf(v);
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(PINE_NO_SHORT_FORMS)
   const float y = __builtin_amdgcn_rsqf(v);
   const float s0 = v * y;
   const float h = 0.5f * y;
@@ -45,7 +51,9 @@ PINE_HD float psqrt(float v) {
 #endif
 }
 PINE_HD float prcp(float v) {  // == 1.0f / v
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PINE_NO_SHORT_FORMS)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PINE_FAST_MATH)
+  return __builtin_amdgcn_rcpf(v);
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(PINE_NO_SHORT_FORMS)
   const float r0 = __builtin_amdgcn_rcpf(v);
   const float e0 = __builtin_fmaf(-v, r0, 1.0f);
   float r1 = __builtin_fmaf(e0, r0, r0);
@@ -57,6 +65,16 @@ PINE_HD float prcp(float v) {  // == 1.0f / v
 #endif
 }
 // libm-exact sin/cos (see pine_libm.h); on the host these equal std::sin/std::cos of glibc.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PINE_FAST_MATH)
+PINE_HD float psin(float v) { return __sinf(v); }
+PINE_HD float pcos(float v) { return __cosf(v); }
+PINE_HD float ppow(float a, float b) { return __powf(a, b); }
+PINE_HD float plog(float v) { return __logf(v); }
+PINE_HD void psincos(float v, float& sn, float& cs) {
+  sn = __sinf(v);
+  cs = __cosf(v);
+}
+#else
 PINE_HD float psin(float v) { return pine_libm::sinf_glibc(v); }
 PINE_HD float pcos(float v) { return pine_libm::cosf_glibc(v); }
 // libm-exact pow / log (pine_libm.h): psl::pow == std::pow (src/psl/math.h:201-202), psl::log == std::log
@@ -65,6 +83,7 @@ PINE_HD float plog(float v) { return pine_libm::logf_glibc(v); }
 PINE_HD void psincos(float v, float& sn, float& cs) {
   pine_libm::sincosf_glibc(v, sn, cs);
 }
+#endif
 
 // ---- division ------------------------------------------------------------------------------------
 // `a / b` in device code is hipcc's IEEE-correct expansion (v_div_scale x2, v_rcp, 5 fma/mul, v_div_fmas,
