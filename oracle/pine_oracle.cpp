@@ -2740,6 +2740,39 @@ bool parse_pscene(const char* text, Scene& scene) {
         vec3 a = rd3(in), b = rd3(in), c = rd3(in);
         g.kind = S_TRIANGLE;
         g.impl = std::make_shared<Triangle>(a, b, c);
+      } else if (kind == "rect_state") {
+        // state-level records (pine_gpu_scene_add_*_state): the members of an already constructed object of the reference,
+        // in member order (geometry.h:92-96, :56-60, :23-25, :134-140, :115-117) -- set as they are, nothing recomputed
+        auto r = std::make_shared<Rect>(vec3(0, 0, 0), vec3(1, 0, 0), vec3(0, 1, 0), false);
+        r->position = rd3(in), r->ex = rd3(in), r->ey = rd3(in), r->n = rd3(in);
+        r->lx = rdf(in), r->ly = rdf(in);
+        r->rx = rd3(in), r->ry = rd3(in);
+        g.kind = S_RECT;
+        g.impl = r;
+      } else if (kind == "disk_state") {
+        auto d = std::make_shared<Disk>(vec3(0, 0, 0), vec3(0, 0, 1), 1.0f);
+        d->position = rd3(in), d->n = rd3(in), d->u = rd3(in), d->v = rd3(in);
+        d->r = rdf(in);
+        g.kind = S_DISK;
+        g.impl = d;
+      } else if (kind == "plane_state") {
+        auto pl = std::make_shared<Plane>(vec3(0, 0, 0), vec3(0, 0, 1));
+        pl->position = rd3(in), pl->n = rd3(in), pl->u = rd3(in), pl->v = rd3(in);
+        g.kind = S_PLANE;
+        g.impl = pl;
+      } else if (kind == "cone_state") {
+        auto c = std::make_shared<Cone>(vec3(0, 0, 0), vec3(0, 0, 1), 1.0f, 1.0f);
+        c->p = rd3(in), c->n = rd3(in);
+        c->r = rdf(in), c->h = rdf(in), c->A = rdf(in), c->A2 = rdf(in), c->S = rdf(in);
+        c->bottom.position = rd3(in);  // (of the bottom Disk only the centre and the radius are ever read: Cone::get_aabb, area)
+        c->bottom.r = c->r;
+        g.kind = S_CONE;
+        g.impl = c;
+      } else if (kind == "triangle_state") {
+        auto t = std::make_shared<Triangle>(vec3(0, 0, 0), vec3(1, 0, 0), vec3(0, 1, 0));
+        t->v0 = rd3(in), t->v1 = rd3(in), t->v2 = rd3(in), t->n = rd3(in);
+        g.kind = S_TRIANGLE;
+        g.impl = t;
       } else if (kind == "mesh") {
         int nv, nt;
         in >> nv >> nt;
@@ -2807,6 +2840,18 @@ bool parse_pscene(const char* text, Scene& scene) {
       std::string kind;
       int W, H;
       in >> kind >> W >> H;
+      if (kind == "thinlens_state") {  // the members of a constructed ThinLenCamera (camera.h:21-26), as they are
+        Camera& c = scene.camera;
+        c.W = W, c.H = H;
+        c.position = rd3(in);
+        const vec3 cx = rd3(in), cy = rd3(in), cz = rd3(in);
+        c.c2w = mat3(cx, cy, cz);
+        const float fx = rdf(in), fy = rdf(in);  // (two reads in one argument list would be evaluated right to left by g++)
+        c.fov2d = vec2(fx, fy);
+        c.len_radius = rdf(in);
+        c.focus_distance = rdf(in);
+        continue;
+      }
       vec3 from = rd3(in), to = rd3(in);
       float fov = rdf(in), lr = rdf(in), fd = rdf(in);
       scene.camera.init(W, H, from, to, fov, lr, fd);

@@ -110,8 +110,16 @@ SIGNATURES = {
     "pine_gpu_scene_add_line": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_int]),
     "pine_gpu_scene_add_cylinder": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_int]),
     "pine_gpu_scene_add_triangle": (C.c_int, [C.c_void_p, f3, f3, f3, C.c_int]),
+    "pine_gpu_scene_add_rect_state": (C.c_int, [C.c_void_p, f3, f3, f3, f3, C.c_float, C.c_float, f3, f3, C.c_int]),
+    "pine_gpu_scene_add_disk_state": (C.c_int, [C.c_void_p, f3, f3, f3, f3, C.c_float, C.c_int]),
+    "pine_gpu_scene_add_plane_state": (C.c_int, [C.c_void_p, f3, f3, f3, f3, C.c_int]),
+    "pine_gpu_scene_add_cone_state": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, f3, C.c_int]),
+    "pine_gpu_scene_add_triangle_state": (C.c_int, [C.c_void_p, f3, f3, f3, f3, C.c_int]),
     "pine_gpu_scene_add_mesh": (C.c_int, [C.c_void_p, c_f_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int]),
     "pine_gpu_scene_set_camera_thinlens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f3, f3, C.c_float, C.c_float, C.c_float]),
+    "pine_gpu_scene_set_camera_thinlens_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f3, C.c_float * 9, C.c_float * 2, C.c_float, C.c_float]),
+    "pine_gpu_scene_shape_record": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "pine_gpu_scene_camera_record": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "pine_gpu_scene_describe": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "pine_gpu_scene_build_accel": (C.c_int, [C.c_void_p]),
     "pine_gpu_scene_accel_dump": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int64]),

@@ -1215,6 +1215,81 @@ int pine_gpu_scene_add_triangle(pine_gpu_scene* s, const float v0_[3], const flo
   g.describe = "shape triangle " + matref(s, material) + " " + hex3(v0_) + " " + hex3(v1_) + " " + hex3(v2_);
   return s->host.add_geometry(std::move(g));
 }
+// ---- state-level entry points: the reference's CONSTRUCTED objects, member for member ---------------------------
+// A binding inside pine's tree walks an already-built pine::Scene; the members a shape keeps (normalised axes,
+// derived lengths) do not invert to its constructor arguments bit-exactly (normalize(normalize(n)) != normalize(n) in
+// floats), so these take the stored state as it is.  Shapes whose members ARE their constructor arguments (Sphere, Box,
+// Line, Cylinder, Mesh) go through the constructor-level calls above.
+static std::string hexn(const float* v, int n) {
+  std::string s;
+  for (int i = 0; i < n; i++) s += fmt(i ? " %a" : "%a", v[i]);
+  return s;
+}
+int pine_gpu_scene_add_rect_state(pine_gpu_scene* s, const float position[3], const float ex[3], const float ey[3], const float n[3],
+                                  float lx, float ly, const float rx[3], const float ry[3], int material) {
+  if (!check(s, position) || !check(s, ex) || !check(s, ey) || !check(s, n) || !check(s, rx) || !check(s, ry)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_RECT;
+  g.shape.material = material;
+  float* f = g.shape.f;  // members of Rect, geometry.h:92-96
+  memcpy(f, position, 12), memcpy(f + 3, ex, 12), memcpy(f + 6, ey, 12), memcpy(f + 9, n, 12);
+  f[12] = lx, f[13] = ly;
+  memcpy(f + 14, rx, 12), memcpy(f + 17, ry, 12);
+  f[20] = lx * ly;  // Rect::area geometry.h:90
+  g.describe = "shape rect_state " + matref(s, material) + " " + hexn(f, 20);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_disk_state(pine_gpu_scene* s, const float position[3], const float n[3], const float u[3], const float v[3],
+                                  float r, int material) {
+  if (!check(s, position) || !check(s, n) || !check(s, u) || !check(s, v)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_DISK;
+  g.shape.material = material;
+  float* f = g.shape.f;  // members of Disk, geometry.h:56-60
+  memcpy(f, position, 12), memcpy(f + 3, n, 12), memcpy(f + 6, u, 12), memcpy(f + 9, v, 12);
+  f[12] = r;
+  f[13] = kPi * r * r;  // Disk::area geometry.h:54
+  g.describe = "shape disk_state " + matref(s, material) + " " + hexn(f, 13);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_plane_state(pine_gpu_scene* s, const float position[3], const float n[3], const float u[3], const float v[3],
+                                   int material) {
+  if (!check(s, position) || !check(s, n) || !check(s, u) || !check(s, v)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_PLANE;
+  g.shape.material = material;
+  float* f = g.shape.f;  // members of Plane, geometry.h:23-25
+  memcpy(f, position, 12), memcpy(f + 3, n, 12), memcpy(f + 6, u, 12), memcpy(f + 9, v, 12);
+  g.describe = "shape plane_state " + matref(s, material) + " " + hexn(f, 12);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_cone_state(pine_gpu_scene* s, const float apex[3], const float n[3], float r, float h, float A, float A2, float S,
+                                  const float bottom_position[3], int material) {
+  if (!check(s, apex) || !check(s, n) || !check(s, bottom_position)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_CONE;
+  g.shape.material = material;
+  float* f = g.shape.f;  // members of Cone, geometry.h:134-140 (bottom: the Disk's centre, its radius is r)
+  memcpy(f, apex, 12), memcpy(f + 3, n, 12);
+  f[6] = r, f[7] = h, f[8] = A, f[9] = A2, f[10] = S;
+  f[11] = std::sqrt(r * r + h * h) * kPi * r + kPi * r * r;  // Cone::area geometry.h:132
+  memcpy(f + 12, bottom_position, 12);
+  g.describe = "shape cone_state " + matref(s, material) + " " + hexn(f, 11) + " " + hexn(f + 12, 3);
+  return s->host.add_geometry(std::move(g));
+}
+int pine_gpu_scene_add_triangle_state(pine_gpu_scene* s, const float v0[3], const float v1[3], const float v2[3], const float n[3],
+                                      int material) {
+  if (!check(s, v0) || !check(s, v1) || !check(s, v2) || !check(s, n)) return -1;
+  HostGeometry g{};
+  g.shape.kind = SHAPE_TRIANGLE;
+  g.shape.material = material;
+  float* f = g.shape.f;  // members of Triangle, geometry.h:115-117
+  memcpy(f, v0, 12), memcpy(f + 3, v1, 12), memcpy(f + 6, v2, 12), memcpy(f + 9, n, 12);
+  f[12] = length(cross(ld3(v1) - ld3(v0), ld3(v2) - ld3(v0))) / 2;  // Triangle::area geometry.h:112
+  g.describe = "shape triangle_state " + matref(s, material) + " " + hexn(f, 12);
+  return s->host.add_geometry(std::move(g));
+}
+
 int pine_gpu_scene_add_mesh(pine_gpu_scene* s, const float* vertices, int nv, const uint32_t* indices,
                             int nt, int material) {
   if (!check(s, vertices) || !check(s, indices)) return -1;
@@ -1265,6 +1340,47 @@ int pine_gpu_scene_set_camera_thinlens(pine_gpu_scene* s, int w, int h, int tone
   s->host.tonemapper = tonemapper;
   s->host.camera_describe = fmt("camera thinlens %d %d ", w, h) + hex3(from) + " " + hex3(to) +
                             fmt(" %a %a %a", fov, len_radius, focus);
+  return 0;
+}
+
+// state-level form: the members of a constructed ThinLenCamera (camera.h:21-26), c2w as 9 floats, columns x, y, z
+int pine_gpu_scene_set_camera_thinlens_state(pine_gpu_scene* s, int w, int h, int tonemapper, const float position[3],
+                                             const float c2w[9], const float fov2d[2], float len_radius, float focus) {
+  if (!check(s, position) || !check(s, c2w) || !check(s, fov2d)) return -1;
+  if (w <= 0 || h <= 0) {
+    set_error("film size must be positive");
+    return -1;
+  }
+  DCamera& c = s->host.camera;
+  memcpy(c.position, position, 12);
+  memcpy(c.c2w, c2w, 36);
+  c.fov2d[0] = fov2d[0], c.fov2d[1] = fov2d[1];
+  c.len_radius = len_radius;
+  c.focus_distance = focus;
+  c.W = w;
+  c.H = h;
+  s->host.has_camera = true;
+  s->host.tonemapper = tonemapper;
+  s->host.camera_describe = fmt("camera thinlens_state %d %d ", w, h) + hex3(position) + " " + hexn(c2w, 9) + " " + hexn(fov2d, 2) +
+                            fmt(" %a %a", len_radius, focus);
+  return 0;
+}
+
+// test hook: the 128-byte device record of geometry `index` (30 floats, kind, material) and the camera record
+int pine_gpu_scene_shape_record(pine_gpu_scene* s, int index, float out[32]) {
+  if (!check(s, out)) return -1;
+  if (index < 0 || size_t(index) >= s->host.geometries.size()) {
+    set_error("geometry index out of range");
+    return -1;
+  }
+  memcpy(out, &s->host.geometries[size_t(index)].shape, sizeof(DShape));
+  return 0;
+}
+int pine_gpu_scene_camera_record(pine_gpu_scene* s, float out[20]) {
+  if (!check(s, out)) return -1;
+  static_assert(sizeof(DCamera) <= 80, "DCamera grew");
+  memset(out, 0, 80);
+  memcpy(out, &s->host.camera, sizeof(DCamera));
   return 0;
 }
 

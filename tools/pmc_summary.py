@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc CSVs for the path kernel: mean counter value per dispatch."""
 import csv, collections, glob, json, sys
 agg = collections.defaultdict(list)
-kname = None
+kname = vg = lds = grid = None
 args = [a for a in sys.argv[1:] if not a.startswith("--traffic-json=")]
 traffic_out = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--traffic-json=")), None)
 for d in args:
@@ -11,7 +11,8 @@ for d in args:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 kname = r["Kernel_Name"].split("<")[0].split("::")[-1].split("(")[0].replace("void ", "")
                 vg = r.get("VGPR_Count"); lds = r.get("LDS_Block_Size"); grid = r.get("Grid_Size")
-print(f"kernel {kname} VGPR={vg} LDS={lds} grid={grid}")
+print(f"kernel {kname} VGPR={vg} static_LDS={lds} grid={grid}   (rocprofv3 reports the kernel's STATIC LDS only; these kernels take all of theirs -- "
+      f"130 - 160 KB per workgroup -- as dynamic shared memory: see `lds_bytes` of plan stats / tools/sections.py, and VGPR is the descriptor's granule count)")
 m = {k: sum(v) / len(v) for k, v in agg.items()}
 for k in sorted(m):
     print(f"{k:28s} {m[k]:.5e}  (n={len(agg[k])})")
