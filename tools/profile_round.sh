@@ -5,7 +5,8 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/profiles
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 10 --warmup 2 > gpurun_out/profiles/${tag}_bench_under_rocprof.log 2>&1
+# (--no-configs: only the headline workload's launches, so that the per-kernel AVERAGE is C2's -- C3 runs the same kernel variant)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 10 --warmup 2 --no-configs --no-cpu > gpurun_out/profiles/${tag}_bench_under_rocprof.log 2>&1
 cp gpurun_out/prof_$tag/*/*_kernel_stats.csv gpurun_out/profiles/${tag}_kernel_stats.csv
 tools/pmc.sh $tag > /dev/null 2>&1
 cp gpurun_out/pmc_${tag}_summary.txt gpurun_out/profiles/${tag}_pmc_summary.txt
