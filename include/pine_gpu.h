@@ -45,6 +45,11 @@ void pine_gpu_mat4_rotate_z(float rad, float out[16]);
 void pine_gpu_mat4_mul(const float a[16], const float b[16], float out[16]);
 void pine_gpu_mat4_inverse(const float m[16], float out[16]);
 void pine_gpu_mat4_look_at(const float from[3], const float at[3], float out[16]);
+/* what the reference's glTF import composes node transforms from (src/pine/core/fileio.cpp:127-169): q2m(w, x, y, z), the
+ * matrix's scalar constructor (row-major arguments) and transpose */
+void pine_gpu_mat4_from_quaternion(float w, float x, float y, float z, float out[16]);
+void pine_gpu_mat4_from_rows(const float rows[16], float out[16]);
+void pine_gpu_mat4_transpose(const float m[16], float out[16]);
 
 /* ---- Scene ---------------------------------------------------------------------------------
  * Scene(): src/pine/core/scene.cpp:64-79 (`Scene` ctor + `add`/`set` methods). */
@@ -138,6 +143,14 @@ int pine_gpu_scene_add_cylinder(pine_gpu_scene*, const float p0[3], const float 
 int pine_gpu_scene_add_triangle(pine_gpu_scene*, const float v0[3], const float v1[3], const float v2[3],
                                 int material);
                                          /* Triangle(vec3,vec3,vec3)  geometry.cpp:528-531 */
+/* Mesh(vertices, indices, texcoords, normals) geometry.cpp:596-604: per-vertex normals (interpolated shading normal,
+ * geometry.h:199-204) and / or texture coordinates (:205-210), as the reference's glTF import produces them; either may be
+ * null.  pine_gpu_mesh_apply: Mesh::apply(mat4) geometry.cpp:647-653 in place on caller arrays (the import applies a node's
+ * accumulated transform to its mesh before adding it). */
+int pine_gpu_scene_add_mesh_full(pine_gpu_scene*, const float* vertices, int num_vertices, const uint32_t* indices, int num_triangles,
+                                 const float* normals, const float* texcoords, int material);
+int pine_gpu_mesh_apply(float* vertices, int num_vertices, float* normals, const float m[16]);
+
 /* State-level forms, for a binding that walks an already constructed pine::Scene (examples/adapter):
  * the members the reference's shape object keeps, exactly as stored -- a constructed Rect / Disk / Plane / Cone holds
  * NORMALISED axes and derived lengths that do not invert to its constructor arguments bit for bit.  (Sphere, Box,

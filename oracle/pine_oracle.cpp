@@ -1364,6 +1364,8 @@ struct Triangle {  // the stand-alone shape, geometry.cpp:525-595
 struct BVHImpl;
 struct Mesh {  // geometry.h:158-232, geometry.cpp:601-650
   std::vector<vec3> vertices;
+  std::vector<vec3> normals;      // per vertex, or empty (geometry.h:215)
+  std::vector<vec2> texcoords;    // per vertex, or empty (:216)
   std::vector<uint32_t> indices;  // 3 per face
   std::shared_ptr<BVHImpl> bvh;   // per-mesh BVH (bvh.cpp:459-475 == ShapeBVH, :549-567)
   size_t num_triangles() const { return indices.size() / 3; }
@@ -1391,7 +1393,15 @@ struct Mesh {  // geometry.h:158-232, geometry.cpp:601-650
     vec3 q = tbn * (p - v0);
     it.uv = vec2(q.x, q.y);
     it.p = lerp3(it.uv[0], it.uv[1], v0, v1, v2);
-    it.n = normalize(it.n);
+    if (!normals.empty())  // normal_of geometry.h:199-204
+      it.n = normalize(lerp3(it.uv[0], it.uv[1], normals[indices[3 * i]], normals[indices[3 * i + 1]], normals[indices[3 * i + 2]]));
+    else
+      it.n = normalize(it.n);
+    if (!texcoords.empty()) {  // texcoord_of :205-210 (read with the barycentric uv)
+      const float u = it.uv[0], v = it.uv[1];
+      const vec2 a = texcoords[indices[3 * i]], b = texcoords[indices[3 * i + 1]], c = texcoords[indices[3 * i + 2]];
+      it.uv = vec2((1.0f - u - v) * a.x + u * b.x + v * c.x, (1.0f - u - v) * a.y + u * b.y + v * c.y);
+    }
   }
   AABB get_aabb(size_t i) const {  // :647-652
     vec3 a, b, c;
@@ -2773,7 +2783,7 @@ bool parse_pscene(const char* text, Scene& scene) {
         t->v0 = rd3(in), t->v1 = rd3(in), t->v2 = rd3(in), t->n = rd3(in);
         g.kind = S_TRIANGLE;
         g.impl = t;
-      } else if (kind == "mesh") {
+      } else if (kind == "mesh" || kind == "mesh_full") {
         int nv, nt;
         in >> nv >> nt;
         auto m = std::make_shared<Mesh>();
@@ -2782,6 +2792,17 @@ bool parse_pscene(const char* text, Scene& scene) {
           uint32_t a;
           in >> a;
           m->indices.push_back(a);
+        }
+        if (kind == "mesh_full") {  // per-vertex normals / texcoords (Mesh(vertices, indices, texcoords, normals))
+          int has_n, has_t;
+          in >> has_n >> has_t;
+          if (has_n)
+            for (int i = 0; i < nv; i++) m->normals.push_back(rd3(in));
+          if (has_t)
+            for (int i = 0; i < nv; i++) {
+              const float tx = rdf(in), ty = rdf(in);
+              m->texcoords.push_back(vec2(tx, ty));
+            }
         }
         g.kind = S_MESH;
         g.impl = m;

@@ -12,6 +12,7 @@
 //   pine_ref rng     <out.bin>           hash()/RNG known answers (fixture 1)
 //   pine_ref host    <out.bin>           host-side math known answers (matrices, look_at, ctors)
 //   pine_ref shapes  <scene.pscene> <rays.bin> <out.bin>   per-shape hit/intersect records
+//   pine_ref gltf <file.glb> <spp> <depth> <out.film>       the reference's own glTF import + PathIntegrator(BVH)
 //   pine_ref finalize <film.bin> <W> <H> <tonemapper> <out.u8> [out.png]   Film::finalize + flip + gamma + x256 (film.save)
 //   pine_ref prl     <literal>...        psl::stof / stoi / to_string of each literal, and the constant
 //                                        expressions of a cbox-class script evaluated with psl::stof values
@@ -223,7 +224,7 @@ static void load_pscene(const char* path, Loaded& out) {
       } else if (kind == "triangle") {
         auto a = rd3(in), b = rd3(in), c = rd3(in);
         scene.add_geometry(Triangle(a, b, c), psl::string(mat.c_str()));
-      } else if (kind == "mesh") {
+      } else if (kind == "mesh" || kind == "mesh_full") {
         int nv, nt;
         in >> nv >> nt;
         psl::vector<vec3> verts;
@@ -234,7 +235,20 @@ static void load_pscene(const char* path, Loaded& out) {
           in >> a >> b >> c;
           idx.push_back(vec3u32(a, b, c));
         }
-        scene.add_geometry(Mesh(MOVE(verts), MOVE(idx)), psl::string(mat.c_str()));
+        psl::vector<vec3> normals;
+        psl::vector<vec2> texcoords;
+        if (kind == "mesh_full") {  // per-vertex normals / texcoords: Mesh(vertices, indices, texcoords, normals)
+          int has_n, has_t;
+          in >> has_n >> has_t;
+          if (has_n)
+            for (int i = 0; i < nv; i++) normals.push_back(rd3(in));
+          if (has_t)
+            for (int i = 0; i < nv; i++) {
+              float tx = rdf(in), ty = rdf(in);
+              texcoords.push_back(vec2(tx, ty));
+            }
+        }
+        scene.add_geometry(Mesh(MOVE(verts), MOVE(idx), MOVE(texcoords), MOVE(normals)), psl::string(mat.c_str()));
       } else {
         fprintf(stderr, "unknown shape kind %s\n", kind.c_str());
         exit(2);
@@ -501,6 +515,24 @@ int main(int argc, char** argv) {
       }
     }
     write_file(argv[4], out.data(), out.size() * 4);
+    return 0;
+  }
+  if (cmd == "gltf" && argc == 6) {
+    // gltf <file.gltf|.glb> <spp> <depth> <out.film>: the reference's OWN importer (load_scene -> scene_from_gltf,
+    // fileio.cpp:146-330 through tinygltf) builds the scene -- meshes with node transforms applied, Uber / Emissive materials
+    // from the pbrMetallicRoughness factors, the camera node -- and PathIntegrator(BVH, BlueSampler) renders it.  Prints the
+    // film size (the importer fixes the height at 640) with the timing.
+    Scene scene = load_scene(argv[2]);
+    int spp = atoi(argv[3]), depth = atoi(argv[4]);
+    scene.camera.film().clear();
+    auto integ = PathIntegrator(Accel(BVH()), Sampler(BlueSobolSampler(spp)), UniformLightSampler(), depth);
+    auto t0 = std::chrono::steady_clock::now();
+    integ.render(scene);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    auto& film = scene.camera.film();
+    write_file(argv[5], film.data(), size_t(16) * film.width() * film.height());
+    printf("{\"seconds\": %.6f, \"w\": %d, \"h\": %d, \"geometries\": %d, \"spp\": %d, \"depth\": %d}\n", sec, film.width(), film.height(),
+           int(scene.geometries.size()), BlueSobolSampler(spp).spp(), depth);
     return 0;
   }
   if (cmd == "finalize" && (argc == 7 || argc == 8)) {

@@ -74,6 +74,9 @@ SIGNATURES = {
     "pine_gpu_mat4_mul": (None, [f16, f16, f16]),
     "pine_gpu_mat4_inverse": (None, [f16, f16]),
     "pine_gpu_mat4_look_at": (None, [f3, f3, f16]),
+    "pine_gpu_mat4_from_quaternion": (None, [C.c_float, C.c_float, C.c_float, C.c_float, f16]),
+    "pine_gpu_mat4_from_rows": (None, [f16, f16]),
+    "pine_gpu_mat4_transpose": (None, [f16, f16]),
     "pine_gpu_scene_create": (C.c_void_p, []),
     "pine_gpu_scene_destroy": (None, [C.c_void_p]),
     "pine_gpu_scene_add_material_emissive": (C.c_int, [C.c_void_p, C.c_char_p, f3]),
@@ -110,6 +113,8 @@ SIGNATURES = {
     "pine_gpu_scene_add_line": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_int]),
     "pine_gpu_scene_add_cylinder": (C.c_int, [C.c_void_p, f3, f3, C.c_float, C.c_int]),
     "pine_gpu_scene_add_triangle": (C.c_int, [C.c_void_p, f3, f3, f3, C.c_int]),
+    "pine_gpu_scene_add_mesh_full": (C.c_int, [C.c_void_p, c_f_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, c_f_p, c_f_p, C.c_int]),
+    "pine_gpu_mesh_apply": (C.c_int, [c_f_p, C.c_int, c_f_p, f16]),
     "pine_gpu_scene_add_rect_state": (C.c_int, [C.c_void_p, f3, f3, f3, f3, C.c_float, C.c_float, f3, f3, C.c_int]),
     "pine_gpu_scene_add_disk_state": (C.c_int, [C.c_void_p, f3, f3, f3, f3, C.c_float, C.c_int]),
     "pine_gpu_scene_add_plane_state": (C.c_int, [C.c_void_p, f3, f3, f3, f3, C.c_int]),

@@ -328,9 +328,16 @@ class Triangle(Shape):
 
 
 class Mesh(Shape):
-    def __init__(self, vertices, indices):
+    """Mesh(vertices, indices[, texcoords, normals]) geometry.cpp:596-604: per-vertex normals give the interpolated shading
+    normal, per-vertex texcoords replace the barycentric uv (geometry.h:199-210)."""
+    def __init__(self, vertices, indices, texcoords=None, normals=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        self.texcoords = None if texcoords is None else np.ascontiguousarray(texcoords, dtype=np.float32).reshape(-1, 2)
+        for name, a in (("normals", self.normals), ("texcoords", self.texcoords)):
+            if a is not None and len(a) != len(self.vertices):
+                raise PineError(f"Mesh: {len(self.vertices)} vertices but {len(a)} {name}")  # CHECK_EQ geometry.cpp:602-603
 
 
 # ---- film / camera / sampler -------------------------------------------------------------------
@@ -512,6 +519,11 @@ class Scene:
         if isinstance(s, Triangle):
             return check(lib.pine_gpu_scene_add_triangle(h, _v3(s.v0), _v3(s.v1), _v3(s.v2), mid), "Triangle")
         if isinstance(s, Mesh):
+            if s.normals is not None or s.texcoords is not None:
+                return check(lib.pine_gpu_scene_add_mesh_full(
+                    h, s.vertices.ctypes.data_as(_lib.c_f_p), len(s.vertices), s.indices.ctypes.data_as(C.POINTER(C.c_uint32)), len(s.indices),
+                    s.normals.ctypes.data_as(_lib.c_f_p) if s.normals is not None else None,
+                    s.texcoords.ctypes.data_as(_lib.c_f_p) if s.texcoords is not None else None, mid), "Mesh")
             return check(lib.pine_gpu_scene_add_mesh(h, s.vertices.ctypes.data_as(_lib.c_f_p), len(s.vertices),
                                                      s.indices.ctypes.data_as(C.POINTER(C.c_uint32)), len(s.indices), mid), "Mesh")
         raise PineError("unsupported shape")

@@ -851,6 +851,19 @@ PINE_HD void tri_surface_info(const float* v, f3 p, DSurface& it) {
   it.n = normalize(n);
 }
 
+// Mesh::compute_surface_info (geometry.cpp:632-646) for a mesh that may carry per-vertex normals / texcoords: after the
+// geometric part above, it.n = normalize(lerp(u, v, n0, n1, n2)) (geometry.h:199-204) and it.uv = lerp(u, v, t0, t1, t2)
+// (:205-210), both read with the BARYCENTRIC uv.  attrs: 16 floats per triangle (n0 n1 n2, t0 t1 t2, pad).
+PINE_HD void mesh_surface_info(const float* tri_verts, const float* tri_attrs, int flags, int prim, f3 p, DSurface& it) {
+  tri_surface_info(tri_verts + size_t(prim) * 9, p, it);
+  if (flags != 0) {
+    const float* a = tri_attrs + size_t(prim) * 16;
+    const f2 bary = it.uv;
+    if (flags & 1) it.n = normalize(lerp3(bary.x, bary.y, ld3(a), ld3(a + 3), ld3(a + 6)));
+    if (flags & 2) it.uv = (1.0f - bary.x - bary.y) * f2{a[9], a[10]} + bary.x * f2{a[11], a[12]} + bary.y * f2{a[13], a[14]};
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Light sampling on shapes (Shape::sample geometry.h:331-340) and Shape::pdf
 // ------------------------------------------------------------------------------------------------

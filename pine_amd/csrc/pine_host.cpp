@@ -605,12 +605,23 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
     if (nt == 0) continue;
     int first_tri = int(accel.tri_verts.size() / 9);
     std::vector<Prim> prims;
+    const bool has_n = !m.normals.empty(), has_t = !m.texcoords.empty();
+    if (has_n || has_t) accel.tri_attrs.resize(size_t(first_tri) * 16, 0.0f);  // (earlier meshes without attributes: zeros, never read)
     for (size_t t = 0; t < nt; t++) {
       Prim p;
       for (int k = 0; k < 3; k++) {
         const float* v = &m.vertices[3 * m.indices[3 * t + k]];
         p.aabb.extend(ld3(v));
         accel.tri_verts.insert(accel.tri_verts.end(), v, v + 3);
+      }
+      if (has_n || has_t || !accel.tri_attrs.empty()) {
+        float a[16] = {};
+        for (int k = 0; k < 3; k++) {
+          const uint32_t vi = m.indices[3 * t + k];
+          if (has_n) memcpy(a + 3 * k, &m.normals[3 * vi], 12);
+          if (has_t) memcpy(a + 9 + 2 * k, &m.texcoords[2 * vi], 8);
+        }
+        accel.tri_attrs.insert(accel.tri_attrs.end(), a, a + 16);
       }
       p.index = int(t);
       prims.push_back(p);
@@ -626,6 +637,8 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
     memcpy(&geometries[gi].shape.f[1], &tmp, 4);
     tmp = bvh_id;
     memcpy(&geometries[gi].shape.f[2], &tmp, 4);
+    tmp = (has_n ? 1 : 0) | (has_t ? 2 : 0);
+    memcpy(&geometries[gi].shape.f[4], &tmp, 4);
     Prim tp;
     tp.aabb = bounds;
     tp.index = int(gi);
@@ -730,6 +743,23 @@ void pine_gpu_mat4_inverse(const float m[16], float out[16]) {
 }
 void pine_gpu_mat4_look_at(const float from[3], const float at[3], float out[16]) {
   mat4_look_at(ld3(from), ld3(at)).to_storage(out);
+}
+// q2m(a, b, c, d) fileio.cpp:127-144 (quaternion w, x, y, z -> rotation; the glTF loader's node rotations), the matrix's
+// scalar constructor (row-major arguments, vecmath.h:579-581) and transpose (vecmath.h:640-648)
+void pine_gpu_mat4_from_quaternion(float a, float b, float c, float d, float out[16]) {
+  const float r[16] = {a * a + b * b - c * c - d * d, 2 * b * c - 2 * a * d, 2 * b * d + 2 * a * c, 0,
+                       2 * b * c + 2 * a * d, a * a - b * b + c * c - d * d, 2 * c * d - 2 * a * b, 0,
+                       2 * b * d - 2 * a * c, 2 * c * d + 2 * a * b, a * a - b * b - c * c + d * d, 0,
+                       0, 0, 0, 1};
+  Mat4::from_rows(r).to_storage(out);
+}
+void pine_gpu_mat4_from_rows(const float rows[16], float out[16]) { Mat4::from_rows(rows).to_storage(out); }
+void pine_gpu_mat4_transpose(const float m[16], float out[16]) {
+  const Mat4 a = Mat4::from_storage(m);
+  Mat4 t{};
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) t.m[c][r] = a.m[r][c];
+  t.to_storage(out);
 }
 
 pine_gpu_scene* pine_gpu_scene_create(void) { return new pine_gpu_scene(); }
@@ -1315,6 +1345,54 @@ int pine_gpu_scene_add_mesh(pine_gpu_scene* s, const float* vertices, int nv, co
   s->host.meshes.push_back(std::move(m));
   g.mesh = int(s->host.meshes.size()) - 1;
   return s->host.add_geometry(std::move(g));
+}
+
+// Mesh(vertices, indices, texcoords, normals) geometry.cpp:596-604: per-vertex normals and / or texture coordinates,
+// as a glTF import produces them (fileio.cpp:146-311).  Either may be null.
+int pine_gpu_scene_add_mesh_full(pine_gpu_scene* s, const float* vertices, int nv, const uint32_t* indices, int nt,
+                                 const float* normals, const float* texcoords, int material) {
+  const int id = pine_gpu_scene_add_mesh(s, vertices, nv, indices, nt, material);
+  if (id < 0 || (!normals && !texcoords)) return id;
+  HostGeometry& g = s->host.geometries[size_t(id)];
+  HostMesh& m = s->host.meshes[size_t(g.mesh)];
+  std::string d = "shape mesh_full " + g.describe.substr(strlen("shape mesh "));
+  d += fmt(" %d %d", normals ? 1 : 0, texcoords ? 1 : 0);
+  if (normals) {
+    m.normals.assign(normals, normals + 3 * size_t(nv));
+    for (int i = 0; i < 3 * nv; i++) d += fmt(" %a", normals[i]);
+  }
+  if (texcoords) {
+    m.texcoords.assign(texcoords, texcoords + 2 * size_t(nv));
+    for (int i = 0; i < 2 * nv; i++) d += fmt(" %a", texcoords[i]);
+  }
+  g.describe = std::move(d);
+  return id;
+}
+
+// Mesh::apply(mat4) geometry.cpp:647-653, in place: v = m * v (affine point transform, vecmath.h:705-707);
+// n = normalize(transpose(inverse(mat3(m))) * n).  `normals` may be null.
+int pine_gpu_mesh_apply(float* vertices, int nv, float* normals, const float m_[16]) {
+  if (!vertices || !m_ || nv < 0) {
+    set_error("bad argument");
+    return -1;
+  }
+  const Mat4 M = Mat4::from_storage(m_);
+  const f3 cx{M.m[0][0], M.m[0][1], M.m[0][2]}, cy{M.m[1][0], M.m[1][1], M.m[1][2]}, cz{M.m[2][0], M.m[2][1], M.m[2][2]},
+      cw{M.m[3][0], M.m[3][1], M.m[3][2]};
+  for (int i = 0; i < nv; i++) {
+    const f3 q = ld3(vertices + 3 * i);
+    const f3 v = cx * q.x + cy * q.y + cz * q.z + cw;  // operator*(mat4, vec3) vecmath.h:705-707
+    vertices[3 * i] = v.x, vertices[3 * i + 1] = v.y, vertices[3 * i + 2] = v.z;
+  }
+  if (normals) {
+    const m3 a{cx, cy, cz};  // mat3(mat4): the upper-left 3x3
+    const m3 t = transpose(inverse(a));
+    for (int i = 0; i < nv; i++) {
+      const f3 n = normalize(mul(t, ld3(normals + 3 * i)));
+      normals[3 * i] = n.x, normals[3 * i + 1] = n.y, normals[3 * i + 2] = n.z;
+    }
+  }
+  return 0;
 }
 
 int pine_gpu_scene_set_camera_thinlens(pine_gpu_scene* s, int w, int h, int tonemapper, const float from[3],

@@ -56,6 +56,8 @@ struct HostAABB {
 struct HostMesh {
   std::vector<float> vertices;    // 3 per vertex
   std::vector<uint32_t> indices;  // 3 per triangle
+  std::vector<float> normals;     // 3 per vertex, or empty (Mesh::normals geometry.h:215)
+  std::vector<float> texcoords;   // 2 per vertex, or empty (Mesh::texcoords :216)
 };
 
 struct HostGeometry {
@@ -74,6 +76,9 @@ struct FlatAccel {
   // tri_verts (as int bits), 2 pad -- in LEAF order and 16-byte aligned, so that a leaf's triangles are consecutive
   // 48-byte records read with three wide loads, without the prims[i] -> triangle indirection
   std::vector<float> tri_leaf;
+  // per-vertex attributes of meshes that have them, expanded per triangle like tri_verts: 16 floats per triangle
+  // (n0 n1 n2, t0 t1 t2, pad); empty when no mesh of the scene carries normals or texcoords
+  std::vector<float> tri_attrs;
   bool built = false;
 };
 

@@ -356,6 +356,7 @@ static int validate_device_scene(const FlatAccel& A, const std::vector<DShape>& 
   if (A.bvhs.empty()) return bad("no top-level BVH");
   if (A.top_prim_begin < 0 || A.top_prim_begin > n_prims) return bad("top_prim_begin");
   if (A.tri_leaf.size() != size_t(A.top_prim_begin) * 12) return bad("tri_leaf size");
+  if (!A.tri_attrs.empty() && A.tri_attrs.size() != size_t(n_tris) * 16) return bad("tri_attrs size");
   for (size_t b = 0; b < A.bvhs.size(); b++) {
     const DBvh& v = A.bvhs[b];
     const int lo = b == 0 ? A.top_prim_begin : 0, hi = b == 0 ? n_prims : A.top_prim_begin;
@@ -414,6 +415,7 @@ struct pine_gpu_plan {
   char* d_blob = nullptr;  // nodes | shapes | materials | bvhs | prims | lights
   float* d_tri = nullptr;
   float* d_tri_leaf = nullptr;
+  float* d_tri_attrs = nullptr;
   uint8_t* d_tables = nullptr;
   int variant = -1;
   int queue_variant = -1;   // >= 0: the stage-queued kernel is used instead of path_trace_kernel
@@ -495,6 +497,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_blob);
   (void)hipFree(p->d_tri);
   (void)hipFree(p->d_tri_leaf);
+  (void)hipFree(p->d_tri_attrs);
   (void)hipFree(p->d_tables);
   (void)hipFree(p->d_ctxg);
   (void)hipFree(p->d_ckpt);
@@ -606,6 +609,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   HIP_OK(hipMemcpy(p->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (upload(p->d_tri, A.tri_verts)) return -1;
   if (upload(p->d_tri_leaf, A.tri_leaf)) return -1;
+  if (upload(p->d_tri_attrs, A.tri_attrs)) return -1;
   // tables: sobol + the selected spp variant
   int k = 0;
   while ((1 << k) < spp) k++;
@@ -632,6 +636,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.node_ops = reinterpret_cast<const DNodeOp*>(p->d_blob + S.off_node_ops);
   S.tri_verts = p->d_tri;
   S.tri_leaf = reinterpret_cast<const float4*>(p->d_tri_leaf);
+  S.tri_attrs = p->d_tri_attrs;
   S.lds_nodes = 0;
   S.num_lights = int(light_list.size());
   S.env_light = H.has_env ? int(light_list.size()) - 1 : -1;

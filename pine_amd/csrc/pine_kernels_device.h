@@ -83,6 +83,7 @@ struct DeviceScene {
   int off_nodes, off_shapes, off_materials, off_bvhs, off_prims, off_lights, off_node_ops, off_leaf;  // byte offsets in the blob
   int top_prim_begin;  // prims[top_prim_begin ..) are the top-level BVH's entries
   const float4* tri_leaf;  // mesh triangles in leaf order, 3 float4 per entry of `prims` (FlatAccel::tri_leaf)
+  const float* tri_attrs;  // per-vertex normals / texcoords per triangle, 16 floats each (FlatAccel::tri_attrs), or null
   int lds_nodes;           // F_LDS_TOP variants: nodes[0 .. lds_nodes) are copied to LDS by every workgroup
 };
 
@@ -106,6 +107,7 @@ struct SceneView {
   int stack_top;
   int num_shapes;
   const float4* tri_leaf;
+  const float* tri_attrs;
   const DNode* lds_nodes;  // F_LDS_TOP: the workgroup's LDS copy of nodes[0 .. lds_node_count)
   int lds_node_count;
 };
@@ -474,6 +476,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   SceneView V;
   V.tri_verts = S.tri_verts;
   V.tri_leaf = S.tri_leaf;
+  V.tri_attrs = S.tri_attrs;
   V.lds_nodes = nullptr;
   V.lds_node_count = 0;
   V.stack_top = S.stack_top;
@@ -699,7 +702,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       const f3 ph = ray_o + ray_tmax * ray_d;
       bool on_mesh = false;
       if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
-      if (on_mesh) tri_surface_info(V.tri_verts + size_t(prim) * 9, ph, it);
+      if (on_mesh) mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), prim, ph, it);
       else shape_surface_info<F>(shape, ph, it);
       if (mat->kind == MAT_EMISSIVE) {  // path.cpp:83-87
         Lo = mk3(1.0f) * material_le(mat, it.n, -ray_d);
@@ -791,7 +794,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               const DRayOct oct = make_oct(wr);
               int wprim = 0;
               h = mesh_traverse<false>(V, V.bvhs[as_int(shape->f[2])], wr, oct, stack, 0, wprim);
-              if (h) tri_surface_info(V.tri_verts + size_t(wprim) * 9, ray_at(wr, wr.tmax), sit);
+              if (h) mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), wprim, ray_at(wr, wr.tmax), sit);
             } else {
               h = shape_intersect<F>(shape, wr);
             }

@@ -122,6 +122,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   SceneView V;
   V.tri_verts = S.tri_verts;
   V.tri_leaf = S.tri_leaf;
+  V.tri_attrs = S.tri_attrs;
   V.lds_nodes = nullptr;
   V.lds_node_count = 0;
   V.stack_top = S.stack_top;
@@ -458,7 +459,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           const f3 ph = ray_o + ray_tmax * ray_d;
           bool on_mesh = false;
           if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
-          if (on_mesh) tri_surface_info(V.tri_verts + size_t(prim) * 9, ph, it);
+          if (on_mesh) mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), prim, ph, it);
           else shape_surface_info<F>(shape, ph, it);
         }
         const f3 wi = -ray_d;
@@ -848,7 +849,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               // leaves the shape here: Shape::intersect filled it.p / it.n for meshes only
               DSurface sit;
               sit.p = sit.n = mk3(0.0f);
-              if (walk_mesh) tri_surface_info(V.tri_verts + size_t(wprim) * 9, ray_at(wr, wr.tmax), sit);
+              if (walk_mesh) mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), wprim, ray_at(wr, wr.tmax), sit);
               cg4[2] = make_float4(sit.p.x, sit.p.y, sit.p.z, a.w);
               cg4[4] = make_float4(sit.n.x, sit.n.y, sit.n.z, 0.0f);
               st.set_walk(kWalkExited);
@@ -916,7 +917,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               const f3 ph = ray_o + ray_tmax * ray_d;
               bool on_mesh = false;
               if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
-              if (on_mesh) tri_surface_info(V.tri_verts + size_t(cstu[CF_PRIM * kQCtx + id]) * 9, ph, it);
+              if (on_mesh) mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), int(cstu[CF_PRIM * kQCtx + id]), ph, it);
               else shape_surface_info<F>(shape, ph, it);
               Lo = mk3(1.0f) * material_le(mat, it.n, -ray_d);
               if (!st.is_delta()) {

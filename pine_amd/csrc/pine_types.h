@@ -33,7 +33,8 @@ enum ShapeKind : int {
 //  SPHERE: f[0..2] c, [3] r
 //  DISK  : f[0..2] position, [3..5] n, [6..8] u, [9..11] v, [12] r, [13] area
 //  CONE  : f[0..2] apex p, [3..5] n, [6] r, [7] h, [8] A, [9] A2, [10] S, [11] area
-//  MESH  : i(0) first_tri, i(1) num_tri, i(2) bvh index, f[3] area (first triangle x count)
+//  MESH  : i(0) first_tri, i(1) num_tri, i(2) bvh index, f[3] area (first triangle x count),
+//          i(4) attribute flags: 1 = per-vertex normals, 2 = per-vertex texcoords (FlatAccel::tri_attrs)
 //  PLANE : f[0..2] position, [3..5] n, [6..8] u, [9..11] v
 //  LINE  : f[0..2] p0, [3..5] p1, [6..8] tbn.x, [9..11] tbn.y, [12..14] tbn.z, [15] thickness, [16] area
 //  CYLINDER: f[0..2] p0, [3..5] p1, [6..8] n, [9] r

@@ -161,8 +161,29 @@ def embree_fixtures(tmp):
         del os.environ["PINE_REF_ACCEL"]
 
 
+def gltf_fixture(tmp):
+    """SURVEY.md 8(f)4 mesh import: tests/golden/import_test.glb (tools/make_test_glb.py) through the reference's OWN importer
+    (`pine_ref gltf`: load_scene -> scene_from_gltf, fileio.cpp:146-330) and PathIntegrator(BVH) -> whole-film statistics."""
+    glb = os.path.join(OUT, "import_test.glb")
+    out = {}
+    for spp, depth in ((4, 5), (16, 6)):
+        fp = os.path.join(tmp, "g.film")
+        info = json.loads(run_ref("gltf", glb, spp, depth, fp).strip().splitlines()[-1])
+        film = np.fromfile(fp, dtype=np.float32).reshape(info["h"], info["w"], 4)
+        out[f"s{spp}_d{depth}"] = {"spp": spp, "depth": depth, "size": [info["w"], info["h"]], "geometries": info["geometries"],
+                                    "md5": hashlib.md5(film.tobytes()).hexdigest(),
+                                    "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
+                                    "row_320": [float(x) for x in film[320, ::64, :3].reshape(-1)]}
+        print("gltf", out[f"s{spp}_d{depth}"]["md5"], out[f"s{spp}_d{depth}"]["mean_rgb"])
+    json.dump(out, open(os.path.join(OUT, "gltf_import.json"), "w"), indent=1)
+
+
 def main():
     full = "--full" in sys.argv
+    if "--gltf" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            gltf_fixture(tmp)
+        return
     if "--embree" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             embree_fixtures(tmp)
