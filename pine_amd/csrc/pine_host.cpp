@@ -1,6 +1,7 @@
 // pine_amd/csrc/pine_host.cpp -- host side of the C ABI: scene container, shape constructors,
 // host matrix math, pine's BVH build flattened for the GPU, film finalize.  No GPU calls here.
 #include "pine_host.h"
+#include "pine_bvh_build.h"
 
 #include <algorithm>
 #include <cmath>
@@ -440,163 +441,118 @@ HostAABB SceneHost::geometry_aabb(int gi) const {
   return b;
 }
 
-// ---- pine's BVH build (bvh.cpp:43-147), emitting the flattened layout directly ---------------
-namespace {
-struct Prim {
-  HostAABB aabb;
-  int index;
-};
-struct ChildRef {
-  bool leaf;
-  int a;  // inner: node index; leaf: prim start
-  int n;  // leaf: count
-};
-struct Builder {
-  std::vector<DNode>& nodes;
-  std::vector<int>& prims;
-  ChildRef build(Prim* begin, Prim* end, const HostAABB& aabb) {
-    int n = int(end - begin);
-    auto make_leaf = [&]() {
-      ChildRef r{true, int(prims.size()), n};
-      for (int i = 0; i < n; i++) prims.push_back(begin[i].index);
-      return r;
-    };
-    if (n == 1) return make_leaf();
-    HostAABB cb;
-    for (int i = 0; i < n; i++) cb.extend(begin[i].aabb.centroid());
-    float surfaceArea = aabb.surface_area();
-    const int nBuckets = 16;
-    float minCost = kFloatMax;
-    int bestAxis = -1, splitBucket = -1;
-    for (int axis = 0; axis < 3; axis++) {
-      if (cb.degenerated(axis)) continue;
-      struct Bucket {
-        int count = 0;
-        HostAABB aabb;
-      } buckets[nBuckets];
-      for (int i = 0; i < n; i++) {
-        int b = std::min(int(nBuckets * cb.relative_position(begin[i].aabb.centroid(axis), axis)),
-                         nBuckets - 1);
-        buckets[b].count++;
-        buckets[b].aabb.extend(begin[i].aabb);
+// ---- pine's BVH build, level-synchronous (pine_bvh_build.h) ------------------------------------------------------
+void build_level_synchronous(std::vector<BuildPrim>& prims, const std::vector<BuildTask>& roots, FlatAccel& A) {
+  std::vector<BuildTask> level = roots, next;
+  std::vector<unsigned char> pred;
+  std::vector<int> perm;
+  std::vector<BuildPrim> scratch;
+  auto set_slot = [&](const BuildTask& t, int child, int count) {  // the parent's child slot, or the BVH's root
+    if (t.parent < 0) {
+      DBvh& b = A.bvhs[size_t(t.bvh)];
+      if (count > 0) b.root = -1, b.root_start = child, b.root_count = count;
+      else b.root = child, b.root_start = 0, b.root_count = 0;
+    } else {
+      A.nodes[size_t(t.parent)].child[t.which] = child;
+      A.nodes[size_t(t.parent)].count[t.which] = count;
+    }
+  };
+  while (!level.empty()) {
+    next.clear();
+    for (const BuildTask& t : level) {
+      const int n = t.end - t.begin;
+      BuildPrim* P = prims.data() + t.begin;
+      if (n == 1) {
+        set_slot(t, t.begin, 1);
+        continue;
       }
-      float cost[nBuckets - 1] = {};
-      HostAABB bF;
-      int cF = 0;
-      for (int i = 0; i < nBuckets - 1; i++) {
-        bF.extend(buckets[i].aabb);
-        cF += buckets[i].count;
-        cost[i] += cF * bF.surface_area();
-      }
-      HostAABB bB;
-      int cB = 0;
-      for (int i = nBuckets - 1; i >= 1; i--) {
-        bB.extend(buckets[i].aabb);
-        cB += buckets[i].count;
-        cost[i - 1] += cB * bB.surface_area();
-      }
-      for (int i = 0; i < nBuckets - 1; i++) cost[i] = 1.0f + cost[i] / surfaceArea;
-      float axisMin = kFloatMax;
-      int axisSplit = -1;
-      for (int i = 0; i < nBuckets - 1; i++)
-        if (cost[i] < axisMin) {
-          axisMin = cost[i];
-          axisSplit = i;
+      // reductions of the range: centroid bounds, then counts and boxes per bucket and axis
+      float clo[3] = {kFloatMax, kFloatMax, kFloatMax}, chi[3] = {-kFloatMax, -kFloatMax, -kFloatMax};
+      for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+          const float c = build_centroid(P[i], k);
+          clo[k] = c < clo[k] ? c : clo[k];
+          chi[k] = c > chi[k] ? c : chi[k];
         }
-      if (axisMin < minCost) {
-        minCost = axisMin;
-        bestAxis = axis;
-        splitBucket = axisSplit;
+      BucketStats B;
+      for (int a = 0; a < 3; a++)
+        for (int j = 0; j < kBuildBuckets; j++) {
+          B.count[a][j] = 0;
+          for (int k = 0; k < 3; k++) B.lo[a][j][k] = kFloatMax, B.hi[a][j][k] = -kFloatMax;
+        }
+      for (int a = 0; a < 3; a++) {
+        if (chi[a] <= clo[a]) continue;
+        for (int i = 0; i < n; i++) {
+          const int j = build_bucket_of(build_centroid(P[i], a), clo[a], chi[a]);
+          B.count[a][j]++;
+          for (int k = 0; k < 3; k++) {
+            B.lo[a][j][k] = P[i].lo[k] < B.lo[a][j][k] ? P[i].lo[k] : B.lo[a][j][k];
+            B.hi[a][j][k] = P[i].hi[k] > B.hi[a][j][k] ? P[i].hi[k] : B.hi[a][j][k];
+          }
+        }
       }
+      SplitDecision d;
+      build_decide(B, n, build_area(t.blo, t.bhi), clo, chi, d);
+      if (d.leaf) {
+        set_slot(t, t.begin, n);
+        continue;
+      }
+      // the partition: predicate per primitive, the swap sequence on an index permutation, then the move
+      pred.resize(size_t(n));
+      perm.resize(size_t(n));
+      for (int i = 0; i < n; i++) {
+        pred[size_t(i)] = build_bucket_of(build_centroid(P[i], d.axis), clo[d.axis], chi[d.axis]) <= d.bucket;
+        perm[size_t(i)] = i;
+      }
+      const int left = build_lomuto(pred.data(), perm.data(), n);
+      scratch.assign(P, P + n);
+      for (int i = 0; i < n; i++) P[i] = scratch[size_t(perm[size_t(i)])];
+      // the node, with its two child boxes; its child slots are filled when the two new ranges are processed
+      BuildTask l{t.begin, t.begin + left, {kFloatMax, kFloatMax, kFloatMax}, {-kFloatMax, -kFloatMax, -kFloatMax}, int(A.nodes.size()), 0, t.bvh};
+      BuildTask r{t.begin + left, t.end, {kFloatMax, kFloatMax, kFloatMax}, {-kFloatMax, -kFloatMax, -kFloatMax}, int(A.nodes.size()), 1, t.bvh};
+      for (int i = 0; i < n; i++) {
+        BuildTask& c = i < left ? l : r;
+        for (int k = 0; k < 3; k++) {
+          c.blo[k] = P[i].lo[k] < c.blo[k] ? P[i].lo[k] : c.blo[k];
+          c.bhi[k] = P[i].hi[k] > c.bhi[k] ? P[i].hi[k] : c.bhi[k];
+        }
+      }
+      DNode nd{};
+      for (int k = 0; k < 3; k++) nd.lo0[k] = l.blo[k], nd.hi0[k] = l.bhi[k], nd.lo1[k] = r.blo[k], nd.hi1[k] = r.bhi[k];
+      set_slot(t, int(A.nodes.size()), 0);
+      A.nodes.push_back(nd);
+      next.push_back(l);
+      next.push_back(r);
     }
-    if (minCost > float(n)) return make_leaf();
-    // Lomuto partition (src/psl/algorithm.h:394-402): primitive order after the split matters,
-    // because leaf primitives are tested in stored order.
-    Prim* tail = begin;
-    for (Prim* i = begin; i != end; ++i) {
-      int b = int(nBuckets * cb.relative_position(i->aabb.centroid(bestAxis), bestAxis));
-      if (b == nBuckets) b = nBuckets - 1;
-      if (b <= splitBucket) std::swap(*tail++, *i);
-    }
-    Prim* pmid = tail;
-    HostAABB a0, a1;
-    for (Prim* p = begin; p != pmid; p++) a0.extend(p->aabb);
-    for (Prim* p = pmid; p != end; p++) a1.extend(p->aabb);
-    ChildRef c0 = build(begin, pmid, a0);
-    ChildRef c1 = build(pmid, end, a1);
-    DNode nd{};
-    nd.lo0[0] = a0.lower.x, nd.lo0[1] = a0.lower.y, nd.lo0[2] = a0.lower.z;
-    nd.hi0[0] = a0.upper.x, nd.hi0[1] = a0.upper.y, nd.hi0[2] = a0.upper.z;
-    nd.lo1[0] = a1.lower.x, nd.lo1[1] = a1.lower.y, nd.lo1[2] = a1.lower.z;
-    nd.hi1[0] = a1.upper.x, nd.hi1[1] = a1.upper.y, nd.hi1[2] = a1.upper.z;
-    nd.child[0] = c0.a;
-    nd.count[0] = c0.leaf ? c0.n : 0;
-    nd.child[1] = c1.a;
-    nd.count[1] = c1.leaf ? c1.n : 0;
-    nodes.push_back(nd);
-    return ChildRef{false, int(nodes.size()) - 1, 0};
+    level.swap(next);
   }
-};
-DBvh build_one(std::vector<Prim> prims, std::vector<DNode>& nodes, std::vector<int>& plist,
-               int prim_base, HostAABB* bounds_out) {
-  HostAABB aabb;
-  for (auto& p : prims) aabb.extend(p.aabb);
-  Builder b{nodes, plist};
-  ChildRef r = b.build(prims.data(), prims.data() + prims.size(), aabb);
-  DBvh out{};
-  out.prim_base = prim_base;
-  if (r.leaf) {
-    out.root = -1;
-    out.root_start = r.a;
-    out.root_count = r.n;
-  } else {
-    out.root = r.a;
-    out.root_start = 0;
-    out.root_count = 0;
-  }
-  // BVHImpl::get_aabb (bvh.h:50-52): union of the root's two child boxes (== bounds of all prims)
-  if (bounds_out) *bounds_out = aabb;
-  return out;
-}
-}  // namespace
-
-// Node numbering is free (the tree, its boxes and the stored primitive order are what the traversal's results
-// depend on): renumber level by level across the whole two-level structure -- the top-level BVH's root first, then
-// the mesh roots, then everybody's children in that order.  The nodes every ray visits get the lowest indices, which
-// the stage-queued kernel keeps in LDS (DeviceScene::lds_nodes); deeper down the two children of a node are
-// neighbours in memory, often in one 128-byte line.
-static void renumber_breadth_first(FlatAccel& A) {
-  const int n = int(A.nodes.size());
-  std::vector<int> order;  // new index -> old index
-  order.reserve(size_t(n));
-  for (auto& b : A.bvhs)
-    if (b.root_count == 0 && b.root >= 0) order.push_back(b.root);
-  for (size_t head = 0; head < order.size(); head++) {
-    const DNode& nd = A.nodes[size_t(order[head])];
-    for (int c = 0; c < 2; c++)
-      if (nd.count[c] == 0) order.push_back(nd.child[c]);
-  }
-  if (int(order.size()) != n) return;  // (cannot happen: every node hangs below exactly one root)
-  std::vector<int> new_of(size_t(n), -1);
-  for (int i = 0; i < n; i++) new_of[size_t(order[size_t(i)])] = i;
-  std::vector<DNode> nodes;
-  nodes.resize(size_t(n));
-  for (int i = 0; i < n; i++) {
-    DNode nd = A.nodes[size_t(order[size_t(i)])];
-    for (int c = 0; c < 2; c++)
-      if (nd.count[c] == 0) nd.child[c] = new_of[size_t(nd.child[c])];
-    nodes[size_t(i)] = nd;
-  }
-  A.nodes.swap(nodes);
-  for (auto& b : A.bvhs)
-    if (b.root_count == 0 && b.root >= 0) b.root = new_of[size_t(b.root)];
 }
 
 void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
   accel = FlatAccel();
-  accel.bvhs.push_back(DBvh{-1, 0, 0, 0});  // slot 0 = top level, filled below
-  std::vector<Prim> top;
-  std::vector<int> top_geom;  // `indices` of the reference: top-level primitive -> geometry
+  accel.bvhs.push_back(DBvh{-1, 0, 0, 0});  // slot 0 = top level
+  std::vector<BuildPrim> prims;   // every BVH's primitives back to back: meshes in geometry order, the top level last
+  std::vector<BuildTask> roots;   // one open range per BVH
+  std::vector<BuildPrim> top;
+  auto make_prim = [](const HostAABB& b, int index) {
+    // (+ 0.0f: a box coordinate of -0 becomes +0.  Every use of a box coordinate is a comparison or feeds one -- the sign
+    //  of a zero never decides anything -- but min / max reductions pick between -0 and +0 by evaluation order, and the
+    //  device build must produce the host build's bits on any number of lanes.)
+    BuildPrim p{};
+    p.lo[0] = b.lower.x + 0.0f, p.lo[1] = b.lower.y + 0.0f, p.lo[2] = b.lower.z + 0.0f;
+    p.hi[0] = b.upper.x + 0.0f, p.hi[1] = b.upper.y + 0.0f, p.hi[2] = b.upper.z + 0.0f;
+    p.index = index;
+    return p;
+  };
+  auto root_task = [&](int begin, int end, int bvh) {
+    BuildTask t{begin, end, {kFloatMax, kFloatMax, kFloatMax}, {-kFloatMax, -kFloatMax, -kFloatMax}, -1, 0, bvh};
+    for (int i = begin; i < end; i++)
+      for (int k = 0; k < 3; k++) {
+        t.blo[k] = prims[size_t(i)].lo[k] < t.blo[k] ? prims[size_t(i)].lo[k] : t.blo[k];
+        t.bhi[k] = prims[size_t(i)].hi[k] > t.bhi[k] ? prims[size_t(i)].hi[k] : t.bhi[k];
+      }
+    return t;
+  };
   // 1. one BVH per non-empty mesh, in geometry order
   for (size_t gi = 0; gi < geometries.size(); gi++) {
     if (geometries[gi].shape.kind != SHAPE_MESH) continue;
@@ -604,14 +560,14 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
     size_t nt = m.indices.size() / 3;
     if (nt == 0) continue;
     int first_tri = int(accel.tri_verts.size() / 9);
-    std::vector<Prim> prims;
+    const int begin = int(prims.size());
     const bool has_n = !m.normals.empty(), has_t = !m.texcoords.empty();
     if (has_n || has_t) accel.tri_attrs.resize(size_t(first_tri) * 16, 0.0f);  // (earlier meshes without attributes: zeros, never read)
     for (size_t t = 0; t < nt; t++) {
-      Prim p;
+      HostAABB box;
       for (int k = 0; k < 3; k++) {
         const float* v = &m.vertices[3 * m.indices[3 * t + k]];
-        p.aabb.extend(ld3(v));
+        box.extend(ld3(v));
         accel.tri_verts.insert(accel.tri_verts.end(), v, v + 3);
       }
       if (has_n || has_t || !accel.tri_attrs.empty()) {
@@ -623,13 +579,11 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
         }
         accel.tri_attrs.insert(accel.tri_attrs.end(), a, a + 16);
       }
-      p.index = int(t);
-      prims.push_back(p);
+      prims.push_back(make_prim(box, int(t)));
     }
-    HostAABB bounds;
-    DBvh b = build_one(std::move(prims), accel.nodes, accel.prims, first_tri, &bounds);
-    accel.bvhs.push_back(b);
-    int bvh_id = int(accel.bvhs.size()) - 1;
+    accel.bvhs.push_back(DBvh{-1, 0, 0, first_tri});
+    const int bvh_id = int(accel.bvhs.size()) - 1;
+    roots.push_back(root_task(begin, int(prims.size()), bvh_id));
     int32_t tmp;
     tmp = first_tri;
     memcpy(&geometries[gi].shape.f[0], &tmp, 4);
@@ -639,22 +593,25 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
     memcpy(&geometries[gi].shape.f[2], &tmp, 4);
     tmp = (has_n ? 1 : 0) | (has_t ? 2 : 0);
     memcpy(&geometries[gi].shape.f[4], &tmp, 4);
-    Prim tp;
-    tp.aabb = bounds;
-    tp.index = int(gi);
-    top.push_back(tp);
+    // BVHImpl::get_aabb (bvh.h:50-52): the mesh as a top-level primitive is bounded by all its triangles
+    HostAABB bounds;
+    const BuildTask& rt = roots.back();
+    bounds.lower = f3{rt.blo[0], rt.blo[1], rt.blo[2]};
+    bounds.upper = f3{rt.bhi[0], rt.bhi[1], rt.bhi[2]};
+    top.push_back(make_prim(bounds, int(gi)));
   }
   // 2. then every non-mesh geometry, in geometry order
   for (size_t gi = 0; gi < geometries.size(); gi++) {
     if (geometries[gi].shape.kind == SHAPE_MESH) continue;
-    Prim tp;
-    tp.aabb = geometry_aabb(int(gi));
-    tp.index = int(gi);
-    top.push_back(tp);
+    top.push_back(make_prim(geometry_aabb(int(gi)), int(gi)));
   }
-  accel.top_prim_begin = int(accel.prims.size());
-  if (!top.empty()) accel.bvhs[0] = build_one(std::move(top), accel.nodes, accel.prims, 0, nullptr);
-  renumber_breadth_first(accel);
+  accel.top_prim_begin = int(prims.size());
+  prims.insert(prims.end(), top.begin(), top.end());
+  // the top-level root is numbered first, then the mesh roots, then level by level across all of them
+  if (!top.empty()) roots.insert(roots.begin(), root_task(accel.top_prim_begin, int(prims.size()), 0));
+  build_level_synchronous(prims, roots, accel);
+  accel.prims.resize(prims.size());
+  for (size_t i = 0; i < prims.size(); i++) accel.prims[i] = prims[i].index;
   // leaf-ordered triangle records for the device (FlatAccel::tri_leaf)
   accel.tri_leaf.assign(size_t(accel.top_prim_begin) * 12, 0.0f);
   for (size_t b = 1; b < accel.bvhs.size(); b++) {
