@@ -232,6 +232,9 @@ typedef struct {
                                     RMSE at 256 spp <= 4e-3 (cbox) / 2e-2 (10 000 cones), bias of the image mean <= 5e-3.  Only
                                     scenes one of the fast variants covers (the BASELINE scenes' feature sets); others fail with a
                                     message.  Never the default, never the parity gate. */
+#define PINE_GPU_FLAG_DEVICE_BVH 8 /* build the BVH on the GPU (the same level-synchronous binned-SAH build as on the host, same tree, same
+                                    primitive order: pine_amd/csrc/pine_bvh_build_device.h) when the plan is the first to need the scene's
+                                    accel; also $PINE_GPU_DEVICE_BVH=1.  pine_gpu_plan_stats.accel_built_on_device says what happened. */
 #define PINE_GPU_FLAG_DEBUG_FORCE_BAIL 0x100 /* test hook: the stage-queued path kernel raises its protocol-failure
                                     bail-out at once; every synchronising entry point must then FAIL (never return the film) */
 
@@ -291,7 +294,12 @@ typedef struct {
   uint64_t walk_steps;       /* BSSRDF random-walk steps of the last launch (bxdf.cpp:340-351; stage-queued kernel) */
   float accel_build_ms;      /* host: BVH build + flattening for this plan (0 if the scene's accel was already built) */
   float upload_ms;           /* host: device allocation + upload of scene, tables and work buffers at plan creation  */
+  int32_t accel_built_on_device; /* 1: that build ran on the GPU (PINE_GPU_FLAG_DEVICE_BVH)                            */
+  int32_t reserved;
 } pine_gpu_plan_stats;
+/* The scene's BVH built on HIP device `device` right now (the accel is then reused by every later plan); returns the node
+ * count, < 0 on failure.  pine_gpu_scene_accel_dump shows the result: identical to the host build's. */
+int pine_gpu_scene_build_accel_device(pine_gpu_scene*, int device);
 /* Blocks until the last launch has finished (needed to read the device-side counters).  Fails (< 0) if the
  * path kernel of that launch bailed out of a bounded wait: its film is incomplete. */
 int pine_gpu_plan_stats_get(pine_gpu_plan*, pine_gpu_plan_stats* out);

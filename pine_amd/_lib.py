@@ -52,12 +52,15 @@ class PlanStats(C.Structure):
         ("walk_steps", C.c_uint64),
         ("accel_build_ms", C.c_float),
         ("upload_ms", C.c_float),
+        ("accel_built_on_device", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
 FLAG_TIMING = 1
 FLAG_PROGRESS = 2
 FLAG_FAST = 4
+FLAG_DEVICE_BVH = 8
 FLAG_DEBUG_FORCE_BAIL = 0x100
 
 # every symbol include/pine_gpu.h declares, with its signature
@@ -127,6 +130,7 @@ SIGNATURES = {
     "pine_gpu_scene_camera_record": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "pine_gpu_scene_describe": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "pine_gpu_scene_build_accel": (C.c_int, [C.c_void_p]),
+    "pine_gpu_scene_build_accel_device": (C.c_int, [C.c_void_p, C.c_int]),
     "pine_gpu_scene_accel_dump": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int64]),
     "pine_gpu_shard_of_pixel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pine_gpu_set_table_path": (C.c_int, [C.c_char_p]),

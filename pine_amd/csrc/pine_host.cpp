@@ -441,6 +441,8 @@ HostAABB SceneHost::geometry_aabb(int gi) const {
   return b;
 }
 
+DeviceBuilderFn g_device_builder = nullptr;
+
 // ---- pine's BVH build, level-synchronous (pine_bvh_build.h) ------------------------------------------------------
 void build_level_synchronous(std::vector<BuildPrim>& prims, const std::vector<BuildTask>& roots, FlatAccel& A) {
   std::vector<BuildTask> level = roots, next;
@@ -609,7 +611,19 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
   prims.insert(prims.end(), top.begin(), top.end());
   // the top-level root is numbered first, then the mesh roots, then level by level across all of them
   if (!top.empty()) roots.insert(roots.begin(), root_task(accel.top_prim_begin, int(prims.size()), 0));
-  build_level_synchronous(prims, roots, accel);
+  built_on_device = false;
+  if (build_on_device >= 0 && g_device_builder && !prims.empty()) {
+    // same schedule, same arithmetic, same tree, on the GPU; a failure there (no device) falls through to the host build
+    // of the SAME thing -- not a different algorithm -- and is remembered in built_on_device
+    std::vector<BuildPrim> dp = prims;
+    FlatAccel tmp = accel;
+    if (g_device_builder(dp, roots, tmp, build_on_device) == 0) {
+      prims.swap(dp);
+      accel = std::move(tmp);
+      built_on_device = true;
+    }
+  }
+  if (!built_on_device) build_level_synchronous(prims, roots, accel);
   accel.prims.resize(prims.size());
   for (size_t i = 0; i < prims.size(); i++) accel.prims[i] = prims[i].index;
   // leaf-ordered triangle records for the device (FlatAccel::tri_leaf)
@@ -1441,7 +1455,23 @@ int64_t pine_gpu_scene_describe(pine_gpu_scene* s, char* buf, int64_t capacity) 
 
 int pine_gpu_scene_build_accel(pine_gpu_scene* s) {
   if (!check(s)) return -1;
+  s->host.build_on_device = -1;
   s->host.build_accel();
+  return int(s->host.accel.nodes.size());
+}
+int pine_gpu_scene_build_accel_device(pine_gpu_scene* s, int device) {
+  if (!check(s)) return -1;
+  if (device < 0) {
+    set_error("bad device ordinal");
+    return -1;
+  }
+  s->host.build_on_device = device;
+  s->host.build_accel();
+  s->host.build_on_device = -1;
+  if (!s->host.built_on_device && !s->host.geometries.empty()) {
+    set_error("the BVH build did not run on the device (no HIP device?); the host built the same tree");
+    return -1;
+  }
   return int(s->host.accel.nodes.size());
 }
 int64_t pine_gpu_scene_accel_dump(pine_gpu_scene* s, void* nodes_out, int64_t node_cap, int32_t* prims_out,

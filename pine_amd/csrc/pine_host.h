@@ -66,6 +66,14 @@ struct HostGeometry {
   int mesh = -1;         // index into SceneHost::meshes for SHAPE_MESH
 };
 
+struct BuildPrim;
+struct BuildTask;
+struct FlatAccel;
+// The GPU build (pine_bvh_build_device.h), installed by the kernels' translation unit; same contract as
+// build_level_synchronous.  Returns 0 on success.
+using DeviceBuilderFn = int (*)(std::vector<BuildPrim>& prims, const std::vector<BuildTask>& roots, FlatAccel& A, int device);
+extern DeviceBuilderFn g_device_builder;
+
 struct FlatAccel {
   std::vector<DNode> nodes;
   std::vector<int> prims;  // leaf primitive ids (top level: geometry index; mesh: triangle index)
@@ -129,6 +137,8 @@ struct SceneHost {
   int add_geometry(HostGeometry g);
   HostAABB geometry_aabb(int g) const;
   void build_accel();
+  int build_on_device = -1;  // >= 0: run the BVH build on this HIP device (pine_bvh_build_device.h) instead of on the host
+  bool built_on_device = false;
   std::string describe() const;
 };
 

@@ -42,7 +42,73 @@ namespace pine_gpu {
 SceneHost& scene_host(pine_gpu_scene* s);
 }  // namespace pine_gpu
 #include "pine_kernels_device.h"
+#include "pine_bvh_build_device.h"
 namespace pine_gpu {
+
+// ---- the BVH build on the device: host orchestration (one decide / scan / split triple per level) ----
+static int device_build(std::vector<BuildPrim>& prims, const std::vector<BuildTask>& roots, FlatAccel& A, int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if (hipSetDevice(device) != hipSuccess) return -1;
+  const size_t n = prims.size();
+  BuildPrim *d_prims = nullptr, *d_scratch = nullptr;
+  BuildTask *d_tasks[2] = {nullptr, nullptr};
+  BuildDecision* d_dec = nullptr;
+  int *d_rank = nullptr, *d_perm = nullptr, *d_counts = nullptr;
+  unsigned char* d_pred = nullptr;
+  DNode* d_nodes = nullptr;
+  DBvh* d_bvhs = nullptr;
+  int rc = -1;
+  auto ok = [](hipError_t e) { return e == hipSuccess; };
+  do {
+    const size_t max_tasks = std::max<size_t>(n, roots.size()) + 2;
+    if (!ok(hipMalloc((void**)&d_prims, n * sizeof(BuildPrim))) || !ok(hipMalloc((void**)&d_scratch, n * sizeof(BuildPrim))) ||
+        !ok(hipMalloc((void**)&d_tasks[0], max_tasks * sizeof(BuildTask))) || !ok(hipMalloc((void**)&d_tasks[1], max_tasks * sizeof(BuildTask))) ||
+        !ok(hipMalloc((void**)&d_dec, max_tasks * sizeof(BuildDecision))) || !ok(hipMalloc((void**)&d_rank, max_tasks * sizeof(int))) ||
+        !ok(hipMalloc((void**)&d_perm, n * sizeof(int))) || !ok(hipMalloc((void**)&d_pred, n)) || !ok(hipMalloc((void**)&d_nodes, (n + 1) * sizeof(DNode))) ||
+        !ok(hipMalloc((void**)&d_bvhs, A.bvhs.size() * sizeof(DBvh))) || !ok(hipMalloc((void**)&d_counts, 4 * sizeof(int))))
+      break;
+    if (!ok(hipMemcpy(d_prims, prims.data(), n * sizeof(BuildPrim), hipMemcpyHostToDevice)) ||
+        !ok(hipMemcpy(d_tasks[0], roots.data(), roots.size() * sizeof(BuildTask), hipMemcpyHostToDevice)) ||
+        !ok(hipMemcpy(d_bvhs, A.bvhs.data(), A.bvhs.size() * sizeof(DBvh), hipMemcpyHostToDevice)))
+      break;
+    int counts[4] = {0, 0, 0, 0};  // nodes so far | tasks of the next level | largest range of the next level
+    int ntasks = int(roots.size()), node_base = 0, max_n = 0;
+    for (const BuildTask& t : roots) max_n = std::max(max_n, t.end - t.begin);
+    if (!ok(hipFuncSetAttribute((const void*)bvh_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBuildLdsPrims * 5 + 16))) break;
+    bool failed = false;
+    for (int cur = 0; ntasks > 0; cur ^= 1) {
+      if (!ok(hipMemcpy(d_counts, counts, sizeof counts, hipMemcpyHostToDevice))) { failed = true; break; }
+      hipLaunchKernelGGL(bvh_decide_kernel, dim3(ntasks), dim3(kBuildWave), 0, 0, d_prims, d_tasks[cur], ntasks, d_dec);
+      hipLaunchKernelGGL(bvh_scan_kernel, dim3(1), dim3(1024), 0, 0, d_tasks[cur], ntasks, d_dec, d_rank, d_nodes, d_bvhs, d_counts);
+      const int lds_prims = std::min(max_n, kBuildLdsPrims);
+      hipLaunchKernelGGL(bvh_split_kernel, dim3(ntasks), dim3(kBuildWave), size_t(lds_prims) * 4 + ((size_t(lds_prims) + 15) & ~size_t(15)), 0, d_prims, d_scratch,
+                         d_tasks[cur], ntasks, d_dec, d_rank, node_base, d_nodes, d_tasks[cur ^ 1], d_perm, d_pred, lds_prims, d_counts + 2);
+      if (!ok(hipGetLastError()) || !ok(hipMemcpy(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost))) { failed = true; break; }
+      node_base = counts[0];
+      ntasks = counts[1];
+      max_n = counts[2];
+      counts[1] = counts[2] = 0;
+      if (size_t(node_base) > n || size_t(ntasks) > max_tasks) { failed = true; break; }  // (cannot happen: a binary tree over n leaves)
+    }
+    if (failed) break;
+    A.nodes.resize(size_t(node_base));
+    if (node_base && !ok(hipMemcpy(A.nodes.data(), d_nodes, size_t(node_base) * sizeof(DNode), hipMemcpyDeviceToHost))) break;
+    if (!ok(hipMemcpy(prims.data(), d_prims, n * sizeof(BuildPrim), hipMemcpyDeviceToHost)) ||
+        !ok(hipMemcpy(A.bvhs.data(), d_bvhs, A.bvhs.size() * sizeof(DBvh), hipMemcpyDeviceToHost)))
+      break;
+    rc = 0;
+  } while (0);
+  (void)hipGetLastError();
+  for (void* q : {(void*)d_prims, (void*)d_scratch, (void*)d_tasks[0], (void*)d_tasks[1], (void*)d_dec, (void*)d_rank, (void*)d_perm, (void*)d_pred,
+                  (void*)d_nodes, (void*)d_bvhs, (void*)d_counts})
+    if (q) (void)hipFree(q);
+  return rc;
+}
+static const bool g_device_builder_installed = (g_device_builder = &device_build, true);
 
 // Compiled specialisations, most specific first.
 using PathKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, Counters*);
@@ -439,6 +505,7 @@ struct pine_gpu_plan {
   hipStream_t last_stream = nullptr;
   unsigned long long* h_progress = nullptr;  // host-mapped progress word (PINE_GPU_FLAG_PROGRESS)
   float accel_build_ms = 0.0f, upload_ms = 0.0f;  // host-side cost of plan creation (reported by stats_get)
+  bool accel_on_device = false;
 };
 
 static int plan_check_counters(const Counters& c) {
@@ -557,9 +624,14 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   p->device = prm->device;
   p->params = *prm;
   const auto t_build0 = std::chrono::steady_clock::now();
-  if (!H.accel.built) H.build_accel();
+  if (!H.accel.built) {
+    const char* e = getenv("PINE_GPU_DEVICE_BVH");
+    H.build_on_device = ((prm->flags & PINE_GPU_FLAG_DEVICE_BVH) || (e && atoi(e) != 0)) ? prm->device : -1;
+    H.build_accel();
+  }
   const auto t_build1 = std::chrono::steady_clock::now();
   p->accel_build_ms = std::chrono::duration<float, std::milli>(t_build1 - t_build0).count();
+  p->accel_on_device = H.built_on_device;
   const FlatAccel& A = H.accel;
 
   std::vector<DShape> shapes;
@@ -1017,6 +1089,7 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   out->block_threads = (p->queue_variant >= 0 || p->fast) ? kQBlock : kBlock;
   out->lds_bytes = int(p->lds_bytes);
   out->accel_build_ms = p->accel_build_ms;
+  out->accel_built_on_device = p->accel_on_device ? 1 : 0;
   out->upload_ms = p->upload_ms;
   if (p->launched) {
     HIP_OK(hipStreamSynchronize(p->last_stream));
