@@ -316,6 +316,10 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan*, uint64_t out[16]);
  * layout [(y*W+x)*spp + s].  Test/debug aid. */
 int pine_gpu_plan_read_samples(pine_gpu_plan*, float* out_host, int64_t capacity_floats);
 
+/* Host test hook: the reference's partition (src/psl/algorithm.h:394-402) as its sequential swap loop and as the data-parallel
+ * formulation of the device BVH build; both permutations out, < 0 if they disagree. */
+int pine_gpu_test_lomuto(const unsigned char* pred, int n, int* perm_sequential, int* perm_parallel);
+
 /* Device-side unit-test hooks: run the device implementations on arrays (parity vs oracle). */
 int pine_gpu_test_sampler(int device, int spp, float* out_host, int64_t capacity);  /* layout of oracle_sampler_stream */
 int pine_gpu_test_rng(int device, uint64_t* out_host, int64_t capacity);            /* layout of oracle_rng_stream */

@@ -148,6 +148,7 @@ SIGNATURES = {
     "pine_gpu_plan_check": (C.c_int, [C.c_void_p]),
     "pine_gpu_plan_read_samples": (C.c_int, [C.c_void_p, c_f_p, C.c_int64]),
     "pine_gpu_plan_debug_sections": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "pine_gpu_test_lomuto": (C.c_int, [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pine_gpu_test_sampler": (C.c_int, [C.c_int, C.c_int, c_f_p, C.c_int64]),
     "pine_gpu_test_rng": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.c_int64]),
     "pine_gpu_test_sincos": (C.c_int, [C.c_int, c_f_p, C.c_int64, c_f_p, c_f_p]),

@@ -4,17 +4,17 @@
 //            order-preserving integer images of the floats), the SAH sweep by lane 0 (build_decide, shared with the host);
 //   scan   : one workgroup: exclusive prefix sum of the "splits" flags -> node index and next-level task slot of every
 //            range (nodes must be numbered in task order, not in the order waves finish);
-//   split  : one wave per splitting range: the predicate per primitive, the reference's Lomuto swap sequence on an index
-//            permutation by lane 0 (in LDS when the range fits), the move, the two child boxes, the node, the two new ranges.
-// Every reduction is a min / max / count, so the result does not depend on how lanes share the work; the partition is
-// sequential by nature (see pine_bvh_build.h) and is the critical path: n dependent LDS round trips for a range of n.
+//   split  : one workgroup per splitting range: the predicate per primitive, the RESULT of the reference's Lomuto swap sequence
+//            computed in parallel (prefix sum + pointer jumping, see the kernel), the move, the two child boxes, the node,
+//            the two new ranges.
+// Every reduction is a min / max / count, so the result does not depend on how lanes share the work.
 #pragma once
 #include "pine_bvh_build.h"
 
 namespace pine_gpu {
 
 constexpr int kBuildWave = 64;
-constexpr int kBuildLdsPrims = 12000;  // a range up to this size partitions in LDS (4-byte permutation + 1-byte predicate each)
+constexpr int kBuildLdsPrims = 6800;  // a range up to this size partitions in LDS (permutation 4 B + chain pointer 4 B + predicate 1 B each)
 
 __device__ __forceinline__ int f2ord(float f) {  // float -> int whose signed order is the float order (no NaNs here)
   const int b = __float_as_int(f);
@@ -144,36 +144,99 @@ __global__ void __launch_bounds__(1024) bvh_scan_kernel(const BuildTask* __restr
   }
 }
 
-// One wave per task that splits.
-__global__ void __launch_bounds__(kBuildWave) bvh_split_kernel(BuildPrim* __restrict__ prims, BuildPrim* __restrict__ scratch, const BuildTask* __restrict__ tasks,
-                                                               int ntasks, const BuildDecision* __restrict__ dec, const int* __restrict__ rank, int node_base,
-                                                               DNode* __restrict__ nodes, BuildTask* __restrict__ next, int* __restrict__ g_perm,
-                                                               unsigned char* __restrict__ g_pred, int lds_prims, int* __restrict__ max_next) {
+// One workgroup per task that splits.
+//
+// The partition.  The reference's Lomuto loop (`for i: if pred(a[i]) swap(a[tail++], a[i])`, src/psl/algorithm.h:394-402)
+// looks sequential, but its result has a closed description.  Elements satisfying the predicate ("trues") end up in front
+// in their original order.  The others form a QUEUE between `tail` and `i`: a false element is appended at its back, and a
+// true element -- swapped with a[tail], the queue's front -- moves the front element to the back.  Number the queue's
+// entries in creation order (op k = the k-th element from the first false on: an append creates an entry holding that
+// element; the j-th rotation consumes entry j -- the oldest unconsumed one -- and creates an entry holding the same
+// element).  With R rotations in total the final queue is entries R, R+1, ... in order, and the element an entry holds is
+// found by following src(k) = (append ? k : j(k)) to a fixed point, where j(k) = number of trues among the ops before k, a
+// prefix sum.  Pointer jumping resolves all chains in log2(n) data-parallel rounds.  (tests/test_abi.py checks this
+// formulation against the sequential loop on random predicates through pine_gpu_test_lomuto; the trees it builds are
+// compared with the host build's in tests/test_gpu_parity.py.)
+constexpr int kSplitBlock = 256;
+__global__ void __launch_bounds__(kSplitBlock) bvh_split_kernel(BuildPrim* __restrict__ prims, BuildPrim* __restrict__ scratch, const BuildTask* __restrict__ tasks,
+                                                                int ntasks, const BuildDecision* __restrict__ dec, const int* __restrict__ rank, int node_base,
+                                                                DNode* __restrict__ nodes, BuildTask* __restrict__ next, int* __restrict__ g_perm,
+                                                                int* __restrict__ g_src, unsigned char* __restrict__ g_pred, int lds_prims,
+                                                                int* __restrict__ max_next) {
   extern __shared__ int s_dyn[];
+  __shared__ int s_part[kSplitBlock];
+  __shared__ int s_f0, s_left;
+  __shared__ float s_box[4][12];
   const int t = blockIdx.x;
   if (t >= ntasks) return;
   const BuildDecision d = dec[t];
   if (!d.splits) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   const BuildTask task = tasks[t];
   const int n = task.end - task.begin;
   BuildPrim* P = prims + task.begin;
-  const bool in_lds = n <= lds_prims;  // (lds_prims: what this launch's dynamic LDS holds)
+  const bool in_lds = n <= lds_prims;  // (lds_prims: what this launch's dynamic LDS holds: perm | src | pred)
   int* perm = in_lds ? s_dyn : g_perm + task.begin;
-  unsigned char* pred = in_lds ? reinterpret_cast<unsigned char*>(s_dyn + lds_prims) : g_pred + task.begin;
-  for (int i = lane; i < n; i += kBuildWave) {
-    pred[i] = build_bucket_of(build_centroid(P[i], d.axis), d.clo[d.axis], d.chi[d.axis]) <= d.bucket;
-    perm[i] = i;
-    scratch[task.begin + i] = P[i];
+  int* src = in_lds ? s_dyn + lds_prims : g_src + task.begin;
+  unsigned char* pred = in_lds ? reinterpret_cast<unsigned char*>(s_dyn + 2 * lds_prims) : g_pred + task.begin;
+  // 1. the predicate; a copy of the range to move from; per-thread chunk counts for the prefix sum
+  const int per = (n + kSplitBlock - 1) / kSplitBlock;
+  const int cb = tid * per < n ? tid * per : n, ce = cb + per < n ? cb + per : n;
+  int count = 0, first_false = n;
+  for (int i = cb; i < ce; i++) {
+    const BuildPrim p = P[i];
+    const bool pr = build_bucket_of(build_centroid(p, d.axis), d.clo[d.axis], d.chi[d.axis]) <= d.bucket;
+    pred[i] = pr;
+    scratch[task.begin + i] = p;
+    count += pr ? 1 : 0;
+    if (!pr && first_false == n) first_false = i;
+  }
+  s_part[tid] = count;
+  if (tid == 0) s_f0 = n;
+  __syncthreads();
+  atomicMin(&s_f0, first_false);
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < kSplitBlock; i++) {
+      const int v = s_part[i];
+      s_part[i] = acc;
+      acc += v;
+    }
+    s_left = acc;
   }
   __syncthreads();
-  __shared__ int s_left;
-  if (lane == 0) s_left = build_lomuto(pred, perm, n);  // the reference's swap sequence: sequential by nature
+  const int f0 = s_f0, left = s_left;  // first false position; number of trues
+  // 2. trues: stable, in front.  ops from the first false on: src(k)
+  {
+    int T = s_part[tid];  // trues before position cb
+    for (int i = cb; i < ce; i++) {
+      const bool pr = pred[i] != 0;
+      if (pr) perm[T] = i;
+      if (i >= f0) src[i - f0] = pr ? T - f0 : i - f0;
+      T += pr ? 1 : 0;
+    }
+  }
   __syncthreads();
-  const int left = s_left;
+  // 3. resolve the chains (in place: a value read mid-update is further along the same chain)
+  const int K = n - f0, R = left - f0;
+  if (K > 0) {
+    int rounds = 1;
+    while ((1 << rounds) < K) rounds++;
+    for (int r = 0; r <= rounds; r++) {
+      for (int k = tid; k < K; k += kSplitBlock) {
+        const int s0 = src[k];
+        src[k] = src[s0];
+      }
+      __syncthreads();
+    }
+    // 4. the falses, in final queue order, behind the trues
+    for (int q = tid; q < n - left; q += kSplitBlock) perm[left + q] = f0 + src[R + q];
+  }
+  __syncthreads();
+  // 5. the move and the two child boxes
   float lo0[3] = {kFloatMax, kFloatMax, kFloatMax}, hi0[3] = {-kFloatMax, -kFloatMax, -kFloatMax};
   float lo1[3] = {kFloatMax, kFloatMax, kFloatMax}, hi1[3] = {-kFloatMax, -kFloatMax, -kFloatMax};
-  for (int i = lane; i < n; i += kBuildWave) {
+  for (int i = tid; i < n; i += kSplitBlock) {
     const BuildPrim p = scratch[task.begin + perm[i]];
     P[i] = p;
     if (i < left) {
@@ -183,7 +246,17 @@ __global__ void __launch_bounds__(kBuildWave) bvh_split_kernel(BuildPrim* __rest
     }
   }
   for (int k = 0; k < 3; k++) lo0[k] = wave_min(lo0[k]), hi0[k] = wave_max(hi0[k]), lo1[k] = wave_min(lo1[k]), hi1[k] = wave_max(hi1[k]);
-  if (lane == 0) {
+  if ((tid & 63) == 0)
+    for (int k = 0; k < 3; k++) s_box[tid >> 6][k] = lo0[k], s_box[tid >> 6][3 + k] = hi0[k], s_box[tid >> 6][6 + k] = lo1[k], s_box[tid >> 6][9 + k] = hi1[k];
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kSplitBlock / 64; w++)
+      for (int k = 0; k < 3; k++) {
+        lo0[k] = s_box[w][k] < lo0[k] ? s_box[w][k] : lo0[k];
+        hi0[k] = s_box[w][3 + k] > hi0[k] ? s_box[w][3 + k] : hi0[k];
+        lo1[k] = s_box[w][6 + k] < lo1[k] ? s_box[w][6 + k] : lo1[k];
+        hi1[k] = s_box[w][9 + k] > hi1[k] ? s_box[w][9 + k] : hi1[k];
+      }
     const int node = node_base + rank[t];
     DNode nd{};
     for (int k = 0; k < 3; k++) nd.lo0[k] = lo0[k], nd.hi0[k] = hi0[k], nd.lo1[k] = lo1[k], nd.hi1[k] = hi1[k];
@@ -194,6 +267,28 @@ __global__ void __launch_bounds__(kBuildWave) bvh_split_kernel(BuildPrim* __rest
     next[2 * rank[t] + 1] = r;
     atomicMax(max_next, left > n - left ? left : n - left);  // the next level's largest range (sizes its partition's LDS)
   }
+}
+
+// The same formulation on the host, for the CPU test of its equivalence with build_lomuto (serial loops standing for the
+// data-parallel ones).
+inline int build_lomuto_by_chains(const unsigned char* pred, int* perm, int n) {
+  std::vector<int> T(size_t(n) + 1, 0);
+  for (int i = 0; i < n; i++) T[size_t(i) + 1] = T[size_t(i)] + (pred[i] ? 1 : 0);
+  const int left = T[size_t(n)];
+  int f0 = n;
+  for (int i = n - 1; i >= 0; i--)
+    if (!pred[i]) f0 = i;
+  for (int i = 0; i < n; i++)
+    if (pred[i]) perm[T[size_t(i)]] = i;
+  const int K = n - f0, R = left - f0;
+  std::vector<int> src(size_t(K > 0 ? K : 0));
+  for (int k = 0; k < K; k++) src[size_t(k)] = pred[f0 + k] ? T[size_t(f0 + k)] - f0 : k;
+  int rounds = 1;
+  while ((1 << rounds) < K) rounds++;
+  for (int r = 0; r <= rounds; r++)
+    for (int k = 0; k < K; k++) src[size_t(k)] = src[size_t(src[size_t(k)])];
+  for (int q = 0; q < n - left; q++) perm[left + q] = f0 + src[size_t(R + q)];
+  return left;
 }
 
 }  // namespace pine_gpu

@@ -57,7 +57,7 @@ static int device_build(std::vector<BuildPrim>& prims, const std::vector<BuildTa
   BuildPrim *d_prims = nullptr, *d_scratch = nullptr;
   BuildTask *d_tasks[2] = {nullptr, nullptr};
   BuildDecision* d_dec = nullptr;
-  int *d_rank = nullptr, *d_perm = nullptr, *d_counts = nullptr;
+  int *d_rank = nullptr, *d_perm = nullptr, *d_src = nullptr, *d_counts = nullptr;
   unsigned char* d_pred = nullptr;
   DNode* d_nodes = nullptr;
   DBvh* d_bvhs = nullptr;
@@ -68,7 +68,7 @@ static int device_build(std::vector<BuildPrim>& prims, const std::vector<BuildTa
     if (!ok(hipMalloc((void**)&d_prims, n * sizeof(BuildPrim))) || !ok(hipMalloc((void**)&d_scratch, n * sizeof(BuildPrim))) ||
         !ok(hipMalloc((void**)&d_tasks[0], max_tasks * sizeof(BuildTask))) || !ok(hipMalloc((void**)&d_tasks[1], max_tasks * sizeof(BuildTask))) ||
         !ok(hipMalloc((void**)&d_dec, max_tasks * sizeof(BuildDecision))) || !ok(hipMalloc((void**)&d_rank, max_tasks * sizeof(int))) ||
-        !ok(hipMalloc((void**)&d_perm, n * sizeof(int))) || !ok(hipMalloc((void**)&d_pred, n)) || !ok(hipMalloc((void**)&d_nodes, (n + 1) * sizeof(DNode))) ||
+        !ok(hipMalloc((void**)&d_perm, n * sizeof(int))) || !ok(hipMalloc((void**)&d_src, n * sizeof(int))) || !ok(hipMalloc((void**)&d_pred, n)) || !ok(hipMalloc((void**)&d_nodes, (n + 1) * sizeof(DNode))) ||
         !ok(hipMalloc((void**)&d_bvhs, A.bvhs.size() * sizeof(DBvh))) || !ok(hipMalloc((void**)&d_counts, 4 * sizeof(int))))
       break;
     if (!ok(hipMemcpy(d_prims, prims.data(), n * sizeof(BuildPrim), hipMemcpyHostToDevice)) ||
@@ -78,15 +78,15 @@ static int device_build(std::vector<BuildPrim>& prims, const std::vector<BuildTa
     int counts[4] = {0, 0, 0, 0};  // nodes so far | tasks of the next level | largest range of the next level
     int ntasks = int(roots.size()), node_base = 0, max_n = 0;
     for (const BuildTask& t : roots) max_n = std::max(max_n, t.end - t.begin);
-    if (!ok(hipFuncSetAttribute((const void*)bvh_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBuildLdsPrims * 5 + 16))) break;
+    if (!ok(hipFuncSetAttribute((const void*)bvh_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBuildLdsPrims * 9 + 16))) break;
     bool failed = false;
     for (int cur = 0; ntasks > 0; cur ^= 1) {
       if (!ok(hipMemcpy(d_counts, counts, sizeof counts, hipMemcpyHostToDevice))) { failed = true; break; }
       hipLaunchKernelGGL(bvh_decide_kernel, dim3(ntasks), dim3(kBuildWave), 0, 0, d_prims, d_tasks[cur], ntasks, d_dec);
       hipLaunchKernelGGL(bvh_scan_kernel, dim3(1), dim3(1024), 0, 0, d_tasks[cur], ntasks, d_dec, d_rank, d_nodes, d_bvhs, d_counts);
       const int lds_prims = std::min(max_n, kBuildLdsPrims);
-      hipLaunchKernelGGL(bvh_split_kernel, dim3(ntasks), dim3(kBuildWave), size_t(lds_prims) * 4 + ((size_t(lds_prims) + 15) & ~size_t(15)), 0, d_prims, d_scratch,
-                         d_tasks[cur], ntasks, d_dec, d_rank, node_base, d_nodes, d_tasks[cur ^ 1], d_perm, d_pred, lds_prims, d_counts + 2);
+      hipLaunchKernelGGL(bvh_split_kernel, dim3(ntasks), dim3(kSplitBlock), size_t(lds_prims) * 8 + ((size_t(lds_prims) + 15) & ~size_t(15)), 0, d_prims, d_scratch,
+                         d_tasks[cur], ntasks, d_dec, d_rank, node_base, d_nodes, d_tasks[cur ^ 1], d_perm, d_src, d_pred, lds_prims, d_counts + 2);
       if (!ok(hipGetLastError()) || !ok(hipMemcpy(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost))) { failed = true; break; }
       node_base = counts[0];
       ntasks = counts[1];
@@ -103,7 +103,7 @@ static int device_build(std::vector<BuildPrim>& prims, const std::vector<BuildTa
     rc = 0;
   } while (0);
   (void)hipGetLastError();
-  for (void* q : {(void*)d_prims, (void*)d_scratch, (void*)d_tasks[0], (void*)d_tasks[1], (void*)d_dec, (void*)d_rank, (void*)d_perm, (void*)d_pred,
+  for (void* q : {(void*)d_prims, (void*)d_scratch, (void*)d_tasks[0], (void*)d_tasks[1], (void*)d_dec, (void*)d_rank, (void*)d_perm, (void*)d_src, (void*)d_pred,
                   (void*)d_nodes, (void*)d_bvhs, (void*)d_counts})
     if (q) (void)hipFree(q);
   return rc;
@@ -1331,6 +1331,23 @@ int pine_gpu_path_render_multi(pine_gpu_scene* scene, const pine_gpu_render_para
     return -1;
   }
   return pine_gpu_path_render_devices(scene, prm, list, n, film_out);
+}
+
+/* Test hook (host only): the reference's Lomuto partition as a sequential swap loop (perm_seq) and as the prefix-sum +
+ * pointer-jumping formulation the device build uses (perm_par); returns the number of trues, < 0 if the two disagree. */
+int pine_gpu_test_lomuto(const unsigned char* pred, int n, int* perm_seq, int* perm_par) {
+  if (!pred || !perm_seq || !perm_par || n < 0) {
+    set_error("bad argument");
+    return -1;
+  }
+  for (int i = 0; i < n; i++) perm_seq[i] = i;
+  const int a = build_lomuto(pred, perm_seq, n);
+  const int b = build_lomuto_by_chains(pred, perm_par, n);
+  if (a != b || memcmp(perm_seq, perm_par, size_t(n) * sizeof(int)) != 0) {
+    set_error("the two partition formulations disagree");
+    return -2;
+  }
+  return a;
 }
 
 // ---- device unit-test hooks -------------------------------------------------------------------

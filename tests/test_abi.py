@@ -248,3 +248,23 @@ def test_bench_reference_baseline_reports_the_real_binary(oracle):
     out = bench.cpu_baseline_reference(sc, (640, 640), 16, 8, gpu_md5=md5, budget_s=1e9)
     assert out and out["kind"] == "reference" and out["cores"] >= 1 and out["value"] > 0
     assert out["film_md5"] == md5 and out["film_equals_gpu"] is True
+
+
+def test_partition_formulations_agree():
+    """The reference's Lomuto partition (src/psl/algorithm.h:394-402) decides the primitive order of every BVH leaf.  The
+    device build does not run its swap loop: it computes the loop's RESULT with a prefix sum and pointer jumping
+    (pine_bvh_build_device.h).  Both formulations, on random predicates of every density, all-true / all-false / single
+    element / alternating inputs: identical permutations."""
+    from pine_amd import _lib
+    if os.environ.get("PINE_SANITIZER_RUN") == "1":
+        pytest.skip("the hook lives in the kernels' translation unit")
+    rng = np.random.default_rng(5)
+    cases = [np.zeros(1, np.uint8), np.ones(1, np.uint8), np.zeros(7, np.uint8), np.ones(9, np.uint8), np.uint8([0, 1] * 50), np.uint8([1, 0] * 50)]
+    cases += [(rng.random(int(rng.integers(2, 3000))) < rng.random()).astype(np.uint8) for _ in range(400)]
+    cases += [(rng.random(200_000) < 0.37).astype(np.uint8)]
+    for p in cases:
+        a, b = np.zeros(len(p), np.int32), np.zeros(len(p), np.int32)
+        left = _lib.lib.pine_gpu_test_lomuto(p.ctypes.data_as(C.POINTER(C.c_uint8)), len(p), a.ctypes.data_as(C.POINTER(C.c_int)), b.ctypes.data_as(C.POINTER(C.c_int)))
+        assert left == int(p.sum()), _lib.last_error()
+        assert np.array_equal(a, b) and sorted(a.tolist()) == list(range(len(p)))
+        assert p[a[:left]].all() and not p[a[left:]].any() and np.array_equal(a[:left], np.sort(a[:left]))  # trues first, in order

@@ -53,6 +53,7 @@ int pine_gpu_packed_offset(int film_w, int film_h, int world, int x, int y, int*
   return 0;
 }
 int pine_gpu_film_unpack(int, int, int, int, const void*, void*, void*) { return fail(); }
+int pine_gpu_test_lomuto(const unsigned char*, int, int*, int*) { return fail(); }
 int pine_gpu_test_sampler(int, int, float*, int64_t) { return fail(); }
 int pine_gpu_test_rng(int, uint64_t*, int64_t) { return fail(); }
 int pine_gpu_test_sincos(int, const float*, int64_t, float*, float*) { return fail(); }
