@@ -808,7 +808,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
         if ((F & F_LDS_SCENE) && !lds_ok) continue;  // (a scene-in-global variant later in the table is the fallback when LDS is short)
-        if ((F & F_LDS_TOP) && (A.nodes.size() > 65535 || S.stack_total > kTravMaxStack)) continue;  // 16-bit stack entries; a parked record holds 32
+        if ((F & F_LDS_TOP) && A.nodes.size() > 65535) continue;  // 16-bit stack entries
         const size_t rest_bytes = size_t(S.blob_bytes - S.off_shapes);
         if ((F & F_LDS_REST) && rest_bytes > 12 * 1024) continue;
         const size_t stack_bytes = std::max(kQueueVariants[v].min_stack,
@@ -838,7 +838,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
       const unsigned F = fv[v].features;
       if ((F & need) != need) continue;
       if ((F & F_LDS_SCENE) && !lds_ok) continue;
-      if ((F & F_LDS_TOP) && (A.nodes.size() > 65535 || S.stack_total > kTravMaxStack)) continue;
+      if ((F & F_LDS_TOP) && A.nodes.size() > 65535) continue;
       const size_t rest_bytes = size_t(S.blob_bytes - S.off_shapes);
       if ((F & F_LDS_REST) && rest_bytes > 12 * 1024) continue;
       const size_t stack_bytes = std::max(fv[v].min_stack, size_t(S.stack_total) * kQBlock * ((F & F_LDS_TOP) ? sizeof(unsigned short) : sizeof(int)));
@@ -863,14 +863,16 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // metallic/transmission: sampler.h:317-324; BSSRDF channel pick: bxdf.cpp:335) make a pixel's
   // samples sequentially dependent: one item = the whole pixel.
   bool in_path_rng = false;
+  bool uber_rng = false;  // ... at any Uber vertex of a path, whatever came before it
   for (auto& m : dev_materials) {
     if (m.kind == MAT_SUBSURFACE) in_path_rng = true;
-    if (m.kind == MAT_UBER && (m.prog[2] >= 0 || m.prog[3] >= 0)) in_path_rng = true;  // value known only at the surface
+    if (m.kind == MAT_UBER && (m.prog[2] >= 0 || m.prog[3] >= 0)) uber_rng = true;  // value known only at the surface
     if (m.kind == MAT_UBER) {
-      if (m.metallic != 0 && m.metallic != 1) in_path_rng = true;
-      if (m.metallic != 1 && m.transmission != 0 && m.transmission != 1) in_path_rng = true;
+      if (m.metallic != 0 && m.metallic != 1) uber_rng = true;
+      if (m.metallic != 1 && m.transmission != 0 && m.transmission != 1) uber_rng = true;
     }
   }
+  in_path_rng |= uber_rng;
   p->serial_rng = in_path_rng;
   int kspi = prm->samples_per_item;
   if (in_path_rng) kspi = spp;
@@ -913,12 +915,19 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     W.idle_budget_ticks = (unsigned long long)(budget_s * 100e6);  // wall_clock64(): 100 MHz
   }
   W.debug_force_bail = (prm->flags & PINE_GPU_FLAG_DEBUG_FORCE_BAIL) ? 1 : 0;
-  // Parking is OFF by default: measured on the MI355X it removes a quarter of the VALU instructions of the
-  // mesh scene but the kernels wait on memory, and a parked traversal costs extra round trips.
-  W.trav_min_lanes = 0;
-  W.trav_min_trips = 8;
-  if (const char* e = getenv("PINE_GPU_TRAV_MIN_LANES")) W.trav_min_lanes = atoi(e);  // (0 = never park: measurement aid)
+  // Traversal stages of the X variants (pine_queue_kernel.h): a wave goes to retire / refill its lanes when fewer than
+  // trav_min_lanes of them are still travelling, at the earliest trav_min_trips trips after the last time.
+  W.trav_min_lanes = 48;
+  W.trav_min_trips = 4;
+  if (const char* e = getenv("PINE_GPU_TRAV_MIN_LANES")) W.trav_min_lanes = atoi(e);
   if (const char* e = getenv("PINE_GPU_TRAV_MIN_TRIPS")) W.trav_min_trips = atoi(e) > 0 ? atoi(e) : 1;
+  // Subsurface is the only in-path user of the RNG and only before a path's first non-delta bounce: such a path hands its
+  // pixel's next sample on when it has made that bounce (pine_queue_kernel.h, "sample tokens")
+  W.fork_sealed = (in_path_rng && !uber_rng && getenv("PINE_GPU_NO_FORK") == nullptr) ? 1 : 0;
+  // A workgroup claims 512 items at a time; when an item is a pixel's whole sample sequence (serial-RNG scenes) that is
+  // tens of milliseconds of its time, and the last claims decide when the launch ends: one 8x8 tile at a time there.
+  W.pool_items = in_path_rng ? 64 : 512;
+  if (const char* e = getenv("PINE_GPU_POOL_ITEMS")) W.pool_items = atoi(e) > 0 ? atoi(e) : W.pool_items;
   W.progress = nullptr;
   if (prm->flags & PINE_GPU_FLAG_PROGRESS) {
     HIP_OK(hipHostMalloc((void**)&p->h_progress, sizeof(unsigned long long), hipHostMallocMapped));
@@ -952,8 +961,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
   const size_t fold_slots = queued ? size_t(p->grid) * qctx : size_t(p->grid) * kBlock;
   HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * fold_slots * sizeof(float)));
-  if (queued)
-    HIP_OK(hipMalloc((void**)&p->d_ctxg, size_t(p->grid) * qctx * q_ctx_global_dwords(queue_features) * sizeof(uint32_t)));
+  if (queued) {
+    // per-context records, then (Subsurface variants) every workgroup's ring of sample-token slots
+    const size_t token_dwords = (queue_features & F_SSS) ? size_t(p->grid) * (qctx <= 1024 ? 1024 : 2048) * kQTokenDwords : 0;
+    HIP_OK(hipMalloc((void**)&p->d_ctxg, (size_t(p->grid) * qctx * q_ctx_global_dwords(queue_features) + token_dwords) * sizeof(uint32_t)));
+  }
   HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
   p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
   if (p->timed)

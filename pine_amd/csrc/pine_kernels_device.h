@@ -147,7 +147,9 @@ struct WorkParams {
   unsigned long long total_items;  // num_local_tiles * items_per_pixel * 64
   unsigned long long idle_budget_ticks;  // stage-queued kernel: a wave that finds no work for this long (100 MHz wall clock) bails out
   int debug_force_bail;  // test hook (PINE_GPU_FLAG_DEBUG_FORCE_BAIL): the first wave bails out at once
-  int trav_min_lanes, trav_min_trips;  // resumable traversal (pine_trav.h): park when fewer lanes than this still travel after this many trips
+  int trav_min_lanes, trav_min_trips;  // traversal stages (pine_queue_kernel.h): retire / refill when fewer lanes than this still travel, at the earliest after this many trips
+  int pool_items;   // stage-queued kernel: work items a workgroup claims from the global counter at a time
+  int fork_sealed;  // Subsurface variants: a path that can make no further RNG draw hands its pixel's next sample to another context
   unsigned long long* progress;  // host-mapped word (or null): work items claimed so far, stored now and then (get_progress)
 };
 // get_progress() (integrator.cpp:17-19): every 16th / 64th pool claim posts the claimed-item count to host memory
@@ -430,7 +432,8 @@ constexpr size_t kLdsFixedBytes = size_t(kOffStack) * 4;
 //   bits 0-11 sample index within the pixel (BlueSobolSampler::index / the low part of SobolSampler's index),
 //   12-20 sampler dimension, 21-26 Vertex::length, 27 Vertex::diffuse_length > 0 (all the path reads of it,
 //   path.cpp:93), 28 Vertex::is_delta, 29-30 the stage-queued kernel's BSSRDF walk status of the vertex being shaded
-//   (kWalk*).  Bit 31 stays clear (0xffffffff marks an empty context).
+//   (kWalk*), 31 "sealed" (stage-queued kernel, Subsurface variants: the path has released its pixel's sample token, see
+//   pine_queue_kernel.h).  0xffffffff marks an empty context (a length of 63 cannot occur: kMaxDepth is 32).
 constexpr int kMaxDeviceSpp = 4096;      // 12 bits of sample index
 constexpr int kMaxSamplerDimension = 511;  // 9 bits: BlueSampler wraps at 256; SobolSampler counts up to 8 draws per vertex
 enum : unsigned { kWalkNone = 0, kWalkRunning = 1, kWalkExited = 2, kWalkFailed = 3 };
@@ -446,9 +449,11 @@ struct PackedState {
   __device__ __forceinline__ void set_dim(int d) { v = (v & ~(0x1ffu << 12)) | (unsigned(d) << 12); }
   __device__ __forceinline__ void start_sample(int s) { v = unsigned(s) | (1u << 28); }  // dim 0, first_vertex()
   __device__ __forceinline__ void next_vertex(bool delta) {  // Vertex(pv, pdf, is_delta) path.cpp:18-19
-    v = (v & 0x1fffffu) + ((unsigned(length()) + 1u) << 21) + (((v >> 27) & 1u) | (delta ? 0u : 1u)) * (1u << 27) +
+    v = (v & 0x801fffffu) + ((unsigned(length()) + 1u) << 21) + (((v >> 27) & 1u) | (delta ? 0u : 1u)) * (1u << 27) +
         (delta ? (1u << 28) : 0u);
   }
+  __device__ __forceinline__ bool sealed() const { return (v >> 31) != 0u; }
+  __device__ __forceinline__ void set_sealed() { v |= 0x80000000u; }
 };
 
 template <unsigned F, int WAVES_PER_SIMD>

@@ -30,17 +30,20 @@ constexpr int kQBlock = PINE_QBLOCK;  // threads per workgroup (one workgroup pe
 #define PINE_QCTX 1536
 #endif
 constexpr int kQFields = 12;   // dwords of context state
-constexpr int kQPoolItems = 512;
 // queues: S shade, T terminal; W walk step (Subsurface variants); XS / XC parked shadow / closest-hit traversals
 // (F_LDS_TOP variants: pine_trav.h)
-enum : int { QS_S = 0, QS_T = 1, QS_W = 2, QS_XS = 3, QS_XC = 4, QS_MAX = 5 };
-constexpr int q_num_queues(unsigned F) { return (F & F_LDS_TOP) ? 5 : (F & F_SSS) ? 3 : 2; }
+enum : int { QS_S = 0, QS_T = 1, QS_W = 2, QS_XS = 3, QS_XC = 4 };
+constexpr int q_num_stage_queues(unsigned F) { return (F & F_LDS_TOP) ? 5 : (F & F_SSS) ? 3 : 2; }
+// Subsurface variants have two more rings that are not stages (see "sample tokens" below): K, the flags of the
+// workgroup's sample-token slots, and F, the ids of contexts with nothing to do
+constexpr int q_num_queues(unsigned F) { return q_num_stage_queues(F) + ((F & F_SSS) ? 2 : 0); }
 // context state fields (SoA in LDS: cst[field * kQCtx + id])
 enum : int { CF_OX, CF_OY, CF_OZ, CF_DX, CF_DY, CF_DZ, CF_TMAX, CF_ST, CF_PXY, CF_SBASE, CF_GEOM, CF_PRIM };
 constexpr unsigned kStFresh = 0xffffffffu;  // context has no path yet
-// control words: heads at 0..4; tails at 8..12 -- the S and T tails are ONE u64 (8..9) so that a stage reserves
+// control words: heads at 0..6; tails at 8..14 -- the S and T tails are ONE u64 (8..9) so that a stage reserves
 // slots in both with one atomic
-enum : int { QC_HEAD = 0, QC_TAIL = 8, QC_BUSY = 13, QC_LOCK = 14, QC_EXHAUSTED = 15, QC_PNEXT = 16, QC_PEND = 18, QC_ABORT = 20, QC_WORDS = 24 };
+enum : int { QC_HEAD = 0, QC_TAIL = 8, QC_BUSY = 16, QC_LOCK = 17, QC_EXHAUSTED = 18, QC_PNEXT = 20, QC_PEND = 22, QC_ABORT = 24, QC_WORDS = 32 };
+constexpr int kQTokenDwords = 8;  // a sample token (Subsurface variants): RNG state (4) | pixel, sample-buffer base, sample index, -
 constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a protocol bug must end the kernel, not hang the GPU
 constexpr int kQWinDwords = 5;  // per-thread sampler window: 3 dwords of ranking bytes (12 dimensions) + 2 of scrambling bytes
 
@@ -82,7 +85,10 @@ template <unsigned F, int CTX = PINE_QCTX>
 __global__ void __launch_bounds__(kQBlock, kQBlock / 256)
 path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
                   float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
-  constexpr int kNQ = q_num_queues(F);
+  constexpr int kNQ = q_num_queues(F);            // rings in LDS
+  constexpr int kNStage = q_num_stage_queues(F);  // ... of which the first kNStage are stage queues
+  constexpr bool kFork = (F & F_SSS) != 0;        // sample tokens (below)
+  constexpr int QS_K = kNStage, QS_F = kNStage + 1;
   constexpr bool kX = (F & F_LDS_TOP) != 0;  // resumable traversals + the XS / XC queues
   static_assert(!(F & F_LDS_REST) || kX, "F_LDS_REST is an option of the F_LDS_TOP variants");
   constexpr int kQCtxGlobalDwords = q_ctx_global_dwords(F);
@@ -198,6 +204,10 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     return reinterpret_cast<float4*>(fold) + ((ctx_base + size_t(id)) * size_t(S.max_path_length) + size_t(level)) * 2;
   };
   auto ctx_global = [&](int id) -> uint32_t* { return ctxg + (ctx_base + size_t(id)) * kQCtxGlobalDwords; };
+  // sample tokens (kFork): the workgroup's kQRing slots sit behind ALL context records
+  auto token_slot = [&](unsigned pos) -> uint32_t* {
+    return ctxg + size_t(gridDim.x) * kQCtx * kQCtxGlobalDwords + (size_t(blockIdx.x) * kQRing + pos) * kQTokenDwords;
+  };
   auto lds_load = [](const unsigned* p) -> unsigned { return __atomic_load_n(p, __ATOMIC_RELAXED); };
 
   // push the contexts of lanes with to_s / to_t to the shade / terminal queue: ballot compaction,
@@ -244,30 +254,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     to_shade = !terminal;
     to_term = terminal;
   };
-  // When does a wave stop a traversal and park the lanes still travelling?  When fewer than trav_min_lanes of them are
-  // left after trav_min_trips trips AND the workgroup has other work queued (otherwise they may as well finish here).
-  const int trav_min_lanes = W.trav_min_lanes, trav_min_trips = W.trav_min_trips;
-  auto other_work = [&]() -> bool {
-    unsigned n = 0;
-#pragma unroll
-    for (int q = 0; q < kNQ; q++) n += lds_load(&qctl[QC_TAIL + q]) - lds_load(&qctl[QC_HEAD + q]);
-    return __builtin_amdgcn_readfirstlane(n) >= 48u;
-  };
-  auto run_trav = [&](auto any_tag, DRay& ray, TravState& ts) {
-    constexpr bool ANY = decltype(any_tag)::value;
-    // (the policy check reads the queue counters, so it runs between bursts of trips, not in every trip)
-    int min_trips = trav_min_trips;
-    while (true) {
-      trav_run<ANY, F, kStride>(V, ray, ts, stack, trav_min_lanes, min_trips);
-      const unsigned long long left = __ballot(ts.done == 0);
-      if (left == 0 || other_work()) break;
-      min_trips = 8;  // nothing else to do: keep going, look again in a few trips
-      if (__popcll(left) >= trav_min_lanes) min_trips = trav_min_trips;
-    }
-  };
   auto trav_record = [&](int id) -> uint32_t* { return ctxg + (ctx_base + size_t(id)) * kQCtxGlobalDwords + kQCtxTravOffset; };
-  // trace the context's new ray (closest hit), record the hit, classify (finish_hit).  X variants: a lane whose
-  // traversal is stopped parks it and the context goes to XC.
+  // trace the context's new ray (closest hit), record the hit, classify (finish_hit).  X variants: the ray waits in
+  // the context and the context goes to XC; the traversal stage traces it.
   auto extend = [&](int id, f3 o, f3 d, float tmax, PackedState st, bool& to_shade, bool& to_term, bool& to_xc) {
     DRay ray{o, d, 0.0f, tmax};
     SEC_MARK(5);  // S: BSDF sample + fold store + spawn  /  T: camera ray
@@ -279,17 +268,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     cstf[CF_DZ * kQCtx + id] = d.z;
     cstu[CF_ST * kQCtx + id] = st.v;
     if constexpr (kX) {
-      TravState ts;
-      trav_begin(V, ts);
-      run_trav(std::false_type{}, ray, ts);
-      SEC_MARK(6);  // closest-hit traversal
-      if (!ts.done) {
-        cstf[CF_TMAX * kQCtx + id] = ray.tmax;
-        trav_park<kStride>(trav_record(id), ts, stack);
-        to_xc = true;
-      } else {
-        finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
-      }
+      cstf[CF_TMAX * kQCtx + id] = tmax;
+      to_xc = true;  // traced by stage XC
     } else {
       int geom = -1, prim = 0;
       const bool hit = scene_traverse<false, F, kStride>(V, ray, stack, geom, prim);
@@ -310,6 +290,108 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     counters->bail_b = b;
   };
 
+  // ---- traversal stage with refill (X variants) ----
+  // A wave that picked XS / XC keeps its lanes' traversals in registers and loops: advance every travelling lane a few
+  // trips; retire the lanes that finished (XS: clear the direct term of an occluded vertex, context -> XC or T; XC:
+  // record the hit, context -> S or T); hand the free lanes NEW contexts from the same queue.  So the rays of a wave
+  // are in different phases of their traversals, but nearly all 64 lanes are travelling as long as the queue has
+  // entries -- where one traversal per stage pass runs each wave until its longest ray is done (measured: 19.5 of 64
+  // lanes travelling in an average trip of the icosphere scene, 37 on the 10 000-cone scene).
+  const int trav_keep_lanes = W.trav_min_lanes, trav_min_trips = W.trav_min_trips;
+  auto trav_stage = [&](auto any_tag, int id) {
+    constexpr bool ANY = decltype(any_tag)::value;
+    constexpr int Q = ANY ? QS_XS : QS_XC;
+    bool fresh = id >= 0;
+    TravState ts;
+    trav_begin(V, ts);
+    ts.done = 1;
+    DRay ray{mk3(0.0f), mk3(1.0f), 0.0f, 0.0f};
+    DRayOct oct = make_oct(ray);
+    unsigned flags = 0;
+    while (true) {
+      // ---- the rays of the lanes that just got a context ----
+      if (fresh) {
+        if (ANY) {
+          const float4* r4 = reinterpret_cast<const float4*>(trav_record(id));
+          const float4 a = r4[0], b = r4[1];
+          ray = DRay{f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, 0.0f, b.z};
+          flags = __float_as_uint(b.w);
+        } else {
+          ray.o = f3{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
+          ray.d = f3{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
+          ray.tmin = 0.0f;
+          ray.tmax = cstf[CF_TMAX * kQCtx + id];
+        }
+        oct = make_oct(ray);
+        trav_begin(V, ts);
+        fresh = false;
+      }
+      trav_trips<ANY, F, kStride>(V, ray, oct, ts, stack, trav_keep_lanes, trav_min_trips);
+      SEC_MARK(ANY ? 3 : 6);
+      // ---- retire ----
+      bool to_shade = false, to_term = false, to_xc = false;
+      const bool retire = id >= 0 && ts.done != 0;
+      if (retire) {
+        const PackedState st{cstu[CF_ST * kQCtx + id]};
+        if (ANY) {
+          const bool occluded = ts.hit_geom >= 0;
+          if (flags & kTravTerminalAfterShadow) {
+            if (occluded) {  // Lo = min(beta * 0, 8) = 0
+              cstf[CF_DX * kQCtx + id] = 0.0f;
+              cstf[CF_DY * kQCtx + id] = 0.0f;
+              cstf[CF_DZ * kQCtx + id] = 0.0f;
+            }
+            to_term = true;
+          } else {
+            if (occluded) {  // the vertex that cast this ray is one level up: its direct term is zero
+              float4* q = fold_entry(id, st.length() - 1);
+              const float4 e = q[0];
+              q[0] = make_float4(0.0f, 0.0f, 0.0f, e.w);
+            }
+            to_xc = true;  // its new ray waits in the context
+          }
+        } else {
+          finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      push2(to_shade, to_term, id);
+      if (ANY) push_q(QS_XC, to_xc, id);
+      if (retire) id = -1;
+      // ---- refill the free lanes from this stage's queue ----
+      const unsigned long long free_lanes = __ballot(id < 0);
+      if (free_lanes != 0) {
+        const unsigned h0 = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_HEAD + Q]));  // (head before tail; the CAS below confirms the head)
+        const unsigned avail = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_TAIL + Q])) - h0;
+        if (avail != 0u) {
+          const unsigned nfree = unsigned(__popcll(free_lanes));
+          const unsigned want = avail < nfree ? avail : nfree;
+          unsigned got = 0;
+          if (lane == 0) got = atomicCAS(&qctl[QC_HEAD + Q], h0, h0 + want) == h0 ? 1u : 0u;  // (lost the race: try again next round)
+          if (__builtin_amdgcn_readfirstlane(got)) {
+            const unsigned rank = unsigned(__popcll(free_lanes & ((1ull << lane) - 1ull)));
+            if (id < 0 && rank < want) {
+              unsigned* slot = &ring[Q * kQRing + ((h0 + rank) & (kQRing - 1))];
+              unsigned v, tries = 0;
+              while ((v = atomicExch(slot, 0u)) == 0u) {
+                if (++tries > kQSpinLimit) {
+                  bail(2, unsigned(Q), h0 + rank);
+                  break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+              }
+              id = int(v) - 1;
+              fresh = id >= 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          }
+        }
+        if (__ballot(id >= 0) == 0) break;
+      }
+      if (__builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_ABORT])) != 0u) break;
+    }
+  };
+
   // (No cap on the number of trips: a trip that finds work retires at least one stage of one path, and the
   // work of a launch is finite; the trips that find none are bounded in wall-clock time below.)
   unsigned long long idle_since = 0;
@@ -326,16 +408,16 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     {
       auto uload = [&](int w) -> unsigned { return __builtin_amdgcn_readfirstlane(lds_load(&qctl[w])); };
       // heads first, then tails: heads and tails only grow, so a count can only be over-estimated
-      unsigned hq[kNQ], cq[kNQ];
+      unsigned hq[kNStage], cq[kNStage];
 #pragma unroll
-      for (int q = 0; q < kNQ; q++) hq[q] = uload(QC_HEAD + q);
+      for (int q = 0; q < kNStage; q++) hq[q] = uload(QC_HEAD + q);
 #pragma unroll
-      for (int q = 0; q < kNQ; q++) cq[q] = uload(QC_TAIL + q) - hq[q];
+      for (int q = 0; q < kNStage; q++) cq[q] = uload(QC_TAIL + q) - hq[q];
       const unsigned busy = uload(QC_BUSY);
       int best = cq[QS_T] > cq[QS_S] ? QS_T : QS_S;
       unsigned cnt_best = cq[best], h_best = hq[best], cnt_all = cq[QS_S] + cq[QS_T];
 #pragma unroll
-      for (int q = 2; q < kNQ; q++) {
+      for (int q = 2; q < kNStage; q++) {
         cnt_all += cq[q];
         if (cq[q] > cnt_best) {
           best = q;
@@ -409,6 +491,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if (stage == QS_S) {
       // ================= shade a non-terminal vertex (path.cpp:91-120) =================
       bool to_shade = false, to_term = false, to_walk = false, to_xs = false, to_xc = false;
+      bool release = false;  // (kFork) this lane's path seals here and its pixel has samples left: a token goes out
       if (valid) {
         const f3 ray_o{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
         const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
@@ -661,17 +744,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const bool continues = !start_walk && bxdf_sample<F, kSM>(bx, T, sampler, bs);
         const f3 wo_world = mul(l2w, bs.wo);
         const float cosine = absdot(wo_world, it.n);
-        // ---- X variants: the deferred shadow ray (resumable; a lane stopped in it parks and goes to XS) ----
-        bool parked_shadow = false;
-        TravState sts;
-        if constexpr (kX) {
-          sts.done = 1;
-          if (have_shadow) trav_begin(V, sts);
-          run_trav(std::true_type{}, shadow_ray, sts);
-          SEC_MARK(3);  // S: shadow traversal
-          parked_shadow = have_shadow && !sts.done;
-          if (have_shadow && sts.done && sts.hit_geom >= 0) nee = mk3(0.0f);  // occluded
-        }
+        // ---- X variants: the shadow ray is traced by stage XS; the fold entry / result below hold the direct term as if
+        // visible, and XS clears it when the ray turns out occluded ----
+        const bool parked_shadow = kX && have_shadow;
         if (start_walk) {
           to_walk = true;  // (state stored above; the context continues in stage W)
         } else if (continues) {
@@ -685,6 +760,14 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           const DRay nr = spawn_ray(it.p, it.n, wo_world, kFloatMax);
           st.set_dim(sampler.dimension);
           st.next_vertex(bs.is_delta);
+          if constexpr (kFork) {
+            // sealed: after its first non-delta bounce a path makes no RNG draw any more (a Subsurface vertex is then
+            // plain diffuse, above), so the pixel's RNG state is final for this sample and the NEXT sample can start
+            if (W.fork_sealed && !st.sealed() && st.diffuse_length() > 0) {
+              st.set_sealed();
+              release = ((st.s_cur() + 1) & (W.samples_per_item - 1)) != 0;
+            }
+          }
           if (kX && parked_shadow) {
             // the fold entry above holds the direct term as if visible; stage XS clears it if the ray is occluded, then
             // traces the new ray, which waits in the context
@@ -719,12 +802,29 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             float4* r4 = reinterpret_cast<float4*>(rec);
             r4[0] = make_float4(shadow_ray.o.x, shadow_ray.o.y, shadow_ray.o.z, shadow_ray.d.x);
             r4[1] = make_float4(shadow_ray.d.y, shadow_ray.d.z, shadow_ray.tmax, __uint_as_float(continues ? 0u : kTravTerminalAfterShadow));
-            trav_park<kStride>(rec, sts, stack);
             to_xs = true;
           }
         }
       }
       SEC_MARK(9);
+      unsigned long long rel_mask = 0;
+      unsigned rel_pos = 0;
+      if constexpr (kFork) {
+        rel_mask = __ballot(release);
+        if (rel_mask != 0) {
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(&qctl[QC_TAIL + QS_K], unsigned(__popcll(rel_mask)));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (release) {
+            rel_pos = (base + unsigned(__popcll(rel_mask & ((1ull << lane) - 1ull)))) & (kQRing - 1);
+            const uint4 g = *reinterpret_cast<const uint4*>(ctx_global(id));  // the pixel's RNG state: final for this sample
+            const PackedState st{cstu[CF_ST * kQCtx + id]};
+            uint4* tok = reinterpret_cast<uint4*>(token_slot(rel_pos));
+            tok[0] = g;
+            tok[1] = make_uint4(cstu[CF_PXY * kQCtx + id], cstu[CF_SBASE * kQCtx + id], unsigned(st.s_cur() + 1), 0u);
+          }
+        }
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       push2(to_shade, to_term, id);
       if constexpr (F & F_SSS) push_w(to_walk, id);
@@ -732,84 +832,44 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         push_q(QS_XS, to_xs, id);
         push_q(QS_XC, to_xc, id);
       }
-    } else if (kX && (stage == QS_XS || stage == QS_XC)) {
-      // ================= parked traversals, regrouped (pine_trav.h) =================
-      bool to_shade = false, to_term = false, to_xs = false, to_xc = false;
-      if constexpr (kX) {
-        TravState ts;
-        ts.done = 1;
-        DRay ray{mk3(0.0f), mk3(1.0f), 0.0f, 0.0f};
-        PackedState st{0};
-        uint32_t* rec = nullptr;
-        bool closest = false;  // this lane has a closest-hit traversal to run in the second phase
-        auto context_ray = [&]() {
-          ray.o = f3{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
-          ray.d = f3{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
-          ray.tmin = 0.0f;
-          ray.tmax = cstf[CF_TMAX * kQCtx + id];
-        };
-        if (valid) {
-          rec = trav_record(id);
-          st.v = cstu[CF_ST * kQCtx + id];
-          trav_unpark<kStride>(rec, ts, stack);
-        }
-        if (stage == QS_XS) {
-          unsigned flags = 0;
-          if (valid) {
-            const float4* r4 = reinterpret_cast<const float4*>(rec);
-            const float4 a = r4[0], b = r4[1];
-            ray = DRay{f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, 0.0f, b.z};
-            flags = __float_as_uint(b.w);
-          }
-          run_trav(std::true_type{}, ray, ts);
-          SEC_MARK(3);
-          if (valid) {
-            if (!ts.done) {
-              trav_park<kStride>(rec, ts, stack);  // (an any-hit query leaves the ray as it was)
-              to_xs = true;
-              ts.done = 1;
-            } else {
-              const bool occluded = ts.hit_geom >= 0;
-              if (flags & kTravTerminalAfterShadow) {
-                if (occluded) {  // Lo = min(beta * 0, 8) = 0
-                  cstf[CF_DX * kQCtx + id] = 0.0f;
-                  cstf[CF_DY * kQCtx + id] = 0.0f;
-                  cstf[CF_DZ * kQCtx + id] = 0.0f;
+      if constexpr (kFork) {
+        if (rel_mask != 0) {
+          if (release) __atomic_store_n(&ring[QS_K * kQRing + rel_pos], 1u, __ATOMIC_RELAXED);
+          // contexts with nothing to do wait in F: wake one per token (they enter stage T as empty contexts and find
+          // the tokens there)
+          const unsigned fh = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_HEAD + QS_F]));
+          const unsigned favail = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_TAIL + QS_F])) - fh;
+          if (favail != 0u) {
+            const unsigned nrel = unsigned(__popcll(rel_mask));
+            const unsigned want = favail < nrel ? favail : nrel;
+            unsigned got = 0;
+            if (lane == 0) got = atomicCAS(&qctl[QC_HEAD + QS_F], fh, fh + want) == fh ? 1u : 0u;
+            if (__builtin_amdgcn_readfirstlane(got)) {
+              int fid = -1;
+              if (lane < want) {
+                unsigned* slot = &ring[QS_F * kQRing + ((fh + lane) & (kQRing - 1))];
+                unsigned v, tries = 0;
+                while ((v = atomicExch(slot, 0u)) == 0u) {
+                  if (++tries > kQSpinLimit) {
+                    bail(6, unsigned(QS_F), fh + lane);
+                    break;
+                  }
+                  __builtin_amdgcn_s_sleep(1);
                 }
-                to_term = true;
-              } else {
-                if (occluded) {  // the vertex that cast this ray is one level up: its direct term is zero
-                  float4* q = fold_entry(id, st.length() - 1);
-                  const float4 e = q[0];
-                  q[0] = make_float4(0.0f, 0.0f, 0.0f, e.w);
-                }
-                context_ray();
-                trav_begin(V, ts);
-                closest = true;
+                fid = int(v) - 1;
               }
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              push2(false, fid >= 0, fid);
             }
-          }
-        } else if (valid) {
-          context_ray();  // (CF_TMAX holds the nearest hit so far)
-          closest = true;
-        }
-        run_trav(std::false_type{}, ray, ts);
-        SEC_MARK(6);
-        if (closest) {
-          if (!ts.done) {
-            cstf[CF_TMAX * kQCtx + id] = ray.tmax;
-            trav_park<kStride>(rec, ts, stack);
-            to_xc = true;
-          } else {
-            finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
           }
         }
       }
-      SEC_MARK(9);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      push2(to_shade, to_term, id);
-      push_q(QS_XS, to_xs, id);
-      push_q(QS_XC, to_xc, id);
+    } else if (kX && (stage == QS_XS || stage == QS_XC)) {
+      // ================= traversal stages: XS any-hit (shadow rays), XC closest hit (pine_trav.h) =================
+      if constexpr (kX) {
+        if (stage == QS_XS) trav_stage(std::true_type{}, valid ? id : -1);
+        else trav_stage(std::false_type{}, valid ? id : -1);
+      }
     } else if ((F & F_SSS) != 0 && stage == QS_W) {
       // ================= one step of a BSSRDF random walk (bxdf.cpp:340-351) =================
       bool to_walk = false, to_shade = false;
@@ -874,6 +934,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       // ================= terminal: result, backward fold, store, next sample / item =================
       bool need_item = false, have_path = false;
       bool to_shade2 = false, to_term2 = false, to_xc2 = false;
+      bool to_free = false;  // (kFork) nothing to do for this context now: it waits in F
       bool fresh_rng = false;  // the context took a new work item this round: its RNG state is in item_rng, not yet in memory
       DRng item_rng{0, 0};
       unsigned pxy = 0, sample_base = 0;
@@ -962,7 +1023,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           pxy = cstu[CF_PXY * kQCtx + id];
           samples[size_t(sample_base) + size_t(s_now) * 64u] = make_float4(Li.x, Li.y, Li.z, float(pv_length + 1));
           s_next = s_now + 1;
-          if ((s_next & (W.samples_per_item - 1)) == 0) need_item = true;
+          if ((kFork && st.sealed()) || (s_next & (W.samples_per_item - 1)) == 0) need_item = true;  // (sealed: the pixel's next sample went out as a token)
           else have_path = true;
         }
       }
@@ -976,9 +1037,11 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           need_item = false;
           break;
         }
-        const unsigned want = __popcll(m);
+        const unsigned want_all = __popcll(m);
+        unsigned want = want_all;
         unsigned long long base = 0;
         unsigned got = 0;
+        unsigned kbase = 0, kgot = 0;  // (kFork) sample tokens taken: ring positions [kbase, kbase + kgot)
         if (lane == 0) {
           unsigned tries = 0;
           while (atomicCAS(&qctl[QC_LOCK], 0u, 1u) != 0u) {
@@ -989,16 +1052,25 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             __builtin_amdgcn_s_sleep(1);
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if constexpr (kFork) {
+            // waiting sample tokens first (only holders of the lock move K's head); NEW pixels only when none waits:
+            // then every pixel in flight has its token in a running path, so there are never more tokens than contexts
+            kbase = lds_load(&qctl[QC_HEAD + QS_K]);
+            const unsigned kavail = lds_load(&qctl[QC_TAIL + QS_K]) - kbase;
+            kgot = want < kavail ? want : kavail;
+            __atomic_store_n(&qctl[QC_HEAD + QS_K], kbase + kgot, __ATOMIC_RELAXED);
+            want -= kgot;
+          }
           unsigned long long nx = (unsigned long long)lds_load(&qctl[QC_PNEXT]) | ((unsigned long long)lds_load(&qctl[QC_PNEXT + 1]) << 32);
           unsigned long long en = (unsigned long long)lds_load(&qctl[QC_PEND]) | ((unsigned long long)lds_load(&qctl[QC_PEND + 1]) << 32);
-          if (nx == en && lds_load(&qctl[QC_EXHAUSTED]) == 0u) {
-            const unsigned long long b = atomicAdd(&counters->next_item, (unsigned long long)kQPoolItems);
+          if (want != 0u && nx == en && lds_load(&qctl[QC_EXHAUSTED]) == 0u) {
+            const unsigned long long b = atomicAdd(&counters->next_item, (unsigned long long)W.pool_items);
             if (b >= W.total_items) {
               __atomic_store_n(&qctl[QC_EXHAUSTED], 1u, __ATOMIC_RELAXED);
             } else {
               post_progress(W, b, 9);
               nx = b;
-              en = b + kQPoolItems < W.total_items ? b + kQPoolItems : W.total_items;
+              en = b + W.pool_items < W.total_items ? b + W.pool_items : W.total_items;
             }
           }
           const unsigned long long avail = en - nx;
@@ -1014,12 +1086,42 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         }
         base = __shfl(base, 0);
         got = __shfl(got, 0);
-        if (got == 0) {
-          // global queue exhausted: these contexts retire (they are simply not pushed anywhere)
+        if constexpr (kFork) {
+          kbase = __shfl(kbase, 0);
+          kgot = __shfl(kgot, 0);
+        }
+        if (got == 0 && kgot == 0) {
+          // global queue exhausted (and no token waits): these contexts retire -- plain variants: they are simply not
+          // pushed anywhere; kFork: they wait in F until a path releases a token
+          if constexpr (kFork) to_free = need_item;
           need_item = false;
           break;
         }
-        const unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+        unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (kFork && need_item && rank < kgot) {
+          // a waiting sample of a pixel in flight: its token holds the pixel's RNG state as the previous sample left it
+          const unsigned pos = (kbase + rank) & (kQRing - 1);
+          unsigned* flag = &ring[QS_K * kQRing + pos];
+          unsigned tries = 0;
+          while (atomicExch(flag, 0u) == 0u) {
+            if (++tries > kQSpinLimit) {
+              bail(8, pos, kbase);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          const uint4* tok = reinterpret_cast<const uint4*>(token_slot(pos));
+          const uint4 g = tok[0], b = tok[1];
+          need_item = false;
+          have_path = true;
+          pxy = b.x;
+          sample_base = b.y;
+          s_next = int(b.z);
+          item_rng = DRng{uint64_t(g.x) | (uint64_t(g.y) << 32), uint64_t(g.z) | (uint64_t(g.w) << 32)};
+          fresh_rng = true;
+        }
+        rank -= kgot;  // (wraps for the lanes served above: they no longer need an item)
         if (need_item && rank < got) {
           const unsigned long long item = base + rank;
           const ItemInfo itf = decode_item(W, S.cam.W, S.cam.H, S.spp, item);
@@ -1041,6 +1143,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           }
         }
       }
+      if constexpr (kFork)
+        if (to_free) cstu[CF_ST * kQCtx + id] = kStFresh;  // (woken through stage T as an empty context)
       SEC_MARK(8);  // T: work-item hand-out
       // ---- start the next camera sample (path.cpp:34-36) ----
       if (valid && have_path) {
@@ -1066,6 +1170,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       push2(to_shade2, to_term2, id);
       if constexpr (kX) push_q(QS_XC, to_xc2, id);
+      if constexpr (kFork) push_q(QS_F, to_free, id);
     }
     if (lane == 0) atomicSub(&qctl[QC_BUSY], 1u);
   }

@@ -30,10 +30,8 @@ struct TravState {
   int hit_prim;  // triangle index of a mesh hit
   int done;      // 0 travelling, 1 finished
 };
-constexpr int kTravStateInts = 16;
-constexpr int kTravMaxStack = 32;                                   // entries a suspended record can hold
-constexpr int kTravRecordDwords = 8 + kTravStateInts + kTravMaxStack / 2;  // shadow ray 7 + flags | state | packed stack
-// flags word of a suspended record
+constexpr int kTravRecordDwords = 8;  // a context's shadow-ray record in its global record: origin, direction, tmax, flags
+// flags word of a shadow-ray record
 enum : unsigned { kTravTerminalAfterShadow = 1u };  // the vertex has no continuation: after the shadow ray the context goes to stage T
 
 __device__ __forceinline__ void trav_begin(const SceneView& S, TravState& ts) {
@@ -62,16 +60,21 @@ __device__ __forceinline__ void trav_begin(const SceneView& S, TravState& ts) {
   }
 }
 
-// Run the lanes whose `ts.done == 0` until every one is finished, or until fewer than `min_lanes` of the
-// wave are still travelling after at least `min_trips` trips (then the remaining lanes keep done == 0 and
-// the caller parks them).  ANY: BVH::hit (first hit ends the ray, hit_geom = 0); else BVH::intersect.
+// Advance the travelling lanes (`ts.done == 0`) one step per trip until every one is finished, or until fewer than
+// `keep_lanes` of the wave are still travelling after at least `min_trips` trips (the caller then retires the finished
+// lanes and gives them new rays).  ANY: BVH::hit (first hit ends the ray, hit_geom = 0); else BVH::intersect.
+//
+// A trip is ONE heavy step per lane -- a leaf primitive test, or a node visit -- followed by the cheap bookkeeping that
+// decides the lane's next step (second leaf range, pop, return from a mesh, finished).  The bookkeeping used to be trips
+// of its own: a lane that only had to pop waited a whole trip of the other lanes' node and primitive tests for it.  The
+// order of the heavy steps per ray is unchanged: primitives pending > second pending range > node > pop > mesh return.
 template <bool ANY, unsigned F, int STRIDE, class StackT>
-__device__ __forceinline__ void trav_run(const SceneView& S, DRay& ray, TravState& ts, StackT* stack, int min_lanes, int min_trips) {
-  const DRayOct oct = make_oct(ray);
+__device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const DRayOct& oct, TravState& ts, StackT* stack, int keep_lanes,
+                                           int min_trips) {
   for (int trip = 0;; trip++) {
     const unsigned long long travelling = __ballot(ts.done == 0);
     if (travelling == 0) break;
-    if (trip >= min_trips && __popcll(travelling) < min_lanes) break;
+    if (trip >= min_trips && __popcll(travelling) < keep_lanes) break;
     if (ts.done) continue;
     if (ts.pan > 0) {
       // ---- one pending leaf primitive ----
@@ -124,9 +127,6 @@ __device__ __forceinline__ void trav_run(const SceneView& S, DRay& ray, TravStat
           ts.hit_geom = word;
         }
       }
-    } else if (ts.pbn > 0) {
-      ts.pa = ts.pb, ts.pan = ts.pbn;
-      ts.pbn = 0;
     } else if (ts.next >= 0) {
       // ---- one node: both child boxes against the tmax of this moment (bvh.cpp:405-446) ----
       const DNode nd = fetch_node<F>(S, ts.next);
@@ -153,48 +153,29 @@ __device__ __forceinline__ void trav_run(const SceneView& S, DRay& ray, TravStat
           ts.sp++;
         } else ts.next = l;
       } else ts.next = r;  // (-1 when neither child is an inner node to visit)
-    } else if (ts.sp > (ts.mesh_base >= 0 ? ts.mesh_base : 0)) {
-      ts.next = int(stack[(--ts.sp) * STRIDE]);
-    } else if (ts.mesh_base >= 0) {
-      // mesh exhausted: back to the top-level leaf it was a primitive of
-      ts.next = ts.r_next, ts.pa = ts.r_pa, ts.pan = ts.r_pan, ts.pb = ts.r_pb, ts.pbn = ts.r_pbn;
-      ts.mesh_base = -1;
-    } else {
-      ts.done = 1;
     }
-  }
-}
-
-// Park / restore a travelling lane: the state words and the lane's stack entries to / from the context's
-// global record (dwords [8, 8 + kTravStateInts) and the packed stack after them).
-template <int STRIDE, class StackT>
-__device__ __forceinline__ void trav_park(uint32_t* rec, const TravState& ts, const StackT* stack) {
-  uint4* q = reinterpret_cast<uint4*>(rec + 8);
-  q[0] = make_uint4(unsigned(ts.next), unsigned(ts.sp), unsigned(ts.pa), unsigned(ts.pan));
-  q[1] = make_uint4(unsigned(ts.pb), unsigned(ts.pbn), unsigned(ts.mesh_base), unsigned(ts.mesh_word));
-  q[2] = make_uint4(unsigned(ts.r_next), unsigned(ts.r_pa), unsigned(ts.r_pan), unsigned(ts.r_pb));
-  q[3] = make_uint4(unsigned(ts.r_pbn), unsigned(ts.hit_geom), unsigned(ts.hit_prim), 0u);
-  uint32_t* sw = rec + 8 + kTravStateInts;
-  for (int i = 0; i < ts.sp; i += 2) {
-    const unsigned lo = unsigned(stack[i * STRIDE]) & 0xffffu;
-    const unsigned hi = i + 1 < ts.sp ? unsigned(stack[(i + 1) * STRIDE]) & 0xffffu : 0u;
-    sw[i >> 1] = lo | (hi << 16);
-  }
-}
-template <int STRIDE, class StackT>
-__device__ __forceinline__ void trav_unpark(const uint32_t* rec, TravState& ts, StackT* stack) {
-  const uint4* q = reinterpret_cast<const uint4*>(rec + 8);
-  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-  ts.next = int(a.x), ts.sp = int(a.y), ts.pa = int(a.z), ts.pan = int(a.w);
-  ts.pb = int(b.x), ts.pbn = int(b.y), ts.mesh_base = int(b.z), ts.mesh_word = int(b.w);
-  ts.r_next = int(c.x), ts.r_pa = int(c.y), ts.r_pan = int(c.z), ts.r_pb = int(c.w);
-  ts.r_pbn = int(d.x), ts.hit_geom = int(d.y), ts.hit_prim = int(d.z);
-  ts.done = 0;
-  const uint32_t* sw = rec + 8 + kTravStateInts;
-  for (int i = 0; i < ts.sp; i += 2) {
-    const unsigned w = sw[i >> 1];
-    stack[i * STRIDE] = StackT(w & 0xffffu);
-    if (i + 1 < ts.sp) stack[(i + 1) * STRIDE] = StackT(w >> 16);
+    // ---- what this lane does in the next trip ----
+    if (!ts.done && ts.pan == 0) {
+      if (ts.pbn > 0) {
+        ts.pa = ts.pb, ts.pan = ts.pbn;
+        ts.pbn = 0;
+      } else if (ts.next < 0) {
+        if (ts.sp > (ts.mesh_base >= 0 ? ts.mesh_base : 0)) {
+          ts.next = int(stack[(--ts.sp) * STRIDE]);
+        } else if (ts.mesh_base >= 0) {
+          // mesh exhausted: back to the top-level leaf it was a primitive of (whatever that state needs next --
+          // its pending primitives, its node, or a pop -- the next trip does)
+          ts.next = ts.r_next, ts.pa = ts.r_pa, ts.pan = ts.r_pan, ts.pb = ts.r_pb, ts.pbn = ts.r_pbn;
+          ts.mesh_base = -1;
+          if (ts.pan == 0 && ts.pbn > 0) {
+            ts.pa = ts.pb, ts.pan = ts.pbn;
+            ts.pbn = 0;
+          }
+        } else {
+          ts.done = 1;
+        }
+      }
+    }
   }
 }
 
