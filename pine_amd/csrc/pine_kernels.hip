@@ -916,9 +916,12 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   W.debug_force_bail = (prm->flags & PINE_GPU_FLAG_DEBUG_FORCE_BAIL) ? 1 : 0;
   // Traversal stages of the X variants (pine_queue_kernel.h): a wave goes to retire / refill its lanes when fewer than
-  // trav_min_lanes of them are still travelling, at the earliest trav_min_trips trips after the last time.
-  W.trav_min_lanes = 48;
-  W.trav_min_trips = 4;
+  // trav_min_lanes of them are still travelling, at the earliest trav_min_trips trips after the last time.  Measured
+  // (DESIGN.md 6.3): refilling pays when (nearly) the whole BVH sits in LDS (icosphere scene: 212 -> 185 ms); when most node
+  // fetches go to L2 it costs -- the rays a wave picks up later are not the neighbours of the ones it has, and the
+  // traversal waits on memory (10 000 cones: 9.8 ms without, 10.9 ms with) -- so there a wave runs its rays to the end.
+  W.trav_min_lanes = (S.lds_nodes > 0 && size_t(S.lds_nodes) * 10 >= A.nodes.size() * 9) ? 48 : 0;  // (nearly) all nodes in LDS
+  W.trav_min_trips = 8;
   if (const char* e = getenv("PINE_GPU_TRAV_MIN_LANES")) W.trav_min_lanes = atoi(e);
   if (const char* e = getenv("PINE_GPU_TRAV_MIN_TRIPS")) W.trav_min_trips = atoi(e) > 0 ? atoi(e) : 1;
   // Subsurface is the only in-path user of the RNG and only before a path's first non-delta bounce: such a path hands its
@@ -926,6 +929,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   W.fork_sealed = (in_path_rng && !uber_rng && getenv("PINE_GPU_NO_FORK") == nullptr) ? 1 : 0;
   // A workgroup claims 512 items at a time; when an item is a pixel's whole sample sequence (serial-RNG scenes) that is
   // tens of milliseconds of its time, and the last claims decide when the launch ends: one 8x8 tile at a time there.
+  W.pick_spins = 8;
+  if (const char* e = getenv("PINE_GPU_PICK_SPINS")) W.pick_spins = atoi(e) > 0 ? atoi(e) : 1;
   W.pool_items = in_path_rng ? 64 : 512;
   if (const char* e = getenv("PINE_GPU_POOL_ITEMS")) W.pool_items = atoi(e) > 0 ? atoi(e) : W.pool_items;
   W.progress = nullptr;

@@ -148,6 +148,7 @@ struct WorkParams {
   unsigned long long idle_budget_ticks;  // stage-queued kernel: a wave that finds no work for this long (100 MHz wall clock) bails out
   int debug_force_bail;  // test hook (PINE_GPU_FLAG_DEBUG_FORCE_BAIL): the first wave bails out at once
   int trav_min_lanes, trav_min_trips;  // traversal stages (pine_queue_kernel.h): retire / refill when fewer lanes than this still travel, at the earliest after this many trips
+  int pick_spins;   // stage-queued kernel: idle polls after which a wave takes a queue's entries although they are fewer than 64
   int pool_items;   // stage-queued kernel: work items a workgroup claims from the global counter at a time
   int fork_sealed;  // Subsurface variants: a path that can make no further RNG draw hands its pixel's next sample to another context
   unsigned long long* progress;  // host-mapped word (or null): work items claimed so far, stored now and then (get_progress)

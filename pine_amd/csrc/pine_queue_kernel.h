@@ -425,7 +425,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           h_best = hq[q];
         }
       }
-      if (cnt_best >= 64u || (cnt_best > 0u && (busy == 0u || spins >= 8u))) {
+      if (cnt_best >= 64u || (cnt_best > 0u && (busy == 0u || spins >= unsigned(W.pick_spins)))) {
         // count ourselves busy BEFORE taking items out of the queue, so that "all queues empty and
         // nobody busy" really means no work can appear any more (idle pollers never touch the
         // counter: two of them must not keep each other alive)

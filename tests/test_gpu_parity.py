@@ -527,11 +527,12 @@ def test_plan_limits_are_errors_not_wraparound():
         pa.Plan(scenes.cbox((4096, 4096)), pa.SobolSampler(512), 2)
 
 
-@pytest.mark.parametrize("min_lanes,min_trips", [(24, 8), (64, 1)])
-def test_parked_and_regrouped_traversals_change_nothing(oracle, monkeypatch, path_kernel, min_lanes, min_trips):
-    """pine_trav.h: a traversal that is stopped, parked in the context's global record and resumed in another
-    wave (stages XS / XC) continues exactly where it stopped.  Off by default; (64, 1) parks every lane after
-    every trip -- each node visit and each leaf primitive of each ray in a different wave."""
+@pytest.mark.parametrize("min_lanes,min_trips", [(0, 8), (24, 8), (64, 1)])
+def test_traversal_stage_refill_settings_change_nothing(oracle, monkeypatch, path_kernel, min_lanes, min_trips):
+    """pine_queue_kernel.h, stages XS / XC: a wave keeps its lanes' traversals in registers, retires the finished ones
+    and hands the free lanes new rays from the queue whenever fewer than `min_lanes` still travel (checked every
+    `min_trips` trips).  The setting decides which rays share a wave and when, never what a ray computes: 0 never
+    refills (a wave runs its rays to the end), (64, 1) retires and refills after every single trip."""
     import pine_amd as pa
     from pine_amd import scenes
     if path_kernel == "mega":
@@ -542,7 +543,7 @@ def test_parked_and_regrouped_traversals_change_nothing(oracle, monkeypatch, pat
              (scenes.sss((48, 48), 2), 16, 8),
              (scenes.sss((40, 40), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True), 16, 6),
              (scenes.lights_zoo((40, 40)), 8, 5)]
-    # lights_zoo is a cbox-class scene (whole scene in LDS: no resumable traversal) unless LDS staging is refused
+    # lights_zoo is a cbox-class scene (whole scene in LDS: traversal inside the stages) unless LDS staging is refused
     for i, (sc, spp, depth) in enumerate(cases):
         if i == 3:
             monkeypatch.setenv("PINE_GPU_NO_LDS_SCENE", "1")
@@ -550,7 +551,33 @@ def test_parked_and_regrouped_traversals_change_nothing(oracle, monkeypatch, pat
         f, st = _render(sc, spp, depth)
         assert st.block_threads == 1024
         ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
-        assert_bit_equal(f, ref, f"parked traversals, case {i}")
+        assert_bit_equal(f, ref, f"traversal stages, case {i}")
+
+
+@pytest.mark.parametrize("env", [{}, {"PINE_GPU_NO_FORK": "1"}, {"PINE_GPU_POOL_ITEMS": "16"}, {"PINE_GPU_POOL_ITEMS": "4096"}])
+def test_sample_tokens_change_nothing(oracle, monkeypatch, path_kernel, env):
+    """Subsurface scenes: a pixel's samples are sequentially dependent through the pixel's RNG (the BSSRDF channel pick,
+    bxdf.cpp:335), but only until a path's first non-delta bounce -- after it the path draws no RNG value any more, so it
+    releases a token (pixel, next sample index, RNG state) and ANOTHER context starts the pixel's next sample while this
+    path is still being traced.  Same films with the mechanism off, with it on, and whatever the size of a workgroup's
+    work-item claims; a film larger than one round of contexts and 64 samples per pixel, so that tokens, waiting
+    contexts and wake-ups all occur."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    if path_kernel == "mega":
+        pytest.skip("the stage-queued kernel's machinery")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    mixed = scenes.sss((40, 40), 2, emissive_mesh=True)  # the all-features variant (a second mesh that is a light)
+    mixed.add("gold", pa.Metal([0.9, 0.7, 0.3], 0.2))
+    mixed.add(pa.Sphere([0.55, 0.3, 0.5], 0.25), "gold")
+    cases = [(scenes.sss((72, 56), 2), 64, 8), (scenes.sss((24, 24), 1), 256, 6), (mixed, 32, 6)]
+    for i, (sc, spp, depth) in enumerate(cases):
+        w, h = sc.camera.film().size
+        f, st = _render(sc, spp, depth)
+        assert st.block_threads == 1024 and st.samples_per_item == st.spp_effective
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
+        assert_bit_equal(f, ref, f"sample tokens {env}, case {i}")
 
 
 def test_one_process_several_devices_entry_point(oracle):
