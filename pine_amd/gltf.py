@@ -87,6 +87,8 @@ def _read(path):
 def load(path, scene=None, transform=None):
     """Import `path` into `scene` (a new Scene by default); returns the scene."""
     doc, glb_blob = _read(path)
+    if not isinstance(doc, dict) or "version" not in (doc.get("asset") or {}):  # (tinygltf's REQUIRE_VERSION, its default)
+        raise PineError("Unable to create scene from GLTF file (no asset.version)")
     base = os.path.dirname(os.path.abspath(path))
     buffers = []
     for i, b in enumerate(doc.get("buffers", [])):
@@ -177,7 +179,7 @@ def load(path, scene=None, transform=None):
         for child in node.get("children", []):
             process(child, xf)
 
-    root = transform if transform is not None else _M4()
+    root = _M4(list(transform.s)) if transform is not None else _M4()  # (a pine_amd.mat4)
     for sc in doc.get("scenes", []):
         for ni in sc.get("nodes", []):
             process(ni, root)

@@ -273,6 +273,10 @@ inline ImportedCamera import_scene(pine_gpu_scene* scene, const std::string& pat
   } else {
     doc = JsonParser(reinterpret_cast<const char*>(file.data()), file.size()).parse();
   }
+  {  // (tinygltf's REQUIRE_VERSION, its default)
+    const Json* asset = doc.find("asset");
+    if (!asset || !asset->find("version")) throw Error("Unable to create scene from GLTF file (no asset.version)");
+  }
   const std::string base = path.find_last_of('/') == std::string::npos ? std::string(".") : path.substr(0, path.find_last_of('/'));
   std::vector<std::vector<uint8_t>> buffers;
   if (auto* bs = doc.find("buffers"))
@@ -320,7 +324,6 @@ inline ImportedCamera import_scene(pine_gpu_scene* scene, const std::string& pat
     return out;
   };
 
-  int material_counter = 0;
   auto material_of = [&](const Json& prim) {
     float basecolor[3] = {1, 1, 1}, roughness = 1.0f, metallic = 0.0f, transmission = 0.0f, ior = 1.45f;
     float emission_color[3] = {1, 1, 1}, emission_strength = 0.0f;
@@ -348,7 +351,7 @@ inline ImportedCamera import_scene(pine_gpu_scene* scene, const std::string& pat
         for (int k = 0; k < 3; k++) emission_color[k] = float(e->at(size_t(k)).number(0));
     }
     const float emission[3] = {emission_color[0] * emission_strength, emission_color[1] * emission_strength, emission_color[2] * emission_strength};
-    const std::string name = "@gltf" + std::to_string(material_counter++);
+    const std::string name;  // (anonymous: the library numbers it, as for scene.add(shape, material))
     if (emission[0] == 0.0f && emission[1] == 0.0f && emission[2] == 0.0f)
       return check(pine_gpu_scene_add_material_uber(scene, name.c_str(), basecolor, roughness, metallic, transmission, ior), "Uber");
     return check(pine_gpu_scene_add_material_emissive(scene, name.c_str(), emission), "Emissive");

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/pine_gpu.h"
+#include "gltf_import.hpp"
 
 namespace pine {
 
@@ -246,5 +247,19 @@ class PathIntegrator {
 };
 
 inline float get_progress() { return pine_gpu_progress(); }
+
+// load(scene, "file.glb" [, mat4]) (fileio.cpp:584-589): glTF import -- every mesh primitive with its material, and the
+// camera when a node carries one (gltf_import.hpp)
+inline void load(Scene& scene, const std::string& filename, const mat4& m = mat4()) {
+  pine_gltf::ImportedCamera cam;
+  try {
+    cam = pine_gltf::import_scene(scene.handle(), filename, m.m);
+  } catch (const pine_gltf::Error& e) {
+    throw Error(std::string("load: ") + e.what());
+  }
+  if (cam.present)
+    scene.set(ThinLenCamera(Film(vec2i{cam.film_w, cam.film_h}), vec3(cam.from[0], cam.from[1], cam.from[2]),
+                            vec3(cam.to[0], cam.to[1], cam.to[2]), cam.fov));
+}
 
 }  // namespace pine

@@ -35,6 +35,7 @@
 
 #include "../../include/pine_gpu.h"
 #include "../../include/pine_prl.h"
+#include "gltf_import.hpp"
 #include "png_writer.hpp"
 
 namespace prl {
@@ -1765,6 +1766,33 @@ Interp::Interp() {
     gpu_check(pine_gpu_scene_set_camera_thinlens(s->h, c->film->w, c->film->h, c->film->tone, c->from, c->to, c->fov, c->len_radius, c->focus), "scene.set");
     return Value();
   });
+  // load(scene, "file.glb" [, mat4]) (fileio.cpp:584-589): glTF import -- meshes, materials and, when a node carries
+  // one, the camera (gltf_import.hpp)
+  auto load = [](std::vector<Cell>& a) {
+    auto s = obj<SceneObj>(a[0]);
+    pine_gltf::ImportedCamera cam;
+    try {
+      cam = pine_gltf::import_scene(s->h, a[1]->s, a.size() > 2 ? a[2]->f : nullptr);
+    } catch (const pine_gltf::Error& e) {
+      fail(std::string("load: ") + e.what());
+    }
+    if (cam.present) {
+      auto f = std::make_shared<FilmObj>();
+      f->w = cam.film_w;
+      f->h = cam.film_h;
+      f->tone = 0;
+      auto c = std::make_shared<CameraObj>();
+      c->film = f;
+      memcpy(c->from, cam.from, 12);
+      memcpy(c->to, cam.to, 12);
+      c->fov = cam.fov;
+      s->camera = cell(retype(mk_obj("ThinLenCamera", c), "Camera"));
+      gpu_check(pine_gpu_scene_set_camera_thinlens(s->h, f->w, f->h, f->tone, c->from, c->to, c->fov, c->len_radius, c->focus), "load: camera");
+    }
+    return Value();
+  };
+  r.def("load", {"Scene&", "str_view"}, "void", [load](Interp&, std::vector<Cell>& a) { return load(a); });
+  r.def("load", {"Scene&", "str_view", "mat4"}, "void", [load](Interp&, std::vector<Cell>& a) { return load(a); });
   r.def("@ma.Scene.camera", {"Scene"}, "Camera", [](Interp&, std::vector<Cell>& a) {
     auto s = obj<SceneObj>(a[0]);
     if (!s->camera) fail("scene has no camera");

@@ -75,3 +75,57 @@ def test_imported_scene_on_the_gpu_equals_the_reference(kernel, monkeypatch):
         plan.check()
         assert hashlib.md5(film.cpu().numpy().tobytes()).hexdigest() == want["md5"], key
         plan.close()
+
+
+def _prl_load(extra=""):
+    from pine_amd import prl
+    out = prl.interpret(f'scene := Scene(); load(scene, "{GLB}"{extra}); integrator := PathIntegrator(BlueSampler(16), 6); '
+                        'integrator.render(scene);', dry_run=True)
+    return prl.scene_of_dry_run(out)
+
+
+def test_prl_load_builtin_builds_the_same_scene():
+    """`load(scene, "file.glb" [, mat4])` of the PRL front-end (fileio.cpp:584-589) goes through the C++ importer
+    (pine_amd/host/gltf_import.hpp); pine_amd/gltf.py is pinned against the reference above, and the two must build the
+    same scene, record for record -- camera included, with and without a global transform."""
+    import pine_amd as pa
+    from pine_amd import gltf, prl
+    ps, spp, depth = _prl_load()
+    assert (spp, depth) == (16, 6) and ps == _scene().describe()
+    ps2, _, _ = _prl_load(", translate(0.5, 0.0, -0.25) * rotate_y(0.3)")
+    assert ps2 == gltf.load(GLB, transform=pa.translate([0.5, 0.0, -0.25]) * pa.rotate_y(0.3)).describe() and ps2 != ps
+    with pytest.raises(Exception, match="Unable to open"):
+        prl.interpret('scene := Scene(); load(scene, "/no/such/file.glb");', dry_run=True)
+    with pytest.raises(Exception):
+        prl.interpret(f'scene := Scene(); load(scene, "{os.path.join(GOLDEN, "stats_640.json")}");', dry_run=True)  # not a glTF document
+
+
+@pytest.mark.gpu
+def test_prl_load_renders_the_reference_film():
+    from pine_amd import prl
+    want = json.load(open(os.path.join(GOLDEN, "gltf_import.json")))["s4_d5"]
+    prl.interpret(f'scene := Scene(); load(scene, "{GLB}"); integrator := PathIntegrator(BlueSampler({want["spp"]}), {want["depth"]}); '
+                  'integrator.render(scene);')
+    assert hashlib.md5(prl.last_film().tobytes()).hexdigest() == want["md5"]
+
+
+def test_cpp_facade_load_builds_the_same_scene(tmp_path):
+    """pine::load(scene, file [, mat4]) of the C++ facade (pine_amd/host/pine.hpp) is the same importer."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "%s/pine_amd/host/pine.hpp"\n#include <cstdio>\n#include <vector>\n'
+                   'int main(int, char** argv) {\n  pine::Scene s;\n  pine::load(s, argv[1]);\n'
+                   '  std::vector<char> buf(1 << 20);\n  int n = pine_gpu_scene_describe(s.handle(), buf.data(), int(buf.size()));\n'
+                   '  if (n < 0) return 2;\n  std::fwrite(buf.data(), 1, size_t(n), stdout);\n'
+                   '  std::fprintf(stderr, "%%d %%d %%a", s.camera.film().size().x, s.camera.film().size().y, double(s.camera.fov));\n'
+                   '  try { pine::load(s, "/no/such.glb"); } catch (const pine::Error&) { return 0; }\n  return 3;\n}\n' % root)
+    exe = tmp_path / "t"
+    lib = os.path.join(root, "pine_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O0", str(src), "-o", str(exe), "-L" + lib, "-lpine_gpu", "-Wl,-rpath," + lib], check=True)
+    r = subprocess.run([str(exe), GLB], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sc = _scene()
+    assert r.stdout.rstrip("\x00") == sc.describe()
+    w, h, fov = r.stderr.split()[-3:]
+    assert [int(w), int(h)] == list(sc.camera.film().size) and float.fromhex(fov) == float(np.float32(sc.camera.fov))
