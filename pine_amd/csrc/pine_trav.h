@@ -76,12 +76,14 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
     if (travelling == 0) break;
     if (trip >= min_trips && __popcll(travelling) < keep_lanes) break;
     if (ts.done) continue;
+    REGION(ANY ? 5 : 1);  // (per-arm lane counts of -DPINE_PROFILE_REGIONS builds: a trip / its triangle, top-level primitive and node arms)
     if (ts.pan > 0) {
       // ---- one pending leaf primitive ----
       const int i = ts.pa++;
       ts.pan--;
       if (ts.mesh_base >= 0) {
         if constexpr (F & F_MESH) {
+          REGION(ANY ? 8 : 4);
           const float4* rec = S.tri_leaf + size_t(i) * 3;
           const float4 a = rec[0], b = rec[1], c = rec[2];
           const float v[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
@@ -96,6 +98,7 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
           }
         }
       } else {
+        REGION(ANY ? 7 : 3);
         const DShape* sh = &S.leaf[i];
         const int word = sh->kind;  // (the packed word rides in the copy's kind field)
         const int kind = word >> kPrimKindShift;
@@ -129,6 +132,7 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
       }
     } else if (ts.next >= 0) {
       // ---- one node: both child boxes against the tmax of this moment (bvh.cpp:405-446) ----
+      REGION(ANY ? 6 : 2);
       const DNode nd = fetch_node<F>(S, ts.next);
       int l = -1, r = -1;
       float t0 = ray.tmax, t1 = ray.tmax;
