@@ -18,6 +18,11 @@ configs = [
     ("xshapes", scenes.xshapes_zoo((48, 48)), 16, 5, {}),
     ("lights", scenes.lights_zoo((64, 64)), 32, 6, {}),
     ("sobol 64", scenes.cbox((96, 96), "readme"), pine_amd.SobolSampler(64), 6, {}),
+    # traversal stages with refill, BSSRDF walk stage, sample tokens (waiting / woken contexts at the end of every launch)
+    ("sss 96x96", scenes.sss((96, 96), 2), 64, 8, {}),
+    ("sss 24x24 x256", scenes.sss((24, 24), 1), 256, 6, {}),
+    ("sss + emissive mesh", scenes.sss((40, 40), 2, emissive_mesh=True), 32, 6, {}),
+    ("classic20", scenes.classic_cones((180, 90), 20), 16, 6, {}),
 ]
 plans = []
 for name, sc, spp, d, kw in configs:
