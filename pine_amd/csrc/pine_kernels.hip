@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -481,6 +482,7 @@ struct pine_gpu_plan {
   char* d_blob = nullptr;  // nodes | shapes | materials | bvhs | prims | lights
   float* d_tri = nullptr;
   float* d_tri_leaf = nullptr;
+  uint4* d_tri_packets = nullptr;
   float* d_tri_attrs = nullptr;
   uint8_t* d_tables = nullptr;
   int variant = -1;
@@ -564,6 +566,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_blob);
   (void)hipFree(p->d_tri);
   (void)hipFree(p->d_tri_leaf);
+  (void)hipFree(p->d_tri_packets);
   (void)hipFree(p->d_tri_attrs);
   (void)hipFree(p->d_tables);
   (void)hipFree(p->d_ctxg);
@@ -576,6 +579,50 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
     for (auto& e : slot)
       if (e) (void)hipEventDestroy(e);
   delete p;
+}
+
+// The mesh triangles as LDS-sized packets (DeviceScene::tri_packets): per leaf-ordered triangle an 8-byte entry -- three
+// 16-bit numbers into the table of the scene's DISTINCT vertices (by bit pattern) and the 16-bit triangle index -- then the
+// vertices as float4.  Returns false when a number does not fit 16 bits (the traversal then reads tri_leaf from memory).
+static bool build_tri_packets(const FlatAccel& A, std::vector<uint32_t>& out, int& entries, int& verts) {
+  entries = A.top_prim_begin;
+  verts = 0;
+  out.clear();
+  if (entries <= 0) return false;
+  struct Key {
+    uint32_t a, b, c;
+    bool operator<(const Key& o) const { return a != o.a ? a < o.a : b != o.b ? b < o.b : c < o.c; }
+  };
+  std::map<Key, uint32_t> index;
+  std::vector<Key> table;
+  std::vector<uint32_t> ent(size_t((entries + 1) & ~1) * 2, 0u);
+  for (int i = 0; i < entries; i++) {
+    uint32_t w[10];
+    memcpy(w, &A.tri_leaf[size_t(i) * 12], sizeof w);
+    uint32_t id[3];
+    for (int k = 0; k < 3; k++) {
+      const Key key{w[3 * k], w[3 * k + 1], w[3 * k + 2]};
+      auto it = index.find(key);
+      if (it == index.end()) {
+        if (table.size() >= 65536) return false;
+        it = index.emplace(key, uint32_t(table.size())).first;
+        table.push_back(key);
+      }
+      id[k] = it->second;
+    }
+    if (w[9] >= 65536u) return false;  // (the triangle index, as tri_leaf stores it)
+    ent[size_t(i) * 2] = id[0] | (id[1] << 16);
+    ent[size_t(i) * 2 + 1] = id[2] | (w[9] << 16);
+  }
+  verts = int(table.size());
+  out = ent;
+  for (const Key& k : table) {
+    out.push_back(k.a);
+    out.push_back(k.b);
+    out.push_back(k.c);
+    out.push_back(0u);
+  }
+  return true;
 }
 
 static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_render_params* prm) {
@@ -681,6 +728,14 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   HIP_OK(hipMemcpy(p->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (upload(p->d_tri, A.tri_verts)) return -1;
   if (upload(p->d_tri_leaf, A.tri_leaf)) return -1;
+  std::vector<uint32_t> tri_packets;
+  int tri_packet_entries = 0, tri_packet_verts = 0;
+  const bool have_tri_packets = build_tri_packets(A, tri_packets, tri_packet_entries, tri_packet_verts);
+  if (have_tri_packets) {
+    HIP_OK(hipMalloc((void**)&p->d_tri_packets, tri_packets.size() * 4));
+    HIP_OK(hipMemcpy(p->d_tri_packets, tri_packets.data(), tri_packets.size() * 4, hipMemcpyHostToDevice));
+  }
+  const size_t tri_packet_bytes = tri_packets.size() * 4;
   if (upload(p->d_tri_attrs, A.tri_attrs)) return -1;
   // tables: sobol + the selected spp variant
   int k = 0;
@@ -710,6 +765,10 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.tri_leaf = reinterpret_cast<const float4*>(p->d_tri_leaf);
   S.tri_attrs = p->d_tri_attrs;
   S.lds_nodes = 0;
+  S.tri_packets = p->d_tri_packets;
+  S.tri_packet_entries = tri_packet_entries;
+  S.tri_packet_verts = tri_packet_verts;
+  S.lds_tris = 0;
   S.num_lights = int(light_list.size());
   S.env_light = H.has_env ? int(light_list.size()) - 1 : -1;
   S.num_shapes = int(shapes.size());
@@ -798,6 +857,18 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (kVariants[p->variant].features & F_LDS_SCENE) p->lds_bytes += size_t(S.blob_bytes);
   // The stage-queued kernel is the default whenever a variant covers the scene and its LDS fits;
   // PINE_GPU_KERNEL=mega forces the lane-owns-a-path kernel, which covers every scene.
+  // LDS left after a variant's fixed parts goes to the BVH node cache first, then -- when ALL nodes are in and there is
+  // still room -- to the triangle packets.  Measured on the icosphere scene: packets in place of the 288
+  // deepest nodes change nothing (191.7 vs 190.1 ms), so nodes are never evicted for them.
+  // PINE_GPU_LDS_TRIS=0 / 1: never / whenever the packets fit, before the nodes (measurement aid).
+  auto lds_tris_fit = [&](unsigned F, size_t lds) -> bool {
+    if (!(F & F_LDS_TOP) || !(F & F_MESH) || !have_tri_packets || lds >= 160 * 1024) return false;
+    const size_t room = 160 * 1024 - lds;
+    const char* e = getenv("PINE_GPU_LDS_TRIS");
+    if (e && atoi(e) == 0) return false;
+    if (e && atoi(e) == 1) return tri_packet_bytes <= room;
+    return tri_packet_bytes + A.nodes.size() * sizeof(DNode) <= room;
+  };
   p->queue_variant = -1;
   {
     const char* ksel = getenv("PINE_GPU_KERNEL");
@@ -819,8 +890,10 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
         p->queue_variant = v;
         p->lds_bytes = lds;
         S.lds_nodes = 0;
+        S.lds_tris = lds_tris_fit(F, lds) ? 1 : 0;
+        if (S.lds_tris) p->lds_bytes += tri_packet_bytes;
         if (F & F_LDS_TOP) {
-          S.lds_nodes = int(std::min<size_t>(A.nodes.size(), (160 * 1024 - lds) / sizeof(DNode)));
+          S.lds_nodes = int(std::min<size_t>(A.nodes.size(), (160 * 1024 - p->lds_bytes) / sizeof(DNode)));
           if (no_top) S.lds_nodes = 0;
           p->lds_bytes += size_t(S.lds_nodes) * sizeof(DNode);
         }
@@ -847,8 +920,10 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
       p->fast = &fv[v];
       p->lds_bytes = lds;
       S.lds_nodes = 0;
+      S.lds_tris = lds_tris_fit(F, lds) ? 1 : 0;
+      if (S.lds_tris) p->lds_bytes += tri_packet_bytes;
       if (F & F_LDS_TOP) {
-        S.lds_nodes = int(std::min<size_t>(A.nodes.size(), (160 * 1024 - lds) / sizeof(DNode)));
+        S.lds_nodes = int(std::min<size_t>(A.nodes.size(), (160 * 1024 - p->lds_bytes) / sizeof(DNode)));
         p->lds_bytes += size_t(S.lds_nodes) * sizeof(DNode);
       }
     }

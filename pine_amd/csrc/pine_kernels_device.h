@@ -85,6 +85,12 @@ struct DeviceScene {
   const float4* tri_leaf;  // mesh triangles in leaf order, 3 float4 per entry of `prims` (FlatAccel::tri_leaf)
   const float* tri_attrs;  // per-vertex normals / texcoords per triangle, 16 floats each (FlatAccel::tri_attrs), or null
   int lds_nodes;           // F_LDS_TOP variants: nodes[0 .. lds_nodes) are copied to LDS by every workgroup
+  // F_LDS_TOP + F_MESH variants: the mesh triangles as LDS-sized packets (plan_build decides whether they are staged):
+  // one 8-byte entry per leaf-ordered triangle (three 16-bit vertex numbers, the 16-bit triangle index) and the
+  // scene's DISTINCT vertices as float4 -- the same floats as tri_leaf's 48-byte records, a third of the bytes
+  const uint4* tri_packets;   // entries (tri_packet_entries x 8 bytes, padded to 16), then vertices (x 16 bytes)
+  int tri_packet_entries, tri_packet_verts;
+  int lds_tris;               // 1: every workgroup copies the packets to LDS and the traversal reads them there
 };
 
 // What the traversal and shading code reads.  In the F_LDS_SCENE specialisation every pointer is
@@ -110,6 +116,8 @@ struct SceneView {
   const float* tri_attrs;
   const DNode* lds_nodes;  // F_LDS_TOP: the workgroup's LDS copy of nodes[0 .. lds_node_count)
   int lds_node_count;
+  const uint2* lds_tri_entries;   // DeviceScene::tri_packets in LDS (null: triangles are read from tri_leaf)
+  const float4* lds_tri_verts;
 };
 
 // One BVH node into registers.  F_LDS_TOP: from the workgroup's LDS copy when the index is below the cached
@@ -134,6 +142,30 @@ __device__ __forceinline__ DNode fetch_node(const SceneView& S, int index) {
   const u32x4* g = reinterpret_cast<const u32x4*>(S.nodes + index);
   b.q[0] = g[0], b.q[1] = g[1], b.q[2] = g[2], b.q[3] = g[3];
   return b.n;
+}
+
+// One leaf-ordered triangle: from the workgroup's LDS packets when they are staged (an 8-byte entry, then three 16-byte
+// vertices: ds_read_b64 + 3 ds_read_b128), else its 48-byte record in global memory.  The floats are the same.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
+template <unsigned F>
+__device__ __forceinline__ void fetch_triangle(const SceneView& S, int i, float (&v)[9], int& tri) {
+  if constexpr ((F & F_LDS_TOP) != 0 && (F & F_MESH) != 0) {
+    if (S.lds_tri_entries != nullptr) {
+      const u32x2 e = *((lds_u32x2*)(S.lds_tri_entries) + i);
+      lds_u32x4* vb = (lds_u32x4*)(S.lds_tri_verts);
+      const u32x4 a = vb[e.x & 0xffffu], b = vb[e.x >> 16], c = vb[e.y & 0xffffu];
+      v[0] = __uint_as_float(a.x), v[1] = __uint_as_float(a.y), v[2] = __uint_as_float(a.z);
+      v[3] = __uint_as_float(b.x), v[4] = __uint_as_float(b.y), v[5] = __uint_as_float(b.z);
+      v[6] = __uint_as_float(c.x), v[7] = __uint_as_float(c.y), v[8] = __uint_as_float(c.z);
+      tri = int(e.y >> 16);
+      return;
+    }
+  }
+  const float4* rec = S.tri_leaf + size_t(i) * 3;
+  const float4 a = rec[0], b = rec[1], c = rec[2];
+  v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w, v[8] = c.x;
+  tri = __float_as_int(c.y);
 }
 
 struct WorkParams {
@@ -171,15 +203,15 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
   bool hit = false;
   auto leaf = [&](int start, int count) -> bool {
     for (int i = start; i < start + count; i++) {
-      // leaf-ordered 48-byte record: v0 v1 v2 | triangle index (FlatAccel::tri_leaf)
-      const float4* rec = S.tri_leaf + size_t(i) * 3;
-      const float4 a = rec[0], b = rec[1], c = rec[2];
-      const float v[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
+      // leaf-ordered record: v0 v1 v2 | triangle index (FlatAccel::tri_leaf, or its LDS packets)
+      float v[9];
+      int tri;
+      fetch_triangle<F>(S, i, v, tri);
       if (ANY) {
         if (tri_hit(v, ray)) return true;
       } else if (tri_intersect(v, ray)) {
         hit = true;
-        prim_out = __float_as_int(c.y);
+        prim_out = tri;
       }
     }
     return false;
@@ -485,6 +517,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   V.tri_attrs = S.tri_attrs;
   V.lds_nodes = nullptr;
   V.lds_node_count = 0;
+  V.lds_tri_entries = nullptr;
+  V.lds_tri_verts = nullptr;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
   if constexpr (F & F_LDS_SCENE) {

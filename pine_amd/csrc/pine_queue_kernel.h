@@ -131,6 +131,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   V.tri_attrs = S.tri_attrs;
   V.lds_nodes = nullptr;
   V.lds_node_count = 0;
+  V.lds_tri_entries = nullptr;
+  V.lds_tri_verts = nullptr;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
   char* lds_after_stack = nullptr;
@@ -141,6 +143,17 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if constexpr (F & F_LDS_REST) lds_after_stack += S.blob_bytes - S.off_shapes;  // (the records staged below)
     // the first S.lds_nodes nodes (breadth-first numbering: the top levels of the top-level BVH and of the mesh
     // BVHs) live in LDS behind the traversal stack
+    if constexpr (F & F_MESH) {
+      // the mesh triangles as packets (entries, then distinct vertices), when plan_build found room for them
+      if (S.lds_tris) {
+        const int entry_quads = (S.tri_packet_entries + 1) >> 1, n16 = entry_quads + S.tri_packet_verts;
+        uint4* tdst = reinterpret_cast<uint4*>(lds_after_stack);
+        for (int i = tid; i < n16; i += kQBlock) tdst[i] = S.tri_packets[i];
+        V.lds_tri_entries = reinterpret_cast<const uint2*>(tdst);
+        V.lds_tri_verts = reinterpret_cast<const float4*>(tdst + entry_quads);
+        lds_after_stack += size_t(n16) * 16;
+      }
+    }
     uint4* dst = reinterpret_cast<uint4*>(lds_after_stack);
     const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
     for (int i = tid; i < S.lds_nodes * 4; i += kQBlock) dst[i] = src[i];

@@ -84,9 +84,9 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
       if (ts.mesh_base >= 0) {
         if constexpr (F & F_MESH) {
           REGION(ANY ? 8 : 4);
-          const float4* rec = S.tri_leaf + size_t(i) * 3;
-          const float4 a = rec[0], b = rec[1], c = rec[2];
-          const float v[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
+          float v[9];
+          int tri;
+          fetch_triangle<F>(S, i, v, tri);
           if (ANY) {
             if (tri_hit(v, ray)) {
               ts.hit_geom = 0;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
             }
           } else if (tri_intersect(v, ray)) {
             ts.hit_geom = ts.mesh_word;
-            ts.hit_prim = __float_as_int(c.y);
+            ts.hit_prim = tri;
           }
         }
       } else {

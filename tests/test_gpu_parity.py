@@ -580,6 +580,31 @@ def test_sample_tokens_change_nothing(oracle, monkeypatch, path_kernel, env):
         assert_bit_equal(f, ref, f"sample tokens {env}, case {i}")
 
 
+@pytest.mark.parametrize("lds_tris", ["0", "1"])
+def test_triangle_packets_in_lds_change_nothing(oracle, monkeypatch, path_kernel, lds_tris):
+    """Mesh triangles as LDS packets (8-byte entries of 16-bit vertex numbers + the scene's distinct vertices as float4,
+    DeviceScene::tri_packets): the traversal stages and the BSSRDF walk read the same floats from LDS instead of the 48-byte
+    leaf records in memory.  Forced off and forced on (whenever they fit), against the oracle; a mesh that is a light, a
+    mesh with per-vertex normals (the imported glTF scene: shading reads tri_verts / tri_attrs as before)."""
+    import pine_amd as pa
+    from pine_amd import scenes, gltf
+    if path_kernel == "mega":
+        pytest.skip("the stage-queued kernel's machinery")
+    monkeypatch.setenv("PINE_GPU_LDS_TRIS", lds_tris)
+    cases = [(scenes.sss((48, 48), 3), 16, 8),
+             (scenes.sss((40, 40), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True), 16, 6),
+             (gltf.load(os.path.join(GOLDEN, "import_test.glb")), 4, 5)]
+    for i, (sc, spp, depth) in enumerate(cases):
+        w, h = sc.camera.film().size
+        if i == 2:
+            w, h = 96, 96
+            sc.set(pa.ThinLenCamera(pa.Film([w, h]), sc.camera.frm, sc.camera.to, sc.camera.fov))
+        f, st = _render(sc, spp, depth)
+        assert st.block_threads == 1024
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
+        assert_bit_equal(f, ref, f"triangle packets {lds_tris}, case {i}")
+
+
 def test_one_process_several_devices_entry_point(oracle):
     """pine_gpu_path_render_devices / _multi (SURVEY.md 8(b)'s device_mask form): shards on a list of devices, slabs
     gathered with peer copies, one film -- bit-identical to the one-device render.  On the 1-GPU box the list names

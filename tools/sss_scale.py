@@ -7,7 +7,7 @@ import torch, pine_amd
 from pine_amd import scenes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 for side in [int(a) for a in sys.argv[2:]] or [256, 362, 512, 640, 724, 1024]:
-    sc = scenes.sss((side, side), 3)
+    sc = scenes.sss((side, side), int(os.environ.get("SUBDIV", "3")))
     plan = pine_amd.Plan(sc, spp, 8, timing=True)
     film = torch.zeros((side, side, 4), device='cuda')
     for _ in range(2):
