@@ -64,10 +64,12 @@ __device__ __forceinline__ void trav_begin(const SceneView& S, TravState& ts) {
 // `keep_lanes` of the wave are still travelling after at least `min_trips` trips (the caller then retires the finished
 // lanes and gives them new rays).  ANY: BVH::hit (first hit ends the ray, hit_geom = 0); else BVH::intersect.
 //
-// A trip is ONE heavy step per lane -- a leaf primitive test, or a node visit -- followed by the cheap bookkeeping that
-// decides the lane's next step (second leaf range, pop, return from a mesh, finished).  The bookkeeping used to be trips
-// of its own: a lane that only had to pop waited a whole trip of the other lanes' node and primitive tests for it.  The
-// order of the heavy steps per ray is unchanged: primitives pending > second pending range > node > pop > mesh return.
+// A trip runs the node arm for the lanes at a node, THEN the primitive arm for the lanes with a pending leaf primitive --
+// among them the lanes whose node visit has just found a leaf child, which so test its first primitive in the same trip
+// (both arms are executed by the wave in nearly every trip anyway) -- and then the cheap bookkeeping that decides the
+// lane's next step (second leaf range, pop, return from a mesh, finished).  The bookkeeping used to be trips of its own:
+// a lane that only had to pop waited a whole trip of the other lanes' node and primitive tests for it.  The order of
+// the steps per ray is unchanged: primitives pending > second pending range > node > pop > mesh return.
 template <bool ANY, unsigned F, int STRIDE, class StackT>
 __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const DRayOct& oct, TravState& ts, StackT* stack, int keep_lanes,
                                            int min_trips) {
@@ -77,6 +79,35 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
     if (trip >= min_trips && __popcll(travelling) < keep_lanes) break;
     if (ts.done) continue;
     REGION(ANY ? 5 : 1);  // (per-arm lane counts of -DPINE_PROFILE_REGIONS builds: a trip / its triangle, top-level primitive and node arms)
+    if (ts.pan == 0 && ts.next >= 0) {
+      // ---- one node: both child boxes against the tmax of this moment (bvh.cpp:405-446) ----
+      REGION(ANY ? 6 : 2);
+      const DNode nd = fetch_node<F>(S, ts.next);
+      int l = -1, r = -1;
+      float t0 = ray.tmax, t1 = ray.tmax;
+      if (box_hit_oct(nd.lo0, nd.hi0, oct, ray.tmin, t0)) {
+        if (nd.count[0] == 0) l = nd.child[0];
+        else ts.pa = nd.child[0], ts.pan = nd.count[0];
+      }
+      if (box_hit_oct(nd.lo1, nd.hi1, oct, ray.tmin, t1)) {
+        if (nd.count[1] == 0) r = nd.child[1];
+        else if (ts.pan > 0) ts.pb = nd.child[1], ts.pbn = nd.count[1];
+        else ts.pa = nd.child[1], ts.pan = nd.count[1];
+      }
+      if (l != -1) {
+        if (r != -1) {
+          if (t0 > t1) {
+            stack[ts.sp * STRIDE] = StackT(l);
+            ts.next = r;
+          } else {
+            stack[ts.sp * STRIDE] = StackT(r);
+            ts.next = l;
+          }
+          ts.sp++;
+        } else ts.next = l;
+      } else ts.next = r;  // (-1 when neither child is an inner node to visit)
+    }
+    // (a node whose child is a leaf: its first primitive is tested in this same trip)
     if (ts.pan > 0) {
       // ---- one pending leaf primitive ----
       const int i = ts.pa++;
@@ -130,33 +161,6 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
           ts.hit_geom = word;
         }
       }
-    } else if (ts.next >= 0) {
-      // ---- one node: both child boxes against the tmax of this moment (bvh.cpp:405-446) ----
-      REGION(ANY ? 6 : 2);
-      const DNode nd = fetch_node<F>(S, ts.next);
-      int l = -1, r = -1;
-      float t0 = ray.tmax, t1 = ray.tmax;
-      if (box_hit_oct(nd.lo0, nd.hi0, oct, ray.tmin, t0)) {
-        if (nd.count[0] == 0) l = nd.child[0];
-        else ts.pa = nd.child[0], ts.pan = nd.count[0];
-      }
-      if (box_hit_oct(nd.lo1, nd.hi1, oct, ray.tmin, t1)) {
-        if (nd.count[1] == 0) r = nd.child[1];
-        else if (ts.pan > 0) ts.pb = nd.child[1], ts.pbn = nd.count[1];
-        else ts.pa = nd.child[1], ts.pan = nd.count[1];
-      }
-      if (l != -1) {
-        if (r != -1) {
-          if (t0 > t1) {
-            stack[ts.sp * STRIDE] = StackT(l);
-            ts.next = r;
-          } else {
-            stack[ts.sp * STRIDE] = StackT(r);
-            ts.next = l;
-          }
-          ts.sp++;
-        } else ts.next = l;
-      } else ts.next = r;  // (-1 when neither child is an inner node to visit)
     }
     // ---- what this lane does in the next trip ----
     if (!ts.done && ts.pan == 0) {
