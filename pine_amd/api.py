@@ -416,6 +416,20 @@ class SobolSampler:
         return self.requested
 
 
+class HaltonSampler:
+    """HaltonSampler(spp) (sampler.h:40-81): scrambled radical inverses over the first primes, the pixel's place in the
+    sequence from its coordinates modulo 128; spp as given.  On the device under SobolSampler's restrictions."""
+    kind = 2  # PINE_GPU_SAMPLER_HALTON
+
+    def __init__(self, samples_per_pixel):
+        if samples_per_pixel <= 0:
+            raise PineError("`HaltonSampler` should have positive samples per pixel")
+        self.requested = int(samples_per_pixel)
+
+    def spp(self):
+        return self.requested
+
+
 # ---- Scene (src/pine/core/scene.cpp:64-79) -----------------------------------------------------
 class Scene:
     def __init__(self):
@@ -546,7 +560,7 @@ class Plan:
         if scene.camera is None:
             raise PineError("scene has no camera")
         self.scene = scene
-        kind = 1 if sampler == "sobol" else 0
+        kind = {"sobol": 1, "halton": 2}.get(sampler, 0)
         if hasattr(spp, "requested"):
             kind, spp = getattr(spp, "kind", 0), spp.requested
         self.params = _lib.RenderParams(int(spp), int(max_path_length), int(device), int(shard_rank),

@@ -110,10 +110,15 @@ struct DTables {
   int tile_stride;           // = workgroup size: the slices are [dword][thread]
   int win_lo, win_len;       // dimensions [win_lo, win_lo + win_len) are present in the cache
   // SobolSampler instead (F_SOBOL variants only; sampler.h:83-164): nothing is read from the tables
-  int kind;                  // 0 = BlueSampler, 1 = SobolSampler
+  int kind;                  // 0 = BlueSampler, 1 = SobolSampler, 2 = HaltonSampler
   int sobol_log2_spp;        // psl::log2i(spp) (sampler.h:127-129)
   int sobol_digits;          // nbase4_digits (sampler.cpp:81-84)
+  // HaltonSampler (sampler.h:40-81): the first kHaltonDims primes, their prefix sums, and the digit permutation of each
+  // (HaltonSampler::radicalInversePermutations, derived on the host: pine_host.cpp)
+  const int* halton_primes;  // [kHaltonDims] primes, then [kHaltonDims] prefix sums
+  const uint16_t* halton_perms;
 };
+constexpr int kHaltonDims = 512;  // the packed path state holds 9 bits of sampler dimension (the reference wraps at 1000)
 // value = sobol[dim + (index ^ rank[(dim + pix*8) % N]) * 256] ^ scramble[dim % 8 + pix*8]
 // (bluenoise_*spp.cpp:14-34); LDS = true reads dims < kLdsSamplerDims from the workgroup cache.
 template <bool LDS = false>
@@ -232,8 +237,41 @@ PINE_HD uint64_t sobol_compute_sample_index(const DTables& t, uint64_t sobol_ind
   return si;
 }
 
+// HaltonSampler::start_pixel + start_next_sample (sampler.cpp:64-79, sampler.h:48-51): the index of sample `index` of
+// pixel (px, py) in the Halton sequence -- the pixel's offset modulo 128 x 243 (from its coordinates' reversed base-2 /
+// base-3 digits through the Chinese remainder theorem), plus 31 104 per sample.  baseScales = {128, 243},
+// baseExponents = {7, 5}, multInverse = {multiplicativeInverse(128, 243), multiplicativeInverse(243, 128)} = {131, 59}.
+PINE_HD uint32_t halton_index_of(int px, int py, int index) {
+  const uint32_t pm0 = uint32_t(px) & 127u;          // psl::mod(p, 128), p >= 0
+  const uint32_t pm1 = uint32_t(py) & 127u;
+  uint32_t off0 = 0, off1 = 0;                       // inverse_radical_inverse (lowdiscrepancy.h:42-51)
+  for (uint32_t v = pm0, i = 0; i < 7; i++, v >>= 1) off0 = off0 * 2u + (v & 1u);
+  for (uint32_t v = pm1, i = 0; i < 5; i++, v /= 3u) off1 = off1 * 3u + v % 3u;
+  uint32_t h = off0 * 243u * 59u + off1 * 128u * 131u;  // dimOffset * baseScales[1 - i] * multInverse[1 - i]
+  h %= 31104u;
+  return h + uint32_t(index) * 31104u;
+}
+// scrambled_radical_inverse (lowdiscrepancy.h:26-40); a < 2^27 on the device (4096 samples x 31 104), so the digit
+// extraction runs in 32 bits; the reversed digits need 64
+PINE_HD float halton_sample_dimension(const DTables& t, int dim, uint32_t a) {
+  const int base = t.halton_primes[dim];
+  const uint16_t* perm = t.halton_perms + t.halton_primes[kHaltonDims + dim];
+  const float inv_base = 1.0f / float(base);
+  float inv_base_n = 1.0f;
+  uint64_t reversed = 0;
+  while (a) {
+    const uint32_t next = a / uint32_t(base);
+    const uint32_t digit = a - next * uint32_t(base);
+    reversed = reversed * uint64_t(base) + perm[digit];
+    inv_base_n *= inv_base;
+    a = next;
+  }
+  const float series = float(perm[0]) / (float(base) + 1.0f);
+  return pmin((float(reversed) + series) * inv_base_n, kOneMinusEps);
+}
+
 // Sampler front: MODE bit 0 = the workgroup has the BlueSampler LDS cache, bit 1 = the variant also
-// carries SobolSampler (selected at run time by DTables::kind).
+// carries SobolSampler and HaltonSampler (selected at run time by DTables::kind).
 constexpr int kSmLds = 1, kSmSobol = 2;
 template <int MODE = 0>
 PINE_HD float sampler_get1d(const DTables& t, DSampler& s) {  // sampler.h:183-187 / :143-148
@@ -244,6 +282,7 @@ PINE_HD float sampler_get1d(const DTables& t, DSampler& s) {  // sampler.h:183-1
       const uint64_t u = hash_int(s.dimension);
       return sobol_sample01(si, 0, uint32_t(u));
     }
+    if (t.kind == 2) return halton_sample_dimension(t, s.dimension++, halton_index_of(s.px, s.py, s.index));  // sampler.h:52-56
   }
   if (s.dimension >= 256) s.dimension = 2;
   return blue_sample_dimension<(MODE & kSmLds) != 0>(t, s.px, s.py, s.index, s.dimension++);
@@ -257,6 +296,14 @@ PINE_HD f2 sampler_get2d(const DTables& t, DSampler& s) {  // sampler.h:188-194 
       const uint64_t u = hash_int(s.dimension);
       const float a = sobol_sample01(si, 0, uint32_t(u));
       const float b = sobol_sample01(si, 1, uint32_t(u >> 32));
+      return f2{a, b};
+    }
+    if (t.kind == 2) {  // sampler.h:57-63
+      const uint32_t hi = halton_index_of(s.px, s.py, s.index);
+      const int dim = s.dimension;
+      s.dimension += 2;
+      const float a = halton_sample_dimension(t, dim, hi);
+      const float b = halton_sample_dimension(t, dim + 1, hi);
       return f2{a, b};
     }
   }

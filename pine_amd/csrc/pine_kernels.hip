@@ -483,6 +483,7 @@ struct pine_gpu_plan {
   float* d_tri = nullptr;
   float* d_tri_leaf = nullptr;
   uint4* d_tri_packets = nullptr;
+  uint8_t* d_halton = nullptr;
   float* d_tri_attrs = nullptr;
   uint8_t* d_tables = nullptr;
   int variant = -1;
@@ -567,6 +568,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_tri);
   (void)hipFree(p->d_tri_leaf);
   (void)hipFree(p->d_tri_packets);
+  (void)hipFree(p->d_halton);
   (void)hipFree(p->d_tri_attrs);
   (void)hipFree(p->d_tables);
   (void)hipFree(p->d_ctxg);
@@ -579,6 +581,45 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
     for (auto& e : slot)
       if (e) (void)hipEventDestroy(e);
   delete p;
+}
+
+// HaltonSampler's tables for the device (sampler.cpp:39-62, lowdiscrepancy.cpp:5-17, primes.cpp): the first kHaltonDims
+// primes, their prefix sums (PrimeSums) and, per prime p, a permutation of 0 .. p-1 -- the identity shuffled with ONE
+// default-seeded RNG running through all the primes in order (shuffle(): element i swaps with i + next32u(p - i)), so the
+// permutations of the first kHaltonDims primes are a prefix of the reference's table of 1000.  Derived, not stored.
+struct HaltonHostTables {
+  std::vector<int> primes_and_sums;  // [kHaltonDims] primes, [kHaltonDims] prefix sums
+  std::vector<uint16_t> perms;
+};
+static const HaltonHostTables& halton_host_tables() {
+  static const HaltonHostTables tables = [] {
+    HaltonHostTables t;
+    t.primes_and_sums.assign(size_t(2 * kHaltonDims), 0);
+    int count = 0, sum = 0;
+    for (int n = 2; count < kHaltonDims; n++) {
+      bool prime = true;
+      for (int d = 2; d * d <= n && prime; d++) prime = n % d != 0;
+      if (!prime) continue;
+      t.primes_and_sums[size_t(count)] = n;
+      t.primes_and_sums[size_t(kHaltonDims + count)] = sum;
+      sum += n;
+      count++;
+    }
+    t.perms.resize(size_t(sum));
+    DRng rng = rng_seed(0);  // `RNG rng;`
+    for (int k = 0; k < kHaltonDims; k++) {
+      const int p = t.primes_and_sums[size_t(k)];
+      uint16_t* perm = &t.perms[size_t(t.primes_and_sums[size_t(kHaltonDims + k)])];
+      for (int j = 0; j < p; j++) perm[j] = uint16_t(j);
+      for (int j = 0; j < p; j++) {
+        const uint64_t u = rng_next64(rng);  // RNG::next32u(n) = uint32(u ^ (u >> 32)) % n  (rng.h:107-114)
+        const uint32_t other = uint32_t(j) + uint32_t(u ^ (u >> 32)) % uint32_t(p - j);
+        std::swap(perm[j], perm[other]);
+      }
+    }
+    return t;
+  }();
+  return tables;
 }
 
 // The mesh triangles as LDS-sized packets (DeviceScene::tri_packets): per leaf-ordered triangle an 8-byte entry -- three
@@ -641,18 +682,22 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   // BlueSampler(n): n rounded up to a power of two, clamped to 256 (sampler.cpp:115-121).  SobolSampler(n):
   // n as given (sampler.h:127-131); the work decomposition here needs a power of two.
-  const bool sobol = prm->sampler == PINE_GPU_SAMPLER_SOBOL;
+  // HaltonSampler(n): n as given too (sampler.h:44-46).  Both run in the F_SOBOL kernel variants.
+  const bool halton = prm->sampler == PINE_GPU_SAMPLER_HALTON;
+  const bool sobol = prm->sampler == PINE_GPU_SAMPLER_SOBOL || halton;  // (the sampler is not BlueSampler)
   if (prm->sampler != PINE_GPU_SAMPLER_BLUE && !sobol) {
     set_error("unknown sampler kind");
     return -1;
   }
   const int spp = sobol ? prm->spp : effective_spp(prm->spp);
   if (spp <= 0) {
-    set_error(sobol ? "`SobolSampler` should have positive samples per pixel" : "samples per pixel must be positive");
+    set_error(halton ? "`HaltonSampler` should have positive samples per pixel"
+                     : sobol ? "`SobolSampler` should have positive samples per pixel" : "samples per pixel must be positive");
     return -1;
   }
   if (sobol && ((spp & (spp - 1)) != 0 || spp > kMaxDeviceSpp)) {
-    set_error("SobolSampler on the device: samples per pixel must be a power of two, at most 4096");
+    set_error(halton ? "HaltonSampler on the device: samples per pixel must be a power of two, at most 4096"
+                     : "SobolSampler on the device: samples per pixel must be a power of two, at most 4096");
     return -1;
   }
   if (prm->shard_world < 1 || prm->shard_rank < 0 || prm->shard_rank >= prm->shard_world) {
@@ -782,7 +827,18 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.tables.tile_stride = 0;
   S.tables.win_lo = 0;
   S.tables.win_len = 0;
-  S.tables.kind = sobol ? 1 : 0;
+  S.tables.kind = halton ? 2 : sobol ? 1 : 0;
+  S.tables.halton_primes = nullptr;
+  S.tables.halton_perms = nullptr;
+  if (halton) {
+    const HaltonHostTables& ht = halton_host_tables();
+    const size_t head = size_t(2 * kHaltonDims) * sizeof(int), bytes = head + ht.perms.size() * sizeof(uint16_t);
+    HIP_OK(hipMalloc((void**)&p->d_halton, bytes));
+    HIP_OK(hipMemcpy(p->d_halton, ht.primes_and_sums.data(), head, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(p->d_halton + head, ht.perms.data(), ht.perms.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    S.tables.halton_primes = reinterpret_cast<const int*>(p->d_halton);
+    S.tables.halton_perms = reinterpret_cast<const uint16_t*>(p->d_halton + head);
+  }
   {
     // SobolSampler(spp): log2_spp = psl::log2i(spp); init(image_size): nbase4_digits =
     // log2i(roundup2(max(w, h))) + (log2_spp + 1) / 2   (sampler.h:127-129, sampler.cpp:81-84)
@@ -835,7 +891,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (sobol && (need & F_SSS)) {
     // a BSSRDF walk draws from the sampler at every step: SobolSampler's dimension counter (no wrap-around,
     // unlike BlueSampler's) is unbounded there and does not fit the packed path state
-    set_error("SobolSampler with Subsurface materials is not supported on the device");
+    set_error(halton ? "HaltonSampler with Subsurface materials is not supported on the device"
+                     : "SobolSampler with Subsurface materials is not supported on the device");
     return -1;
   }
   for (auto& L : light_list)

@@ -676,6 +676,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         REGION(0);  // camera ray generation
         // start sample s_cur: BlueSobolSampler index = s, dimension = 0 (sampler.h:174-181)
         st.start_sample(st.s_cur());
+        if constexpr (F & F_SOBOL)
+          if (S.tables.kind == 2) st.set_dim(2);  // HaltonSampler::start_pixel / start_next_sample: dimension = 2
         const int px = int(pxy & 0xffffu), py = int(pxy >> 16);
         // g++ evaluates gen_ray's arguments right to left (path.cpp:35): lens first, then jitter
         DRng g = rng_load();

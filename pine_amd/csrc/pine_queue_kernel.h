@@ -1175,6 +1175,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const DRay r = camera_gen_ray(S.cam, pf, f2{lx, ly});
         PackedState st{0};
         st.start_sample(s_next);
+        if constexpr (F & F_SOBOL)
+          if (S.tables.kind == 2) st.set_dim(2);  // HaltonSampler::start_pixel / start_next_sample: dimension = 2
         cstu[CF_PXY * kQCtx + id] = pxy;
         cstu[CF_SBASE * kQCtx + id] = sample_base;
         extend(id, r.o, r.d, r.tmax, st, to_shade2, to_term2, to_xc2);

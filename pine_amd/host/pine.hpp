@@ -139,10 +139,17 @@ struct SobolSampler {  // sampler.h:83-164: spp as given (on the device a power 
   int requested;
   explicit SobolSampler(int spp) : requested(spp) {}
 };
-struct Sampler {  // the variant PathIntegrator takes (sampler.h:275-; Uniform / Halton are not reproducible / not built)
+struct HaltonSampler {  // sampler.h:40-81: spp as given (on the device a power of two up to 4096)
+  int requested;
+  explicit HaltonSampler(int spp) : requested(spp) {
+    if (spp <= 0) throw Error("`HaltonSampler` should have positive samples per pixel");
+  }
+};
+struct Sampler {  // the variant PathIntegrator takes (sampler.h:275-; UniformSampler is not reproducible)
   int requested, kind;
   Sampler(BlueSampler s) : requested(s.requested), kind(PINE_GPU_SAMPLER_BLUE) {}
   Sampler(SobolSampler s) : requested(s.requested), kind(PINE_GPU_SAMPLER_SOBOL) {}
+  Sampler(HaltonSampler s) : requested(s.requested), kind(PINE_GPU_SAMPLER_HALTON) {}
 };
 
 class Scene {

@@ -1865,10 +1865,18 @@ Interp::Interp() {
     return v;
   });
   r.convert("SobolSampler", "Sampler", [](const Value& v) { return retype(v, "Sampler"); });
-  for (const char* k : {"BlueSampler", "SobolSampler"})
+  // HaltonSampler(i32) (sampler.cpp:39-62, :176-181)
+  r.def("HaltonSampler", {"i32"}, "HaltonSampler", [](Interp&, std::vector<Cell>& a) {
+    if (a[0]->i[0] <= 0) fail("`HaltonSampler` should have positive samples per pixel");
+    Value v = retype(mk_i32(a[0]->i[0]), "HaltonSampler");
+    v.i[1] = PINE_GPU_SAMPLER_HALTON;
+    return v;
+  });
+  r.convert("HaltonSampler", "Sampler", [](const Value& v) { return retype(v, "Sampler"); });
+  for (const char* k : {"BlueSampler", "SobolSampler", "HaltonSampler"})
     r.def("spp", {k}, "i32", [](Interp&, std::vector<Cell>& a) {
       int n = a[0]->i[0];
-      if (a[0]->i[1] != PINE_GPU_SAMPLER_SOBOL) {  // BlueSobolSampler ctor sampler.cpp:115-121
+      if (a[0]->i[1] == PINE_GPU_SAMPLER_BLUE) {  // BlueSobolSampler ctor sampler.cpp:115-121
         n = n > 256 ? 256 : n;
         int p = 1;
         while (p < n) p *= 2;
@@ -1879,10 +1887,7 @@ Interp::Interp() {
   // names a script may reach for that this build deliberately does not provide: say why
   r.def("UniformSampler", {"i32"}, "Sampler", [](Interp&, std::vector<Cell>&) -> Value {
     fail("`UniformSampler` is not provided: its stream depends on the reference's thread scheduling (per-thread RNG clones, "
-         "no per-pixel reseed), so there is no result to reproduce -- use BlueSampler or SobolSampler");
-  });
-  r.def("HaltonSampler", {"i32"}, "Sampler", [](Interp&, std::vector<Cell>&) -> Value {
-    fail("`HaltonSampler` is not built on the GPU path -- use BlueSampler or SobolSampler");
+         "no per-pixel reseed), so there is no result to reproduce -- use BlueSampler, SobolSampler or HaltonSampler");
   });
   r.def("PathIntegrator", {"Sampler", "i32"}, "PathIntegrator", [](Interp&, std::vector<Cell>& a) {
     if (a[1]->i[0] <= 0) fail("`PathIntegrator` expect `max_path_length` to be positive, get " + std::to_string(a[1]->i[0]));
@@ -1898,7 +1903,7 @@ Interp::Interp() {
     if (!s->camera) fail("PathIntegrator.render: scene has no camera");
     auto f = obj<CameraObj>(s->camera)->film;
     if (in.flags & PINE_PRL_DRY_RUN) {
-      in.log(std::string("@render PathIntegrator ") + (p->sampler == PINE_GPU_SAMPLER_SOBOL ? "SobolSampler " : "BlueSampler ") +
+      in.log(std::string("@render PathIntegrator ") + (p->sampler == PINE_GPU_SAMPLER_SOBOL ? "SobolSampler " : p->sampler == PINE_GPU_SAMPLER_HALTON ? "HaltonSampler " : "BlueSampler ") +
              std::to_string(p->spp) + " max_path_length " + std::to_string(p->depth) + "\n");
       in.log(describe_scene(s->h));
       in.log("@end\n");
@@ -1953,7 +1958,7 @@ static std::string value_text(const Value& v) {
     snprintf(buf, sizeof buf, "%a", double(x));
     return std::string(buf);
   };
-  if (v.type == "i32" || v.type == "BlueSampler" || v.type == "SobolSampler") s += std::to_string(v.i[0]);
+  if (v.type == "i32" || v.type == "BlueSampler" || v.type == "SobolSampler" || v.type == "HaltonSampler") s += std::to_string(v.i[0]);
   else if (v.type == "f32") s += hexf(v.f[0]);
   else if (v.type == "Nodef" || v.type == "Node3f") {
     auto n = std::dynamic_pointer_cast<NodeObj>(v.o);

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SOBOL_FILM_NAMES, GOLDEN, FILM_NAMES, assert_bit_equal, load_film
+from conftest import SOBOL_FILM_NAMES, HALTON_FILM_NAMES, GOLDEN, FILM_NAMES, assert_bit_equal, load_film
 
 pytestmark = pytest.mark.gpu
 
@@ -198,6 +198,42 @@ def test_sobol_sampler_film_matches_reference_golden(name):
     film, st = _render(sc, pa.SobolSampler(spp), depth)
     assert st.spp_effective == spp
     assert_bit_equal(film, ref, name)
+
+
+@pytest.mark.parametrize("name", HALTON_FILM_NAMES)
+def test_halton_sampler_film_matches_reference_golden(name):
+    """PathIntegrator(HaltonSampler(spp), depth) on the device (sampler.h:40-81: scrambled radical inverses, digit
+    permutations derived on the host from a default-seeded RNG, pixel offsets through the 128 x 243 grid) against the film
+    the REAL reference rendered with HaltonSampler; the 12-spp film is the reference's to take and the device's to refuse."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    ref, ps, spp, depth = load_film(name)
+    sc = {"halton_cbox_readme_40_s8_d4": lambda: scenes.cbox((40, 40), "readme"),
+          "halton_mats_zoo_32_s12_d6": lambda: scenes.materials_zoo((32, 32))}[name]()
+    assert sc.describe() == ps
+    if spp & (spp - 1):
+        with pytest.raises(pa.PineError, match="power of two"):
+            pa.Plan(sc, pa.HaltonSampler(spp), depth)
+        return
+    film, st = _render(sc, pa.HaltonSampler(spp), depth)
+    assert st.spp_effective == spp
+    assert_bit_equal(film, ref, name)
+
+
+def test_halton_sampler_matches_the_oracle(oracle, path_kernel):
+    """... and against the CPU restatement (itself pinned by both reference films) on scenes with every material, node
+    graphs, every light kind, meshes and 10 000-cone-class BVHs, up to 64 spp and depth 8 (42 sampler dimensions)."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    cases = [(scenes.materials_zoo((32, 32)), 16, 6), (scenes.lights_zoo((40, 40)), 8, 5), (scenes.classic_cones((64, 32), 12), 4, 6),
+             (scenes.sss((32, 32), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True), 8, 6), (scenes.cbox((37, 29)), 64, 8)]
+    for i, (sc, spp, depth) in enumerate(cases):
+        w, h = sc.camera.film().size
+        f, st = _render(sc, pa.HaltonSampler(spp), depth)
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth, sampler="halton")
+        assert_bit_equal(f, ref, f"HaltonSampler case {i} ({path_kernel})")
+    with pytest.raises(pa.PineError, match="Subsurface"):
+        pa.Plan(scenes.sss((16, 16), 1), pa.HaltonSampler(4), 4)
 
 
 def test_sobol_sampler_limits():

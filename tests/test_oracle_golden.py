@@ -87,7 +87,7 @@ def test_halton_sampler_film_bit_identical_to_reference(oracle, name):
     """HaltonSampler (sampler.h:40-81, sampler.cpp:16-79): scrambled radical inverses over the first 1000 primes, the
     digit permutations shuffled by a default-seeded RNG, pixel offsets through the 128 x 243 grid -- the oracle's
     restatement (tables derived, not stored) against films the real reference rendered with HaltonSampler(spp).
-    Oracle only: the device path refuses this sampler."""
+    (The device path is held to the same two films and to this restatement: tests/test_gpu_parity.py.)"""
     ref, ps, spp, depth = load_film(name)
     h, w, _ = ref.shape
     film, st = oracle.render(ps, (w, h), spp, depth, sampler="halton")

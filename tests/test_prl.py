@@ -233,8 +233,11 @@ def test_sobol_sampler_in_scripts():
     assert prl.evaluate("BlueSampler(5).spp()") == "i32 8"
     with pytest.raises(prl.PrlError, match="thread scheduling"):
         prl.interpret("PathIntegrator(UniformSampler(4), 3);", dry_run=True)
-    with pytest.raises(prl.PrlError, match="not built"):
-        prl.interpret("PathIntegrator(HaltonSampler(4), 3);", dry_run=True)
+    assert prl.evaluate("HaltonSampler(12).spp()") == "i32 12"  # (as given, sampler.h:44-46)
+    with pytest.raises(prl.PrlError, match="positive"):
+        prl.interpret("PathIntegrator(HaltonSampler(0), 3);", dry_run=True)
+    out_h = prl.interpret(_cornell((64, 64), 8, 4).replace("BlueSampler(spp)", "HaltonSampler(spp)"), dry_run=True)
+    assert "@render PathIntegrator HaltonSampler 8 max_path_length 4" in out_h
     src = _cornell((64, 64), 32, 4).replace("BlueSampler(spp)", "SobolSampler(spp)")
     assert "SobolSampler(spp)" in src
     out = prl.interpret(src, dry_run=True)
