@@ -24,8 +24,8 @@ struct GpuPathIntegrator {
   GpuPathIntegrator(Sampler sampler_, int max_path_length) : sampler(MOVE(sampler_)), max_path_length(max_path_length) {
     if (max_path_length <= 0)
       SEVERE("`PathIntegrator` expect `max_path_length` to be positive, get", max_path_length);  // path.cpp:12-13
-    if (!sampler.is<BlueSobolSampler>() && !sampler.is<SobolSampler>())
-      SEVERE("GpuPathIntegrator supports BlueSampler and SobolSampler");
+    if (!sampler.is<BlueSobolSampler>() && !sampler.is<SobolSampler>() && !sampler.is<HaltonSampler>())
+      SEVERE("GpuPathIntegrator supports BlueSampler, SobolSampler and HaltonSampler");
   }
 
   // Replays an already built scene on the C ABI.  The caller owns the returned handle.
@@ -98,7 +98,7 @@ struct GpuPathIntegrator {
     auto* s = mirror(scene);
     auto& film = scene.camera.film();
     pine_gpu_render_params prm{sampler.spp(), max_path_length, /*device*/ 0, /*rank*/ 0, /*world*/ 1, 0, 0,
-                               sampler.is<SobolSampler>() ? PINE_GPU_SAMPLER_SOBOL : PINE_GPU_SAMPLER_BLUE};
+                               sampler.is<SobolSampler>() ? PINE_GPU_SAMPLER_SOBOL : sampler.is<HaltonSampler>() ? PINE_GPU_SAMPLER_HALTON : PINE_GPU_SAMPLER_BLUE};
     // film.data() is Array2d<vec4>: W*H float4, row 0 first -- exactly the layout the ABI writes (array.h:51-55)
     const int rc = pine_gpu_path_render(s, &prm, &film.data()[0][0]);
     const psl::string err = rc < 0 ? pine_gpu_last_error() : "";
