@@ -32,6 +32,8 @@ enum : unsigned {
                           // the levels every ray visits) are staged in LDS, and the traversal stack holds 16-bit node ids
   F_LDS_REST = 1u << 14,  // with F_LDS_TOP: everything of the scene blob except the BVH nodes (shape / leaf / material / light records:
                           // small when the geometry count is, whatever the meshes' sizes) is staged in LDS as well
+  F_XSTAGE = 1u << 15,    // with F_LDS_TOP (stage-queued kernel): traversal is a stage of its own (XS / XC queues, lanes refilled) instead
+                          // of a loop inside stages S and T
   F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES | F_SOBOL,
 };
 

@@ -153,15 +153,15 @@ static const QueueVariant kQueueVariants[] = {
     // in whatever LDS the contexts and the 16-bit traversal stack (2 KB per slot) leave; traversals are resumable and
     // regrouped through the XS / XC queues (pine_trav.h)
     PINE_QV(F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP, 1024, "queue: rect+sphere+disk+cone/uber, 1024 contexts, BVH top in LDS (classic.pine's kinds exactly)"),
-    PINE_QV(kFAnalytic | F_LDS_TOP, 1024, "queue: analytic shapes/uber, 1024 contexts, BVH top in LDS"),
+    PINE_QV(kFAnalytic | F_LDS_TOP | F_XSTAGE, 1024, "queue: analytic shapes/uber, 1024 contexts, BVH top in LDS"),
     // everything except Subsurface (meshes, node-graph materials, every light kind); F_LDS_REST: few geometries (big
     // meshes or not): their shape / leaf / material / light records are staged in LDS too
-    PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP | F_LDS_REST, 1024, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP, 1024, "queue: all but SSS, 1024 contexts, BVH top in LDS"),
+    PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP | F_XSTAGE | F_LDS_REST, 1024, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS"),
+    PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP | F_XSTAGE, 1024, "queue: all but SSS, 1024 contexts, BVH top in LDS"),
     // Subsurface: the BSSRDF random walk is a third stage (W) with its own queue
-    PINE_QV(F_MESH | F_SSS | F_LDS_TOP | F_LDS_REST, 1024, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV(F_ALL | F_LDS_TOP | F_LDS_REST, 1024, "queue: all features, walk stage, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV(F_ALL | F_LDS_TOP, 1024, "queue: all features, walk stage, 1024 contexts, BVH top in LDS"),
+    PINE_QV(F_MESH | F_SSS | F_LDS_TOP | F_XSTAGE | F_LDS_REST, 1024, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top + scene records in LDS"),
+    PINE_QV(F_ALL | F_LDS_TOP | F_XSTAGE | F_LDS_REST, 1024, "queue: all features, walk stage, 1024 contexts, BVH top + scene records in LDS"),
+    PINE_QV(F_ALL | F_LDS_TOP | F_XSTAGE, 1024, "queue: all features, walk stage, 1024 contexts, BVH top in LDS"),
     // BVHs of 65 536 nodes and more: 32-bit traversal stack, no node cache
     PINE_QV(F_ALL, 1024, "queue: all features, walk stage, 1024 contexts"),
 #endif

@@ -31,7 +31,7 @@ static const PineFastVariant kFast[] = {
     PINE_FV(F_OBB | F_LDS_SCENE, PINE_QCTX, "fast queue: rect+transformed box/diffuse, scene in LDS"),
     PINE_FV(kFAnalytic | F_LDS_SCENE, PINE_QCTX, "fast queue: analytic shapes/uber, scene in LDS"),
     PINE_FV(F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP, 1024, "fast queue: rect+sphere+disk+cone/uber, 1024 contexts, BVH top in LDS"),
-    PINE_FV(F_MESH | F_SSS | F_LDS_TOP | F_LDS_REST, 1024, "fast queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top + scene records in LDS"),
+    PINE_FV(F_MESH | F_SSS | F_LDS_TOP | F_XSTAGE | F_LDS_REST, 1024, "fast queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top + scene records in LDS"),
 };
 }  // namespace pine_gpu_fast
 

@@ -33,7 +33,7 @@ constexpr int kQFields = 12;   // dwords of context state
 // queues: S shade, T terminal; W walk step (Subsurface variants); XS / XC parked shadow / closest-hit traversals
 // (F_LDS_TOP variants: pine_trav.h)
 enum : int { QS_S = 0, QS_T = 1, QS_W = 2, QS_XS = 3, QS_XC = 4 };
-constexpr int q_num_stage_queues(unsigned F) { return (F & F_LDS_TOP) ? 5 : (F & F_SSS) ? 3 : 2; }
+constexpr int q_num_stage_queues(unsigned F) { return ((F & F_LDS_TOP) && (F & F_XSTAGE)) ? 5 : (F & F_SSS) ? 3 : 2; }
 // Subsurface variants have two more rings that are not stages (see "sample tokens" below): K, the flags of the
 // workgroup's sample-token slots, and F, the ids of contexts with nothing to do
 constexpr int q_num_queues(unsigned F) { return q_num_stage_queues(F) + ((F & F_SSS) ? 2 : 0); }
@@ -89,11 +89,13 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   constexpr int kNStage = q_num_stage_queues(F);  // ... of which the first kNStage are stage queues
   constexpr bool kFork = (F & F_SSS) != 0;        // sample tokens (below)
   constexpr int QS_K = kNStage, QS_F = kNStage + 1;
-  constexpr bool kX = (F & F_LDS_TOP) != 0;  // resumable traversals + the XS / XC queues
-  static_assert(!(F & F_LDS_REST) || kX, "F_LDS_REST is an option of the F_LDS_TOP variants");
+  constexpr bool kTop = (F & F_LDS_TOP) != 0;         // flat traversal (pine_trav.h), node cache, 16-bit per-wave stacks
+  constexpr bool kX = kTop && (F & F_XSTAGE) != 0;    // ... as stages of its own: the XS / XC queues
+  static_assert(!(F & F_LDS_REST) || kTop, "F_LDS_REST is an option of the F_LDS_TOP variants");
+  static_assert(!(F & F_XSTAGE) || kTop, "F_XSTAGE is an option of the F_LDS_TOP variants");
   constexpr int kQCtxGlobalDwords = q_ctx_global_dwords(F);
   constexpr int kQCtxTravOffset = q_ctx_trav_offset(F);
-  using L = QLayout<CTX, kNQ, kX>;
+  using L = QLayout<CTX, kNQ, kTop>;
   constexpr int kQCtx = L::ctx, kQRing = L::ring, kQOffCtl = L::off_ctl, kQOffRing = L::off_ring, kQOffState = L::off_state,
                 kQOffSobol = L::off_sobol, kQOffWin = L::off_win, kQOffStack = L::off_stack;
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -283,6 +285,14 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if constexpr (kX) {
       cstf[CF_TMAX * kQCtx + id] = tmax;
       to_xc = true;  // traced by stage XC
+    } else if constexpr (kTop) {
+      // the flat traversal, here and now: every lane of the wave to its end
+      TravState ts;
+      trav_begin(V, ts);
+      const DRayOct oct = make_oct(ray);
+      trav_trips<false, F, kStride>(V, ray, oct, ts, stack, 0, 1 << 30);
+      SEC_MARK(6);  // closest-hit traversal
+      finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
     } else {
       int geom = -1, prim = 0;
       const bool hit = scene_traverse<false, F, kStride>(V, ray, stack, geom, prim);
@@ -660,7 +670,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         bool have_shadow = false;
         DRay shadow_ray{};
         auto shadow_test = [&](const DRay& sr) -> bool {
-          if constexpr (kX) {
+          if constexpr (kTop) {
             have_shadow = true;
             shadow_ray = sr;
             return false;  // evaluated as if visible; cleared below when the ray turns out occluded
@@ -760,6 +770,18 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         // ---- X variants: the shadow ray is traced by stage XS; the fold entry / result below hold the direct term as if
         // visible, and XS clears it when the ray turns out occluded ----
         const bool parked_shadow = kX && have_shadow;
+        if constexpr (kTop && !kX) {
+          // ... or (F_LDS_TOP variants without traversal stages) here, now that the BSDF has been sampled and little is live
+          if (__ballot(have_shadow) != 0) {
+            TravState sts;
+            trav_begin(V, sts);
+            if (!have_shadow) sts.done = 1;
+            const DRayOct soct = make_oct(shadow_ray);
+            trav_trips<true, F, kStride>(V, shadow_ray, soct, sts, stack, 0, 1 << 30);
+            if (have_shadow && sts.hit_geom >= 0) nee = mk3(0.0f);  // occluded
+          }
+          SEC_MARK(3);  // S: shadow traversal
+        }
         if (start_walk) {
           to_walk = true;  // (state stored above; the context continues in stage W)
         } else if (continues) {
