@@ -152,16 +152,22 @@ static const QueueVariant kQueueVariants[] = {
     // scenes that do not fit LDS whole (F_LDS_TOP): 1024 contexts; the top of the BVH (breadth-first numbering) is cached
     // in whatever LDS the contexts and the 16-bit traversal stack (2 KB per slot) leave; traversals are resumable and
     // regrouped through the XS / XC queues (pine_trav.h)
+    // The mesh-capable feature sets twice: with traversal stages (F_XSTAGE: XS / XC queues, lanes refilled -- taken for scenes
+    // WITH meshes whose BVH (nearly) fits the LDS node cache: the rays of a two-level BVH need very different numbers of trips
+    // and refilling pays), and with the flat traversal inside stages S / T (two queue hops per vertex fewer --
+    // taken otherwise: analytic scenes, 20 % faster that way whether their nodes fit or not, and BVHs that stay in L2, where
+    // a wave runs its rays to the end anyway).  plan_build decides.
+#define PINE_QV2(F, NAME) PINE_QV((F) | F_LDS_TOP | F_XSTAGE, 1024, NAME ", traversal stages"), PINE_QV((F) | F_LDS_TOP, 1024, NAME)
     PINE_QV(F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP, 1024, "queue: rect+sphere+disk+cone/uber, 1024 contexts, BVH top in LDS (classic.pine's kinds exactly)"),
-    PINE_QV(kFAnalytic | F_LDS_TOP | F_XSTAGE, 1024, "queue: analytic shapes/uber, 1024 contexts, BVH top in LDS"),
+    PINE_QV(kFAnalytic | F_LDS_TOP, 1024, "queue: analytic shapes/uber, 1024 contexts, BVH top in LDS"),
     // everything except Subsurface (meshes, node-graph materials, every light kind); F_LDS_REST: few geometries (big
     // meshes or not): their shape / leaf / material / light records are staged in LDS too
-    PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP | F_XSTAGE | F_LDS_REST, 1024, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV((F_ALL & ~F_SSS) | F_LDS_TOP | F_XSTAGE, 1024, "queue: all but SSS, 1024 contexts, BVH top in LDS"),
+    PINE_QV2((F_ALL & ~F_SSS) | F_LDS_REST, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS"),
+    PINE_QV2((F_ALL & ~F_SSS), "queue: all but SSS, 1024 contexts, BVH top in LDS"),
     // Subsurface: the BSSRDF random walk is a third stage (W) with its own queue
-    PINE_QV(F_MESH | F_SSS | F_LDS_TOP | F_XSTAGE | F_LDS_REST, 1024, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV(F_ALL | F_LDS_TOP | F_XSTAGE | F_LDS_REST, 1024, "queue: all features, walk stage, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV(F_ALL | F_LDS_TOP | F_XSTAGE, 1024, "queue: all features, walk stage, 1024 contexts, BVH top in LDS"),
+    PINE_QV2(F_MESH | F_SSS | F_LDS_REST, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top + scene records in LDS"),
+    PINE_QV2(F_ALL | F_LDS_REST, "queue: all features, walk stage, 1024 contexts, BVH top + scene records in LDS"),
+    PINE_QV2(F_ALL, "queue: all features, walk stage, 1024 contexts, BVH top in LDS"),
     // BVHs of 65 536 nodes and more: 32-bit traversal stack, no node cache
     PINE_QV(F_ALL, 1024, "queue: all features, walk stage, 1024 contexts"),
 #endif
@@ -944,6 +950,14 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
         const size_t lds = kQueueVariants[v].fixed_lds + stack_bytes + ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0) +
                            ((F & F_LDS_REST) ? rest_bytes : 0);
         if (lds > 160 * 1024) continue;
+        if (F & F_XSTAGE) {
+          // traversal stages only where refilling pays: a scene with meshes, (nearly) all nodes in this variant's LDS.
+          // PINE_GPU_XSTAGE=0 / 1: never / always (measurement aid, tools/xstage_ab.py).
+          const size_t cached = no_top ? 0 : std::min<size_t>(A.nodes.size(), (160 * 1024 - lds) / sizeof(DNode));
+          bool want = (need & F_MESH) != 0 && cached * 10 >= A.nodes.size() * 9;
+          if (const char* e = getenv("PINE_GPU_XSTAGE")) want = atoi(e) != 0;
+          if (!want) continue;  // (the same feature set without F_XSTAGE follows in the table)
+        }
         p->queue_variant = v;
         p->lds_bytes = lds;
         S.lds_nodes = 0;

@@ -590,6 +590,30 @@ def test_traversal_stage_refill_settings_change_nothing(oracle, monkeypatch, pat
         assert_bit_equal(f, ref, f"traversal stages, case {i}")
 
 
+@pytest.mark.parametrize("xstage", ["0", "1"])
+def test_traversal_as_stages_or_inside_stages_changes_nothing(oracle, monkeypatch, path_kernel, xstage):
+    """Every F_LDS_TOP feature set that can hold meshes is compiled twice: traversal as stages XS / XC (F_XSTAGE; what
+    plan_build picks for mesh scenes whose BVH fits the LDS node cache) and the same flat traversal inside stages S / T
+    (analytic scenes; BVHs that stay in L2).  PINE_GPU_XSTAGE forces one or the other on scenes of both classes."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    if path_kernel == "mega":
+        pytest.skip("the stage-queued kernel's machinery")
+    monkeypatch.setenv("PINE_GPU_XSTAGE", xstage)
+    cases = [(scenes.classic_cones((96, 48), 40), 16, 6),
+             (scenes.sss((48, 48), 2), 16, 8),
+             (scenes.sss((40, 40), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True), 16, 6),
+             (scenes.xshapes_zoo((40, 40)), 8, 5)]
+    for i, (sc, spp, depth) in enumerate(cases):
+        if i == 3:
+            monkeypatch.setenv("PINE_GPU_NO_LDS_SCENE", "1")  # (a cbox-class scene otherwise: whole scene in LDS)
+        w, h = sc.camera.film().size
+        f, st = _render(sc, spp, depth)
+        assert st.block_threads == 1024
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
+        assert_bit_equal(f, ref, f"PINE_GPU_XSTAGE={xstage}, case {i}")
+
+
 @pytest.mark.parametrize("env", [{}, {"PINE_GPU_NO_FORK": "1"}, {"PINE_GPU_POOL_ITEMS": "16"}, {"PINE_GPU_POOL_ITEMS": "4096"}])
 def test_sample_tokens_change_nothing(oracle, monkeypatch, path_kernel, env):
     """Subsurface scenes: a pixel's samples are sequentially dependent through the pixel's RNG (the BSSRDF channel pick,
