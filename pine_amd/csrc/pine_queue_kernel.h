@@ -30,8 +30,8 @@ constexpr int kQBlock = PINE_QBLOCK;  // threads per workgroup (one workgroup pe
 #define PINE_QCTX 1536
 #endif
 constexpr int kQFields = 12;   // dwords of context state
-// queues: S shade, T terminal; W walk step (Subsurface variants); XS / XC parked shadow / closest-hit traversals
-// (F_LDS_TOP variants: pine_trav.h)
+// queues: S shade, T terminal; W walk step (Subsurface variants); XS / XC shadow / closest-hit rays waiting for the
+// traversal stages (F_XSTAGE variants: pine_trav.h)
 enum : int { QS_S = 0, QS_T = 1, QS_W = 2, QS_XS = 3, QS_XC = 4 };
 constexpr int q_num_stage_queues(unsigned F) { return ((F & F_LDS_TOP) && (F & F_XSTAGE)) ? 5 : (F & F_SSS) ? 3 : 2; }
 // Subsurface variants have two more rings that are not stages (see "sample tokens" below): K, the flags of the
@@ -71,7 +71,7 @@ struct QLayout {
 // the 256 KB tables (L2-resident, shared by every context).
 //   float4 0: RNG            1: beta flags lo, hi, -, -
 //   float4 2: walk ray origin (at exit: the exit point) | channel    3: walk direction | tmax    4: exit normal
-//   F_LDS_TOP variants, after those: the record of a parked traversal (pine_trav.h): shadow ray + flags, state, stack
+//   F_LDS_TOP variants, after those: the vertex's shadow ray for stage XS (origin, direction, tmax, flags)
 constexpr int kQCtxGlobalDwordsPlain = 4, kQCtxGlobalDwordsSss = 20;
 constexpr int q_ctx_trav_offset(unsigned F) { return (F & F_SSS) ? kQCtxGlobalDwordsSss : kQCtxGlobalDwordsPlain; }
 constexpr int q_ctx_global_dwords(unsigned F) { return q_ctx_trav_offset(F) + ((F & F_LDS_TOP) ? kTravRecordDwords : 0); }

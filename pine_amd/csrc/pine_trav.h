@@ -1,19 +1,18 @@
-// pine_amd/csrc/pine_trav.h -- resumable BVH traversal for the stage-queued kernel (included by
-// pine_kernels.hip after SceneView / fetch_node; used by the F_LDS_TOP variants of pine_queue_kernel.h).
+// pine_amd/csrc/pine_trav.h -- the flat BVH traversal of the stage-queued kernel's F_LDS_TOP variants (included by
+// pine_kernels.hip after SceneView / fetch_node; used by pine_queue_kernel.h).
 //
 // Why: in scenes with a real BVH (10 000 cones, triangle meshes) the rays of one wave need wildly
-// different numbers of node visits; with one traversal per stage pass the wave runs until its longest ray
-// is done.  Measured on the round-1 structure: 12.8 % VALU lane utilisation on the Subsurface-icosphere
-// scene, 27.6 % on the 10 000-cone scene.  Here a traversal is an explicit per-lane state machine -- ONE
-// step per loop trip (a node visit, one leaf primitive, or a pop) -- that can stop at any trip boundary:
-// when too few lanes of the wave are still travelling, those lanes park their state (a few registers and
-// their stack entries) in the context's global record and the contexts go to a traversal queue, where
-// they are regrouped, 64 at a time, with the stragglers of other waves.
+// different numbers of node visits; with nested node / leaf loops the wave runs until its longest ray
+// is done and lanes wait for their neighbours' inner loops.  Measured on the round-1 structure: 12.8 % VALU lane
+// utilisation on the Subsurface-icosphere scene, 27.6 % on the 10 000-cone scene.  Here a traversal is an explicit
+// per-lane state machine -- per loop trip at most one node visit and one leaf primitive -- whose state is a handful of
+// registers (TravState) and that can stop at any trip boundary: pine_queue_kernel.h either runs it to the end inside
+// stages S / T, or (F_XSTAGE variants) makes it stages of its own in which a wave retires its finished lanes and hands
+// them new rays from the queue while the others keep travelling.
 //
 // The order of operations per ray is pine's exactly (src/pine/impl/accel/bvh.cpp:321-451, :497-548):
 // both child boxes are tested against the tmax captured when the node is visited, leaf children are
 // tested in stored order before the next node, the child with the larger exit distance is pushed.
-// Suspending and resuming does not change it: the state that continues is the state that stopped.
 #pragma once
 
 namespace pine_gpu {
