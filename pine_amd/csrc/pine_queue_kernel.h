@@ -269,6 +269,26 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     to_shade = !terminal;
     to_term = terminal;
   };
+#ifdef PINE_TRIP_STATS
+  // diagnostic: per stage pass, the wave's longest shadow traversal + its longest closest-hit traversal (what two loops
+  // cost) against its longest shadow + closest sequence of ONE lane (what a merged loop would cost); needs -DPINE_PROFILE_REGIONS
+  int stat_shadow_trips = 0;
+  auto trip_stats = [&](int& shadow_trips, int closest_trips) {
+    int ms = shadow_trips, mc = closest_trips, mb = shadow_trips + closest_trips;
+    for (int off = 32; off > 0; off >>= 1) {
+      ms = max(ms, __shfl_xor(ms, off));
+      mc = max(mc, __shfl_xor(mc, off));
+      mb = max(mb, __shfl_xor(mb, off));
+    }
+    if (lane == 0) {
+      atomicAdd(&g_region_lanes[10], (unsigned long long)(ms + mc));
+      atomicAdd(&g_region_hits[10], 1ull);
+      atomicAdd(&g_region_lanes[11], (unsigned long long)mb);
+      atomicAdd(&g_region_hits[11], 1ull);
+    }
+    shadow_trips = 0;
+  };
+#endif
   auto trav_record = [&](int id) -> uint32_t* { return ctxg + (ctx_base + size_t(id)) * kQCtxGlobalDwords + kQCtxTravOffset; };
   // trace the context's new ray (closest hit), record the hit, classify (finish_hit).  X variants: the ray waits in
   // the context and the context goes to XC; the traversal stage traces it.
@@ -290,7 +310,13 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       TravState ts;
       trav_begin(V, ts);
       const DRayOct oct = make_oct(ray);
+#ifdef PINE_TRIP_STATS
+      int ctrips = 0;
+      trav_trips<false, F, kStride>(V, ray, oct, ts, stack, 0, 1 << 30, &ctrips);
+      trip_stats(stat_shadow_trips, ctrips);
+#else
       trav_trips<false, F, kStride>(V, ray, oct, ts, stack, 0, 1 << 30);
+#endif
       SEC_MARK(6);  // closest-hit traversal
       finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
     } else {
@@ -777,7 +803,11 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             trav_begin(V, sts);
             if (!have_shadow) sts.done = 1;
             const DRayOct soct = make_oct(shadow_ray);
+#ifdef PINE_TRIP_STATS
+            trav_trips<true, F, kStride>(V, shadow_ray, soct, sts, stack, 0, 1 << 30, &stat_shadow_trips);
+#else
             trav_trips<true, F, kStride>(V, shadow_ray, soct, sts, stack, 0, 1 << 30);
+#endif
             if (have_shadow && sts.hit_geom >= 0) nee = mk3(0.0f);  // occluded
           }
           SEC_MARK(3);  // S: shadow traversal

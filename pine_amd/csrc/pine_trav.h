@@ -71,12 +71,13 @@ __device__ __forceinline__ void trav_begin(const SceneView& S, TravState& ts) {
 // the steps per ray is unchanged: primitives pending > second pending range > node > pop > mesh return.
 template <bool ANY, unsigned F, int STRIDE, class StackT>
 __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const DRayOct& oct, TravState& ts, StackT* stack, int keep_lanes,
-                                           int min_trips) {
+                                           int min_trips, int* lane_trips = nullptr) {
   for (int trip = 0;; trip++) {
     const unsigned long long travelling = __ballot(ts.done == 0);
     if (travelling == 0) break;
     if (trip >= min_trips && __popcll(travelling) < keep_lanes) break;
     if (ts.done) continue;
+    if (lane_trips) ++*lane_trips;  // (diagnostic builds: trips this lane took part in)
     REGION(ANY ? 5 : 1);  // (per-arm lane counts of -DPINE_PROFILE_REGIONS builds: a trip / its triangle, top-level primitive and node arms)
     if (ts.pan == 0 && ts.next >= 0) {
       // ---- one node: both child boxes against the tmax of this moment (bvh.cpp:405-446) ----
