@@ -1298,6 +1298,9 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
   HIP_OK(hipMemcpy(&c, p->d_counters, sizeof c, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; i++) out[i] = c.section_cycles[i];
 #ifdef PINE_PROFILE_SECTIONS
+  if (c.t_end > c.t_start && c.t_start)
+    fprintf(stderr, "timeline: kernel %.2f ms, work-item pool dry after %.2f ms\n", double(c.t_end - c.t_start) * 1e-5,
+            c.t_pool_dry ? double(c.t_pool_dry - c.t_start) * 1e-5 : -1.0);
   unsigned long long rl[16], rh[16];
   HIP_OK(hipMemcpyFromSymbol(rl, HIP_SYMBOL(g_region_lanes), sizeof rl));
   HIP_OK(hipMemcpyFromSymbol(rh, HIP_SYMBOL(g_region_hits), sizeof rh));

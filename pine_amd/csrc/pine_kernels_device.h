@@ -436,6 +436,7 @@ struct Counters {
   unsigned long long bail_code, bail_a, bail_b;
   unsigned long long walk_steps;  // BSSRDF random-walk steps (stage-queued kernel, F_SSS variants)
   unsigned long long section_cycles[16];  // diagnostic builds (-DPINE_PROFILE_SECTIONS) only
+  unsigned long long t_start, t_pool_dry, t_end;  // ... 100 MHz wall clock: first workgroup in, the work-item pool found empty, last workgroup out
 };
 
 

@@ -444,6 +444,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   // (No cap on the number of trips: a trip that finds work retires at least one stage of one path, and the
   // work of a launch is finite; the trips that find none are bounded in wall-clock time below.)
   unsigned long long idle_since = 0;
+#ifdef PINE_PROFILE_SECTIONS
+  if (tid == 0) atomicCAS(&counters->t_start, 0ull, wall_clock64());
+#endif
   if (W.debug_force_bail && blockIdx.x == 0 && tid == 0) bail(7, 0, 0);  // test hook: the host must report this launch as failed
   __syncthreads();
   while (true) {
@@ -1131,6 +1134,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           if (want != 0u && nx == en && lds_load(&qctl[QC_EXHAUSTED]) == 0u) {
             const unsigned long long b = atomicAdd(&counters->next_item, (unsigned long long)W.pool_items);
             if (b >= W.total_items) {
+#ifdef PINE_PROFILE_SECTIONS
+              atomicCAS(&counters->t_pool_dry, 0ull, wall_clock64());
+#endif
               __atomic_store_n(&qctl[QC_EXHAUSTED], 1u, __ATOMIC_RELAXED);
             } else {
               post_progress(W, b, 9);
@@ -1242,6 +1248,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if (lane == 0) atomicSub(&qctl[QC_BUSY], 1u);
   }
 
+#ifdef PINE_PROFILE_SECTIONS
+  if (tid == 0) atomicMax(&counters->t_end, wall_clock64());
+#endif
   SEC_FLUSH();
   unsigned long long sc = shadow_count;
   for (int off = 32; off > 0; off >>= 1) sc += __shfl_down(sc, off);
