@@ -1073,6 +1073,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // Subsurface is the only in-path user of the RNG and only before a path's first non-delta bounce: such a path hands its
   // pixel's next sample on when it has made that bounce (pine_queue_kernel.h, "sample tokens")
   W.fork_sealed = (in_path_rng && !uber_rng && getenv("PINE_GPU_NO_FORK") == nullptr) ? 1 : 0;
+  // ... and then a workgroup keeps at most 320 pixels in flight (each with one unsealed path; the other contexts trace the
+  // sealed rest of earlier samples): when the work-item pool runs dry little is left half-done, so the workgroups end closer
+  // together (C5: 178 -> 171 ms; 192 ... 384 within 1 %, 512 and more as without a limit)
+  W.max_pixels = W.fork_sealed ? 320 : (1 << 20);
+  if (const char* e = getenv("PINE_GPU_MAX_PIXELS")) W.max_pixels = atoi(e) > 0 ? atoi(e) : W.max_pixels;
   // A workgroup claims 512 items at a time; when an item is a pixel's whole sample sequence (serial-RNG scenes) that is
   // tens of milliseconds of its time, and the last claims decide when the launch ends: one 8x8 tile at a time there.
   W.pick_spins = 8;

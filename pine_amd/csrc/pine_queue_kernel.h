@@ -42,7 +42,7 @@ enum : int { CF_OX, CF_OY, CF_OZ, CF_DX, CF_DY, CF_DZ, CF_TMAX, CF_ST, CF_PXY, C
 constexpr unsigned kStFresh = 0xffffffffu;  // context has no path yet
 // control words: heads at 0..6; tails at 8..14 -- the S and T tails are ONE u64 (8..9) so that a stage reserves
 // slots in both with one atomic
-enum : int { QC_HEAD = 0, QC_TAIL = 8, QC_BUSY = 16, QC_LOCK = 17, QC_EXHAUSTED = 18, QC_PNEXT = 20, QC_PEND = 22, QC_ABORT = 24, QC_WORDS = 32 };
+enum : int { QC_HEAD = 0, QC_TAIL = 8, QC_BUSY = 16, QC_LOCK = 17, QC_EXHAUSTED = 18, QC_PNEXT = 20, QC_PEND = 22, QC_ABORT = 24, QC_PIXELS = 25, QC_WORDS = 32 };
 constexpr int kQTokenDwords = 8;  // a sample token (Subsurface variants): RNG state (4) | pixel, sample-buffer base, sample index, -
 constexpr unsigned kQSpinLimit = 1u << 22;  // every spin loop is bounded: a protocol bug must end the kernel, not hang the GPU
 constexpr int kQWinDwords = 5;  // per-thread sampler window: 3 dwords of ranking bytes (12 dimensions) + 2 of scrambling bytes
@@ -834,6 +834,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             if (W.fork_sealed && !st.sealed() && st.diffuse_length() > 0) {
               st.set_sealed();
               release = ((st.s_cur() + 1) & (W.samples_per_item - 1)) != 0;
+              if (!release) atomicSub(&qctl[QC_PIXELS], 1u);  // the pixel's last sample is under way: no longer "in flight" for the intake limit
             }
           }
           if (kX && parked_shadow) {
@@ -1093,6 +1094,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           s_next = s_now + 1;
           if ((kFork && st.sealed()) || (s_next & (W.samples_per_item - 1)) == 0) need_item = true;  // (sealed: the pixel's next sample went out as a token)
           else have_path = true;
+          if constexpr (kFork)
+            if (!st.sealed() && (s_next & (W.samples_per_item - 1)) == 0) atomicSub(&qctl[QC_PIXELS], 1u);
         }
       }
       SEC_MARK(7);  // T: terminal result + backward fold + sample store
@@ -1128,6 +1131,11 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             kgot = want < kavail ? want : kavail;
             __atomic_store_n(&qctl[QC_HEAD + QS_K], kbase + kgot, __ATOMIC_RELAXED);
             want -= kgot;
+            // pixels in flight per workgroup are bounded (W.max_pixels): each one's samples then follow one another
+            // quickly, and little is left half-done -- unevenly, workgroup by workgroup -- when the work-item pool runs dry
+            const unsigned inflight = lds_load(&qctl[QC_PIXELS]);
+            const unsigned room = inflight < unsigned(W.max_pixels) ? unsigned(W.max_pixels) - inflight : 0u;
+            if (want > room) want = room;
           }
           unsigned long long nx = (unsigned long long)lds_load(&qctl[QC_PNEXT]) | ((unsigned long long)lds_load(&qctl[QC_PNEXT + 1]) << 32);
           unsigned long long en = (unsigned long long)lds_load(&qctl[QC_PEND]) | ((unsigned long long)lds_load(&qctl[QC_PEND + 1]) << 32);
@@ -1146,6 +1154,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           }
           const unsigned long long avail = en - nx;
           got = want < avail ? want : unsigned(avail);
+          if constexpr (kFork) atomicAdd(&qctl[QC_PIXELS], got);
           base = nx;
           nx += got;
           __atomic_store_n(&qctl[QC_PNEXT], unsigned(nx), __ATOMIC_RELAXED);
@@ -1211,6 +1220,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             }
             item_rng = g;
             fresh_rng = true;
+          } else {
+            if constexpr (kFork) atomicSub(&qctl[QC_PIXELS], 1u);  // (counted when claimed)
           }
         }
       }

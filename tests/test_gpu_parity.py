@@ -614,13 +614,14 @@ def test_traversal_as_stages_or_inside_stages_changes_nothing(oracle, monkeypatc
         assert_bit_equal(f, ref, f"PINE_GPU_XSTAGE={xstage}, case {i}")
 
 
-@pytest.mark.parametrize("env", [{}, {"PINE_GPU_NO_FORK": "1"}, {"PINE_GPU_POOL_ITEMS": "16"}, {"PINE_GPU_POOL_ITEMS": "4096"}])
+@pytest.mark.parametrize("env", [{}, {"PINE_GPU_NO_FORK": "1"}, {"PINE_GPU_POOL_ITEMS": "16"}, {"PINE_GPU_POOL_ITEMS": "4096"},
+                                 {"PINE_GPU_MAX_PIXELS": "1"}, {"PINE_GPU_MAX_PIXELS": "100000"}])
 def test_sample_tokens_change_nothing(oracle, monkeypatch, path_kernel, env):
     """Subsurface scenes: a pixel's samples are sequentially dependent through the pixel's RNG (the BSSRDF channel pick,
     bxdf.cpp:335), but only until a path's first non-delta bounce -- after it the path draws no RNG value any more, so it
     releases a token (pixel, next sample index, RNG state) and ANOTHER context starts the pixel's next sample while this
-    path is still being traced.  Same films with the mechanism off, with it on, and whatever the size of a workgroup's
-    work-item claims; a film larger than one round of contexts and 64 samples per pixel, so that tokens, waiting
+    path is still being traced.  Same films with the mechanism off, with it on, whatever the size of a workgroup's
+    work-item claims and whatever the number of pixels it may have in flight (default 320; 1: a pixel at a time); a film larger than one round of contexts and 64 samples per pixel, so that tokens, waiting
     contexts and wake-ups all occur."""
     import pine_amd as pa
     from pine_amd import scenes
