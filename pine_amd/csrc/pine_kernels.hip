@@ -1022,7 +1022,13 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   p->serial_rng = in_path_rng;
   int kspi = prm->samples_per_item;
   if (in_path_rng) kspi = spp;
-  else if (kspi <= 0) kspi = (p->queue_variant >= 0 || p->fast) ? 1 : std::min(spp, 4);  // (queue kernel: one sample per item balances small shards best)
+  else if (kspi <= 0) {
+    // stage-queued kernel: two samples per item for the scene-in-LDS variants (cbox-class scenes, all pixels alike: half the
+    // checkpoint prepass and hand-outs, C2 13.93 -> 13.75 ms per step, C3 69.9 -> 68.4), one where pixels differ a lot
+    // (10 000 cones: 8.06 ms at one, 8.52 at two); the megakernel four
+    const unsigned qf = p->fast ? p->fast->features : p->queue_variant >= 0 ? kQueueVariants[p->queue_variant].features : 0u;
+    kspi = (p->queue_variant >= 0 || p->fast) ? ((qf & F_LDS_SCENE) ? std::min(spp, 2) : 1) : std::min(spp, 4);
+  }
   if (kspi > spp) kspi = spp;
   {  // spp is a power of two; k must be a power of two dividing it
     int k2 = 1;
