@@ -1087,6 +1087,10 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // A workgroup claims 512 items at a time; when an item is a pixel's whole sample sequence (serial-RNG scenes) that is
   // tens of milliseconds of its time, and the last claims decide when the launch ends: one 8x8 tile at a time there.
   W.pick_spins = 8;
+  W.idle_sleep = 1;
+  W.prio_mode = 0;
+  if (const char* e = getenv("PINE_GPU_IDLE_SLEEP")) W.idle_sleep = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char* e = getenv("PINE_GPU_PRIO")) W.prio_mode = atoi(e);
   if (const char* e = getenv("PINE_GPU_PICK_SPINS")) W.pick_spins = atoi(e) > 0 ? atoi(e) : 1;
   W.pool_items = in_path_rng ? 64 : 512;
   if (const char* e = getenv("PINE_GPU_POOL_ITEMS")) W.pool_items = atoi(e) > 0 ? atoi(e) : W.pool_items;
