@@ -1087,10 +1087,6 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // A workgroup claims 512 items at a time; when an item is a pixel's whole sample sequence (serial-RNG scenes) that is
   // tens of milliseconds of its time, and the last claims decide when the launch ends: one 8x8 tile at a time there.
   W.pick_spins = 8;
-  W.idle_sleep = 1;
-  W.prio_mode = 0;
-  if (const char* e = getenv("PINE_GPU_IDLE_SLEEP")) W.idle_sleep = atoi(e) > 0 ? atoi(e) : 1;
-  if (const char* e = getenv("PINE_GPU_PRIO")) W.prio_mode = atoi(e);
   if (const char* e = getenv("PINE_GPU_PICK_SPINS")) W.pick_spins = atoi(e) > 0 ? atoi(e) : 1;
   W.pool_items = in_path_rng ? 64 : 512;
   if (const char* e = getenv("PINE_GPU_POOL_ITEMS")) W.pool_items = atoi(e) > 0 ? atoi(e) : W.pool_items;
@@ -1122,6 +1118,15 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (queued) want = (W.total_items + qctx - 1) / qctx;
   p->grid = int(std::min<unsigned long long>(want, (unsigned long long)prop.multiProcessorCount * blocks_per_cu));
   if (p->grid < 1) p->grid = 1;
+  if (!in_path_rng && getenv("PINE_GPU_POOL_ITEMS") == nullptr) {
+    // work-item claims of the stage-queued kernel: 1/32 of a workgroup's share, between 512 and 2048 (a claim is a run of
+    // neighbouring tiles: larger ones keep a workgroup's camera rays together and are fewer -- 10 000 cones 8.00 -> 7.88 ms
+    // at 2048, 7.81 at 4096, 8.4 at 8192 where the last claims unbalance the end; cbox indifferent up to 2048)
+    unsigned long long share = W.total_items / ((unsigned long long)p->grid * 32ull);
+    int claim = 512;
+    while (claim < 2048 && (unsigned long long)claim * 2ull <= share) claim *= 2;
+    W.pool_items = claim;
+  }
 
   if (W.items_per_pixel > 1) HIP_OK(hipMalloc((void**)&p->d_ckpt, W.total_items * sizeof(ulonglong2)));
   HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));

@@ -182,7 +182,6 @@ struct WorkParams {
   int trav_min_lanes, trav_min_trips;  // traversal stages (pine_queue_kernel.h): retire / refill when fewer lanes than this still travel, at the earliest after this many trips
   int pick_spins;   // stage-queued kernel: idle polls after which a wave takes a queue's entries although they are fewer than 64
   int pool_items;   // stage-queued kernel: work items a workgroup claims from the global counter at a time
-  int idle_sleep, prio_mode;  // experiments
   int max_pixels;   // Subsurface variants: pixels a workgroup has in flight at most
   int fork_sealed;  // Subsurface variants: a path that can make no further RNG draw hands its pixel's next sample to another context
   unsigned long long* progress;  // host-mapped word (or null): work items claimed so far, stored now and then (get_progress)

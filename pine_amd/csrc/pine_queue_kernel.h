@@ -513,7 +513,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 16));
         break;
       }
-      for (int k = 0; k < W.idle_sleep; k++) __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(4);
       continue;
     }
     spins = 0;
@@ -540,10 +540,6 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     SEC_MARK(0);  // pick + pop
 
-    if (W.prio_mode) {  // experiment: the short stages that feed the queues ahead of the traversal stages
-      if (stage == QS_XS || stage == QS_XC) __builtin_amdgcn_s_setprio(0);
-      else __builtin_amdgcn_s_setprio(2);
-    }
     if (stage == QS_S) {
       // ================= shade a non-terminal vertex (path.cpp:91-120) =================
       bool to_shade = false, to_term = false, to_walk = false, to_xs = false, to_xc = false;
