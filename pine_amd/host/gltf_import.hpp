@@ -49,7 +49,11 @@ struct Json {
     return arr[i];
   }
   double number(double dflt) const { return kind == Number ? num : dflt; }
-  int integer(int dflt) const { return kind == Number ? int(num) : dflt; }
+  int integer(int dflt) const {
+    if (kind != Number) return dflt;
+    if (!(num >= -2147483648.0 && num <= 2147483647.0)) throw Error("glTF: integer out of range");
+    return int(num);
+  }
   size_t size() const { return kind == Array ? arr.size() : kind == Object ? obj.size() : 0; }
 };
 class JsonParser {
@@ -301,12 +305,23 @@ inline ImportedCamera import_scene(pine_gpu_scene* scene, const std::string& pat
     const std::string& type = acc.at("type").str;
     const size_t nc = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
     if (!nc) throw Error("glTF: unsupported accessor type");
-    const size_t start = size_t((view.find("byteOffset") ? view.at("byteOffset").number(0) : 0) + (acc.find("byteOffset") ? acc.at("byteOffset").number(0) : 0));
-    size_t stride = view.find("byteStride") ? size_t(view.at("byteStride").number(0)) : 0;
+    // (offsets, strides and counts are JSON numbers: range-checked as such BEFORE they become sizes -- a negative or
+    // huge one must not wrap the bounds check below)
+    auto as_size = [](const Json* j) -> size_t {
+      if (!j) return 0;
+      const double d = j->number(0);
+      if (!(d >= 0.0 && d <= 4294967295.0)) throw Error("glTF: offset / stride / count out of range");
+      return size_t(d);
+    };
+    const size_t view_offset = as_size(view.find("byteOffset")), acc_offset = as_size(acc.find("byteOffset"));
+    const size_t start = view_offset + acc_offset;
+    size_t stride = as_size(view.find("byteStride"));
     if (!stride) stride = cs * nc;
-    const std::vector<uint8_t>& raw = buffers.at(size_t(view.at("buffer").integer(0)));
-    const size_t count = size_t(acc.at("count").number(0));
-    if (count && start + (count - 1) * stride + cs * nc > raw.size()) throw Error("glTF: accessor runs past its buffer");
+    const int buffer_index = view.at("buffer").integer(-1);
+    if (buffer_index < 0 || size_t(buffer_index) >= buffers.size()) throw Error("glTF: bufferView names a buffer that does not exist");
+    const std::vector<uint8_t>& raw = buffers[size_t(buffer_index)];
+    const size_t count = as_size(&acc.at("count"));
+    if (start > raw.size() || (count && (count - 1) * stride + cs * nc > raw.size() - start)) throw Error("glTF: accessor runs past its buffer");
     return View{raw.data() + start, count, nc, stride, cs, ctype};
   };
   auto read_floats = [&](const View& v, size_t want_comp) {

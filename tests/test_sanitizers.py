@@ -1,8 +1,8 @@
 """CPU: the AddressSanitizer + UndefinedBehaviorSanitizer leg.  tools/sanitize builds the host code
 that handles caller-supplied data -- pine_amd/csrc/pine_host.cpp (scene building, BVH build, node folding, film
-finalize), pine_amd/host/prl.cpp (the parser / interpreter of untrusted script text) -- and the oracle with
--fsanitize=address,undefined, and runs CPU tests and a mutation fuzzer of the PRL front-end against those
-libraries.  A sanitizer report aborts the child process, so a zero exit status means there was none.
+finalize), pine_amd/host/prl.cpp (the parser / interpreter of untrusted script text) with pine_amd/host/gltf_import.hpp
+(the reader of untrusted binary glTF files) -- and the oracle with -fsanitize=address,undefined, and runs CPU tests, a
+mutation fuzzer of the PRL front-end and one of the glTF importer against those libraries.  A sanitizer report aborts the child process, so a zero exit status means there was none.
 (GPU AddressSanitizer is not available on this pool: the device entry points of the sanitizer build fail as on a
 host without a GPU, tools/sanitize/nogpu_entry_points.cpp.)"""
 import os
@@ -24,5 +24,5 @@ def test_host_code_is_clean_under_asan_and_ubsan():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
-    assert "0 crashes" in r.stdout and " passed" in r.stdout, tail
+    assert "0 crashes" in r.stdout and "no crash" in r.stdout and " passed" in r.stdout, tail
     assert "runtime error" not in tail and "AddressSanitizer" not in tail

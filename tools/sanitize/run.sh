@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/sanitize/run.sh [pytest args...]   (from the repo root; CPU only)
-# Builds the ASan + UBSan host libraries (tools/sanitize/Makefile) and runs the CPU test-suite and the PRL fuzzer
-# against them.  Any sanitizer report aborts the process (halt_on_error), so a green run means none.
+# Builds the ASan + UBSan host libraries (tools/sanitize/Makefile) and runs the CPU test-suite, the PRL fuzzer and the
+# glTF-importer fuzzer against them.  Any sanitizer report aborts the process (halt_on_error), so a green run means none.
 set -e
 cd "$(dirname "$0")/../.."
 make -s -C tools/sanitize -j3
@@ -12,3 +12,4 @@ export PINE_SANITIZER_RUN=1
 if [ $# -eq 0 ]; then set -- tests/test_abi.py tests/test_prl.py tests/test_oracle_golden.py -m "not gpu"; fi
 python -m pytest -x -q -p no:cacheprovider "$@"
 python tools/fuzz_prl.py ${PINE_FUZZ_MUTANTS:-300}
+python tools/fuzz_gltf.py ${PINE_FUZZ_MUTANTS:-300}
