@@ -636,6 +636,7 @@ static bool build_tri_packets(const FlatAccel& A, std::vector<uint32_t>& out, in
   verts = 0;
   out.clear();
   if (entries <= 0) return false;
+  if (size_t(entries) * 8 > 96 * 1024) return false;  // (the entries alone would not fit the LDS the variants leave: no point in building the table)
   struct Key {
     uint32_t a, b, c;
     bool operator<(const Key& o) const { return a != o.a ? a < o.a : b != o.b ? b < o.b : c < o.c; }
