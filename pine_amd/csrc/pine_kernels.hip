@@ -29,13 +29,14 @@
 #include <mutex>
 #include <string>
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 
 #include <dlfcn.h>
 
 #include "../../include/pine_gpu.h"
 #include "pine_device.h"
-#include "pine_fast.h"
+#include "pine_variants.h"
 #include "pine_host.h"
 
 struct pine_gpu_scene;
@@ -111,68 +112,33 @@ static int device_build(std::vector<BuildPrim>& prims, const std::vector<BuildTa
 }
 static const bool g_device_builder_installed = (g_device_builder = &device_build, true);
 
-// Compiled specialisations, most specific first.
-using PathKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, Counters*);
-struct KernelVariant {
-  unsigned features;
-  int waves_per_simd;
-  PathKernelFn fn;
-  const char* name;
+// Compiled specialisations (pine_variants.h): instantiated by the PART translation units (pine_kernels_part.hip, built in
+// parallel), merged here in `order`; the host takes the first one that covers a scene.
+struct VariantTables {
+  std::vector<PineKernelVariant> queue, mega;
+  VariantTables() {
+    using PartFn = const PineKernelVariant* (*)(int*, int*);
+    static const PartFn parts[kPineKernelParts] = {pine_gpu_kernel_part_0, pine_gpu_kernel_part_1, pine_gpu_kernel_part_2, pine_gpu_kernel_part_3,
+                                                   pine_gpu_kernel_part_4, pine_gpu_kernel_part_5, pine_gpu_kernel_part_6, pine_gpu_kernel_part_7};
+    for (PartFn f : parts) {
+      int nq = 0, nm = 0;
+      const PineKernelVariant* t = f(&nq, &nm);
+      queue.insert(queue.end(), t, t + nq);
+      mega.insert(mega.end(), t + nq, t + nq + nm);
+    }
+    auto by_order = [](const PineKernelVariant& a, const PineKernelVariant& b) { return a.order < b.order; };
+    std::sort(queue.begin(), queue.end(), by_order);
+    std::sort(mega.begin(), mega.end(), by_order);
+  }
 };
-constexpr unsigned kFBoxes = F_AABB | F_OBB;
-constexpr unsigned kFAnalytic = F_AABB | F_OBB | F_SPHERE | F_DISK | F_CONE | F_UBER;
-static const KernelVariant kVariants[] = {
-    {kFBoxes | F_LDS_SCENE, 4, path_trace_kernel<kFBoxes | F_LDS_SCENE, 4>, "rect+box/diffuse, scene in LDS"},
-#ifndef PINE_ONLY_CBOX_VARIANT  /* experiment builds compile just the first variant */
-    {kFAnalytic | F_LDS_SCENE, 2, path_trace_kernel<kFAnalytic | F_LDS_SCENE, 2>, "analytic shapes/uber, scene in LDS"},
-    {kFAnalytic, 2, path_trace_kernel<kFAnalytic, 2>, "analytic shapes/uber"},
-    {F_ALL | F_LDS_SCENE, 2, path_trace_kernel<F_ALL | F_LDS_SCENE, 2>, "all features, scene in LDS"},
-    {F_ALL, 2, path_trace_kernel<F_ALL, 2>, "all features"},
-#endif
-};
-constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
-
-// stage-queued kernel (pine_queue_kernel.h): same feature lattice
-using QueueKernelFn = void (*)(DeviceScene, WorkParams, const ulonglong2*, float4*, float*, uint32_t*, Counters*);
-struct QueueVariant {
-  unsigned features;
-  int ctx;             // path contexts per workgroup
-  size_t fixed_lds;    // LDS bytes before the traversal stack
-  size_t min_stack;    // least size of the stack region (it also holds the sampler window in the F_LDS_TOP variants)
-  QueueKernelFn fn;
-  const char* name;
-};
-#define PINE_QV(F, CTX, NAME) \
-  {F, CTX, QLayout<CTX, q_num_queues(F), ((F) & F_LDS_TOP) != 0>::fixed_bytes, QLayout<CTX, q_num_queues(F), ((F) & F_LDS_TOP) != 0>::min_stack_bytes, path_queue_kernel<F, CTX>, NAME}
-static const QueueVariant kQueueVariants[] = {
-    PINE_QV(F_OBB | F_LDS_SCENE, PINE_QCTX, "queue: rect+transformed box/diffuse, scene in LDS"),  // cbox exactly
-    PINE_QV(kFBoxes | F_LDS_SCENE, PINE_QCTX, "queue: rect+box/diffuse, scene in LDS"),
-#ifndef PINE_ONLY_CBOX_VARIANT
-    PINE_QV(kFAnalytic | F_LDS_SCENE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS"),
-    // scenes that do not fit LDS whole (F_LDS_TOP): 1024 contexts; the top of the BVH (breadth-first numbering) is cached
-    // in whatever LDS the contexts and the 16-bit traversal stack (2 KB per slot) leave; traversals are resumable and
-    // regrouped through the XS / XC queues (pine_trav.h)
-    // The mesh-capable feature sets twice: with traversal stages (F_XSTAGE: XS / XC queues, lanes refilled -- taken for scenes
-    // WITH meshes whose BVH (nearly) fits the LDS node cache: the rays of a two-level BVH need very different numbers of trips
-    // and refilling pays), and with the flat traversal inside stages S / T (two queue hops per vertex fewer --
-    // taken otherwise: analytic scenes, 20 % faster that way whether their nodes fit or not, and BVHs that stay in L2, where
-    // a wave runs its rays to the end anyway).  plan_build decides.
-#define PINE_QV2(F, NAME) PINE_QV((F) | F_LDS_TOP | F_XSTAGE, 1024, NAME ", traversal stages"), PINE_QV((F) | F_LDS_TOP, 1024, NAME)
-    PINE_QV(F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP, 1024, "queue: rect+sphere+disk+cone/uber, 1024 contexts, BVH top in LDS (classic.pine's kinds exactly)"),
-    PINE_QV(kFAnalytic | F_LDS_TOP, 1024, "queue: analytic shapes/uber, 1024 contexts, BVH top in LDS"),
-    // everything except Subsurface (meshes, node-graph materials, every light kind); F_LDS_REST: few geometries (big
-    // meshes or not): their shape / leaf / material / light records are staged in LDS too
-    PINE_QV2((F_ALL & ~F_SSS) | F_LDS_REST, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV2((F_ALL & ~F_SSS), "queue: all but SSS, 1024 contexts, BVH top in LDS"),
-    // Subsurface: the BSSRDF random walk is a third stage (W) with its own queue
-    PINE_QV2(F_MESH | F_SSS | F_LDS_REST, "queue: rect+mesh/diffuse+subsurface, walk stage, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV2(F_ALL | F_LDS_REST, "queue: all features, walk stage, 1024 contexts, BVH top + scene records in LDS"),
-    PINE_QV2(F_ALL, "queue: all features, walk stage, 1024 contexts, BVH top in LDS"),
-    // BVHs of 65 536 nodes and more: 32-bit traversal stack, no node cache
-    PINE_QV(F_ALL, 1024, "queue: all features, walk stage, 1024 contexts"),
-#endif
-};
-constexpr int kNumQueueVariants = int(sizeof(kQueueVariants) / sizeof(kQueueVariants[0]));
+static const VariantTables& variant_tables() {
+  static const VariantTables t;
+  return t;
+}
+#define kVariants (variant_tables().mega)
+#define kQueueVariants (variant_tables().queue)
+#define kNumVariants (int(variant_tables().mega.size()))
+#define kNumQueueVariants (int(variant_tables().queue.size()))
 
 // Ordered per-pixel sum: film[p] = (sum_{s=0..spp-1, in order} L_s) / spp  (path.cpp:34-38).
 // One wave per tile, lane = pixel in tile: every sample row is one coalesced 1 KiB read.
@@ -1192,11 +1158,15 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
     void* args[] = {&p->S, &p->W, &ckpt, &p->d_samples, &p->d_fold, &p->d_ctxg, &p->d_counters};
     HIP_OK(hipLaunchKernel(p->fast->fn, dim3(p->grid), dim3(kQBlock), args, p->lds_bytes, stream));
   } else if (p->queue_variant >= 0)
-    hipLaunchKernelGGL(kQueueVariants[p->queue_variant].fn, dim3(p->grid), dim3(kQBlock), p->lds_bytes, stream, p->S,
-                       p->W, (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_ctxg, p->d_counters);
-  else
-    hipLaunchKernelGGL(kVariants[p->variant].fn, dim3(p->grid), dim3(kBlock), p->lds_bytes, stream, p->S, p->W,
-                       (const ulonglong2*)p->d_ckpt, p->d_samples, p->d_fold, p->d_counters);
+  {
+    const ulonglong2* ckpt = p->d_ckpt;
+    void* args[] = {&p->S, &p->W, &ckpt, &p->d_samples, &p->d_fold, &p->d_ctxg, &p->d_counters};
+    HIP_OK(hipLaunchKernel(kQueueVariants[p->queue_variant].fn, dim3(p->grid), dim3(kQBlock), args, p->lds_bytes, stream));
+  } else {
+    const ulonglong2* ckpt = p->d_ckpt;
+    void* args[] = {&p->S, &p->W, &ckpt, &p->d_samples, &p->d_fold, &p->d_counters};
+    HIP_OK(hipLaunchKernel(kVariants[p->variant].fn, dim3(p->grid), dim3(kBlock), args, p->lds_bytes, stream));
+  }
   if (p->timed) HIP_OK(hipEventRecord(ev[2], stream));
   if (has_work) {
     const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;

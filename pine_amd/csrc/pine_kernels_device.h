@@ -19,6 +19,9 @@ constexpr int kTile = 8;         // 8x8 pixel tiles = 64 pixels = one wave's wor
 constexpr int kLdsFoldLevels = PINE_LDS_FOLD_LEVELS;  // fold-stack levels kept in LDS (deeper levels spill to global memory)
 constexpr int kPoolItems = 128;  // items a wave claims from the global queue per atomic
 constexpr int kMaxDepth = 32;    // max_path_length supported (2 beta bits per level in one u64)
+// feature sets that several compiled variants share (pine_variants.h)
+constexpr unsigned kFBoxes = F_AABB | F_OBB;
+constexpr unsigned kFAnalytic = F_AABB | F_OBB | F_SPHERE | F_DISK | F_CONE | F_UBER;
 
 // Diagnostic section timing: per-wave s_memtime deltas summed per section.  Never compiled into the
 // product build; the stamps only go to Counters::section_cycles, which nothing else reads.
@@ -404,7 +407,7 @@ __device__ __forceinline__ ItemInfo decode_item(const WorkParams& W, int film_w,
 // RNG state at the start of every item: the reference reseeds per pixel (sampler.h:286-290) and
 // then draws 4 floats per camera sample (path.cpp:35); when nothing inside radiance() touches the
 // RNG the state at sample s is the seed advanced 4*s steps.
-__global__ void __launch_bounds__(kBlock) rng_checkpoint_kernel(WorkParams W, int film_w, int film_h, int spp,
+static __global__ void __launch_bounds__(kBlock) rng_checkpoint_kernel(WorkParams W, int film_w, int film_h, int spp,
                                                                ulonglong2* ckpt) {
   // one thread per (local tile, pixel in tile); walks the whole pixel, storing at chunk starts
   const unsigned long long t = blockIdx.x * (unsigned long long)kBlock + threadIdx.x;

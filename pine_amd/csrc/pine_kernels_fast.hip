@@ -20,12 +20,11 @@
 #include "pine_kernels_device.h"
 #undef pine_gpu
 #undef pine_libm
-#include "pine_fast.h"
+#include "pine_variants.h"
 
 namespace pine_gpu_fast {
-constexpr unsigned kFAnalytic = F_AABB | F_OBB | F_SPHERE | F_DISK | F_CONE | F_UBER;
 #define PINE_FV(F, CTX, NAME)                                                                                        \
-  {F, CTX, QLayout<CTX, q_num_queues(F), ((F) & F_LDS_TOP) != 0>::fixed_bytes, QLayout<CTX, q_num_queues(F), ((F) & F_LDS_TOP) != 0>::min_stack_bytes, \
+  {F, CTX, 0, kQBlock / 256, QLayout<CTX, q_num_queues(F), ((F) & F_LDS_TOP) != 0>::fixed_bytes, QLayout<CTX, q_num_queues(F), ((F) & F_LDS_TOP) != 0>::min_stack_bytes, \
    (const void*)path_queue_kernel<F, CTX>, NAME}
 static const PineFastVariant kFast[] = {
     PINE_FV(F_OBB | F_LDS_SCENE, PINE_QCTX, "fast queue: rect+transformed box/diffuse, scene in LDS"),

@@ -187,7 +187,10 @@ PINE_HD void sincosf_glibc(float y, float& sn, float& cs) {
 // sinf/cosf, every a*b+c is a fused multiply-add because x86-64 glibc runs its -mfma build.
 // tools/check_libm.cpp: 0 mismatches against the container's libm over every float x in [0, 1] with
 // y = 5 (Schlick), 2^31 positive floats for logf and 10^9 random (x, y) pairs.
-// The tables are switch statements (immediates), not arrays: no memory traffic, no static data on the device.
+// The tables are constant arrays read with one (lane-indexed) load per lookup.  They were switch statements of immediates
+// until round 3: the compiler hoisted every 64-bit immediate of the select chains out of the kernel's persistent loop --
+// a hundred VGPRs of loop-invariant constants, ALL of the stage-queued kernel's register spills (98 of 108 spilled VGPRs
+// in the 10 000-cone variant, 64 scratch reloads per powf call).
 PINE_HD uint64_t asuint64(double d) {
   uint64_t u;
   memcpy(&u, &d, 8);
@@ -199,80 +202,61 @@ PINE_HD double asdouble(uint64_t u) {
   return d;
 }
 PINE_HD uint64_t exp2f_tab(unsigned i) {
-  switch (i) {
-    case 0: return 0x3ff0000000000000ull;
-    case 1: return 0x3fefd9b0d3158574ull;
-    case 2: return 0x3fefb5586cf9890full;
-    case 3: return 0x3fef9301d0125b51ull;
-    case 4: return 0x3fef72b83c7d517bull;
-    case 5: return 0x3fef54873168b9aaull;
-    case 6: return 0x3fef387a6e756238ull;
-    case 7: return 0x3fef1e9df51fdee1ull;
-    case 8: return 0x3fef06fe0a31b715ull;
-    case 9: return 0x3feef1a7373aa9cbull;
-    case 10: return 0x3feedea64c123422ull;
-    case 11: return 0x3feece086061892dull;
-    case 12: return 0x3feebfdad5362a27ull;
-    case 13: return 0x3feeb42b569d4f82ull;
-    case 14: return 0x3feeab07dd485429ull;
-    case 15: return 0x3feea47eb03a5585ull;
-    case 16: return 0x3feea09e667f3bcdull;
-    case 17: return 0x3fee9f75e8ec5f74ull;
-    case 18: return 0x3feea11473eb0187ull;
-    case 19: return 0x3feea589994cce13ull;
-    case 20: return 0x3feeace5422aa0dbull;
-    case 21: return 0x3feeb737b0cdc5e5ull;
-    case 22: return 0x3feec49182a3f090ull;
-    case 23: return 0x3feed503b23e255dull;
-    case 24: return 0x3feee89f995ad3adull;
-    case 25: return 0x3feeff76f2fb5e47ull;
-    case 26: return 0x3fef199bdd85529cull;
-    case 27: return 0x3fef3720dcef9069ull;
-    case 28: return 0x3fef5818dcfba487ull;
-    case 29: return 0x3fef7c97337b9b5full;
-    case 30: return 0x3fefa4afa2a490daull;
-    default: return 0x3fefd0765b6e4540ull;
-  }
+  static constexpr uint64_t T[32] = {
+      0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+      0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+      0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+      0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+      0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+      0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+      0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+      0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+  };
+  return T[i & 31u];
 }
 PINE_HD void powf_log2_tab(unsigned i, double& invc, double& logc) {
-  switch (i) {
-    case 0: invc = 0x1.661ec79f8f3bep+0; logc = -0x1.efec65b963019p-2; break;
-    case 1: invc = 0x1.571ed4aaf883dp+0; logc = -0x1.b0b6832d4fca4p-2; break;
-    case 2: invc = 0x1.49539f0f010b0p+0; logc = -0x1.7418b0a1fb77bp-2; break;
-    case 3: invc = 0x1.3c995b0b80385p+0; logc = -0x1.39de91a6dcf7bp-2; break;
-    case 4: invc = 0x1.30d190c8864a5p+0; logc = -0x1.01d9bf3f2b631p-2; break;
-    case 5: invc = 0x1.25e227b0b8ea0p+0; logc = -0x1.97c1d1b3b7af0p-3; break;
-    case 6: invc = 0x1.1bb4a4a1a343fp+0; logc = -0x1.2f9e393af3c9fp-3; break;
-    case 7: invc = 0x1.12358f08ae5bap+0; logc = -0x1.960cbbf788d5cp-4; break;
-    case 8: invc = 0x1.0953f419900a7p+0; logc = -0x1.a6f9db6475fcep-5; break;
-    case 9: invc = 0x1.0000000000000p+0; logc = 0x0p+0; break;
-    case 10: invc = 0x1.e608cfd9a47acp-1; logc = 0x1.338ca9f24f53dp-4; break;
-    case 11: invc = 0x1.ca4b31f026aa0p-1; logc = 0x1.476a9543891bap-3; break;
-    case 12: invc = 0x1.b2036576afce6p-1; logc = 0x1.e840b4ac4e4d2p-3; break;
-    case 13: invc = 0x1.9c2d163a1aa2dp-1; logc = 0x1.40645f0c6651cp-2; break;
-    case 14: invc = 0x1.886e6037841edp-1; logc = 0x1.88e9c2c1b9ff8p-2; break;
-    default: invc = 0x1.767dcf5534862p-1; logc = 0x1.ce0a44eb17bccp-2; break;
-  }
+  static constexpr double T[16][2] = {
+      {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2},
+      {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+      {0x1.49539f0f010b0p+0, -0x1.7418b0a1fb77bp-2},
+      {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+      {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2},
+      {0x1.25e227b0b8ea0p+0, -0x1.97c1d1b3b7af0p-3},
+      {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3},
+      {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+      {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5},
+      {0x1.0000000000000p+0, 0x0p+0},
+      {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},
+      {0x1.ca4b31f026aa0p-1, 0x1.476a9543891bap-3},
+      {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},
+      {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+      {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},
+      {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+  };
+  invc = T[i & 15u][0];
+  logc = T[i & 15u][1];
 }
 PINE_HD void logf_tab(unsigned i, double& invc, double& logc) {
-  switch (i) {
-    case 0: invc = 0x1.661ec79f8f3bep+0; logc = -0x1.57bf7808caadep-2; break;
-    case 1: invc = 0x1.571ed4aaf883dp+0; logc = -0x1.2bef0a7c06ddbp-2; break;
-    case 2: invc = 0x1.49539f0f010b0p+0; logc = -0x1.01eae7f513a67p-2; break;
-    case 3: invc = 0x1.3c995b0b80385p+0; logc = -0x1.b31d8a68224e9p-3; break;
-    case 4: invc = 0x1.30d190c8864a5p+0; logc = -0x1.6574f0ac07758p-3; break;
-    case 5: invc = 0x1.25e227b0b8ea0p+0; logc = -0x1.1aa2bc79c8100p-3; break;
-    case 6: invc = 0x1.1bb4a4a1a343fp+0; logc = -0x1.a4e76ce8c0e5ep-4; break;
-    case 7: invc = 0x1.12358f08ae5bap+0; logc = -0x1.1973c5a611cccp-4; break;
-    case 8: invc = 0x1.0953f419900a7p+0; logc = -0x1.252f438e10c1ep-5; break;
-    case 9: invc = 0x1.0000000000000p+0; logc = 0x0p+0; break;
-    case 10: invc = 0x1.e608cfd9a47acp-1; logc = 0x1.aa5aa5df25984p-5; break;
-    case 11: invc = 0x1.ca4b31f026aa0p-1; logc = 0x1.c5e53aa362eb4p-4; break;
-    case 12: invc = 0x1.b2036576afce6p-1; logc = 0x1.526e57720db08p-3; break;
-    case 13: invc = 0x1.9c2d163a1aa2dp-1; logc = 0x1.bc2860d224770p-3; break;
-    case 14: invc = 0x1.886e6037841edp-1; logc = 0x1.1058bc8a07ee1p-2; break;
-    default: invc = 0x1.767dcf5534862p-1; logc = 0x1.4043057b6ee09p-2; break;
-  }
+  static constexpr double T[16][2] = {
+      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2},
+      {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+      {0x1.49539f0f010b0p+0, -0x1.01eae7f513a67p-2},
+      {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+      {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3},
+      {0x1.25e227b0b8ea0p+0, -0x1.1aa2bc79c8100p-3},
+      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4},
+      {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+      {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
+      {0x1.0000000000000p+0, 0x0p+0},
+      {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},
+      {0x1.ca4b31f026aa0p-1, 0x1.c5e53aa362eb4p-4},
+      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},
+      {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d224770p-3},
+      {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
+      {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2},
+  };
+  invc = T[i & 15u][0];
+  logc = T[i & 15u][1];
 }
 PINE_HD double powf_log2_inline(uint32_t ix) {  // e_powf.c log2_inline; |relative error| < 2^-68
   const uint32_t tmp = ix - 0x3f330000u;
