@@ -298,7 +298,9 @@ typedef struct {
   float accel_build_ms;      /* host: BVH build + flattening for this plan (0 if the scene's accel was already built) */
   float upload_ms;           /* host: device allocation + upload of scene, tables and work buffers at plan creation  */
   int32_t accel_built_on_device; /* 1: that build ran on the GPU (PINE_GPU_FLAG_DEVICE_BVH)                            */
-  int32_t reserved;
+  int32_t serial_tiles;      /* tile classes (Subsurface scenes): 8x8 tiles of this shard whose pixels are one whole-pixel item each
+                              * because a camera ray of theirs can reach a Subsurface shape; the others' samples are independent
+                              * items of samples_per_item samples.  0: one class (samples_per_item describes every item) */
 } pine_gpu_plan_stats;
 /* The scene's BVH built on HIP device `device` right now (the accel is then reused by every later plan); returns the node
  * count, < 0 on failure.  pine_gpu_scene_accel_dump shows the result: identical to the host build's. */

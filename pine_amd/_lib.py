@@ -53,7 +53,7 @@ class PlanStats(C.Structure):
         ("accel_build_ms", C.c_float),
         ("upload_ms", C.c_float),
         ("accel_built_on_device", C.c_int32),
-        ("reserved", C.c_int32),
+        ("serial_tiles", C.c_int32),
     ]
 
 

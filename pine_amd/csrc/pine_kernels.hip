@@ -22,6 +22,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(WorkParams W, int film_
   const int ltile = int(t >> 6);
   if (ltile >= W.num_local_tiles) return;
   const int p = int(t & 63);
-  const int tile = ltile * W.shard_world + W.shard_rank;
+  const int tile = film_tile_of(W, ltile);
   const int px = (tile % W.tiles_x) * kTile + (p & 7), py = (tile / W.tiles_x) * kTile + (p >> 3);
   if (px >= film_w || py >= film_h) return;
   const float4* row = samples + (unsigned long long)ltile * (unsigned)spp * 64ull + p;
@@ -175,7 +176,8 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(WorkParams W, int film_
     verts += (unsigned long long)v.w;
   }
   const f3 m = L / float(spp);
-  const size_t out_index = packed ? size_t(ltile) * 64u + size_t(p) : size_t(py) * film_w + px;
+  // (the slab is tile-major in the shard's NATURAL tile order, whatever order the launch works in: tile_order)
+  const size_t out_index = packed ? size_t(tile / W.shard_world) * 64u + size_t(p) : size_t(py) * film_w + px;
   film[out_index] = make_float4(m.x, m.y, m.z, 1.0f);
   // radiance() invocation count of the launch (the unit of the roofline's algorithmic bytes)
   for (int off = 32; off > 0; off >>= 1) verts += __shfl_down(verts, off);
@@ -463,6 +465,8 @@ struct pine_gpu_plan {
   const PineFastVariant* fast = nullptr;  // PINE_GPU_FLAG_FAST: the declared-tolerance variant that runs instead (pine_kernels_fast.hip)
   uint32_t* d_ctxg = nullptr;
   ulonglong2* d_ckpt = nullptr;
+  int* d_tile_order = nullptr;          // tile classes (WorkParams::tile_order), or null
+  std::vector<int> tile_order;          // ... its host copy (empty: local tile t is film tile t * shard_world + shard_rank)
   float4* d_samples = nullptr;
   float* d_fold = nullptr;
   Counters* d_counters = nullptr;
@@ -545,6 +549,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_tables);
   (void)hipFree(p->d_ctxg);
   (void)hipFree(p->d_ckpt);
+  (void)hipFree(p->d_tile_order);
   (void)hipFree(p->d_samples);
   (void)hipFree(p->d_fold);
   (void)hipFree(p->d_counters);
@@ -880,11 +885,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     p->variant = v;
     break;
   }
-  if (p->variant < 0) {
-    set_error("no kernel variant covers this scene");
-    return -1;
-  }
-  if (kVariants[p->variant].features & F_LDS_SCENE) p->lds_bytes += size_t(S.blob_bytes);
+  if (p->variant >= 0 && (kVariants[p->variant].features & F_LDS_SCENE)) p->lds_bytes += size_t(S.blob_bytes);
   // The stage-queued kernel is the default whenever a variant covers the scene and its LDS fits;
   // PINE_GPU_KERNEL=mega forces the lane-owns-a-path kernel, which covers every scene.
   // LDS left after a variant's fixed parts goes to the BVH node cache first, then -- when ALL nodes are in and there is
@@ -940,6 +941,10 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     }
   }
 
+  if (p->variant < 0 && p->queue_variant < 0) {  // (only experiment builds lack the all-features megakernel)
+    set_error("no kernel variant covers this scene");
+    return -1;
+  }
   if (prm->flags & PINE_GPU_FLAG_FAST) {
     // declared-tolerance arithmetic: one of the few variants pine_kernels_fast.hip compiles, chosen by the same rules
     int nf = 0;
@@ -1018,6 +1023,83 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   while ((1 << W.log2_items_per_pixel) < W.items_per_pixel) W.log2_items_per_pixel++;
   W.tiles_x_magic = unsigned(((1ull << 32) + unsigned(W.tiles_x) - 1) / unsigned(W.tiles_x));  // tiles_x >= 1
   W.total_items = (unsigned long long)W.num_local_tiles * W.items_per_pixel * 64ull;
+  W.tile_order = nullptr;
+  W.serial_tiles = 0;
+  {
+    // Tile classes (WorkParams::serial_tiles): in a scene whose only in-path RNG consumer is the BSSRDF channel pick and
+    // whose other materials are Diffuse / Emissive, a path draws from the pixel's RNG only while it has met nothing but
+    // Subsurface surfaces -- so a pixel none of whose camera rays can reach a Subsurface shape makes NO in-path draw, its
+    // samples are independent (RNG state of sample s = the seed advanced 4 s steps, as in a scene without in-path draws)
+    // and need not form a chain.  Conservative test per 8x8 tile: the world boxes of the Subsurface shapes projected
+    // through the pinhole camera, two pixels of margin.  Everything else (thin lens, a box behind the camera, other
+    // materials, the megakernel) keeps one whole-pixel item per pixel.  PINE_GPU_NO_TILE_CLASSES: off (measurement aid).
+    const unsigned qf = p->queue_variant >= 0 ? kQueueVariants[p->queue_variant].features : p->fast ? p->fast->features : 0u;
+    bool ok = in_path_rng && !uber_rng && (qf & F_SSS) != 0 && H.camera.len_radius == 0.0f && getenv("PINE_GPU_NO_TILE_CLASSES") == nullptr &&
+              getenv("PINE_GPU_NO_FORK") == nullptr && spp > 1;
+    for (auto& m : dev_materials)
+      if (m.kind != MAT_EMISSIVE && m.kind != MAT_DIFFUSE && m.kind != MAT_SUBSURFACE) ok = false;
+    if (ok) {
+      // inverse of the camera's linear part (columns x, y, z of c2w), in double
+      const float* c = H.camera.c2w;
+      const double a[3][3] = {{c[0], c[3], c[6]}, {c[1], c[4], c[7]}, {c[2], c[5], c[8]}};  // a[row][col]
+      const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                         a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+      if (!(std::fabs(det) > 1e-12) || !(H.camera.fov2d[0] > 0) || !(H.camera.fov2d[1] > 0)) ok = false;
+      double inv[3][3];
+      if (ok) {
+        inv[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) / det, inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det, inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
+        inv[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) / det, inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det, inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+        inv[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) / det, inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det, inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+      }
+      // pixel rectangles [x0, x1] x [y0, y1] that the Subsurface shapes can project into
+      struct Rect2 { double x0, y0, x1, y1; };
+      std::vector<Rect2> rects;
+      for (size_t g = 0; ok && g < shapes.size(); g++) {
+        if (dev_materials[size_t(shapes[g].material)].kind != MAT_SUBSURFACE) continue;
+        const HostAABB b = H.geometry_aabb(int(g));
+        Rect2 r{1e300, 1e300, -1e300, -1e300};
+        for (int corner = 0; corner < 8 && ok; corner++) {
+          const double P[3] = {double((corner & 1) ? b.upper.x : b.lower.x) - H.camera.position[0], double((corner & 2) ? b.upper.y : b.lower.y) - H.camera.position[1],
+                               double((corner & 4) ? b.upper.z : b.lower.z) - H.camera.position[2]};
+          if (!(std::isfinite(P[0]) && std::isfinite(P[1]) && std::isfinite(P[2]))) { ok = false; break; }
+          const double qx = inv[0][0] * P[0] + inv[0][1] * P[1] + inv[0][2] * P[2], qy = inv[1][0] * P[0] + inv[1][1] * P[1] + inv[1][2] * P[2],
+                       qz = inv[2][0] * P[0] + inv[2][1] * P[1] + inv[2][2] * P[2];
+          if (!(qz > 1e-4)) { ok = false; break; }  // a corner at or behind the camera plane: no bounded projection
+          const double fx = ((qx / qz) / H.camera.fov2d[0] * 0.5 + 0.5) * H.camera.W, fy = ((qy / qz) / H.camera.fov2d[1] * 0.5 + 0.5) * H.camera.H;
+          r.x0 = std::min(r.x0, fx), r.y0 = std::min(r.y0, fy), r.x1 = std::max(r.x1, fx), r.y1 = std::max(r.y1, fy);
+        }
+        // margin: the pixel's own extent (jitter in [0, 1)) + two pixels for every rounding on the way
+        r.x0 -= 3.0, r.y0 -= 3.0, r.x1 += 2.0, r.y1 += 2.0;
+        rects.push_back(r);
+      }
+      if (ok) {
+        std::vector<int> serial, free_tiles;
+        for (int lt = 0; lt < W.num_local_tiles; lt++) {
+          const int tile = lt * W.shard_world + W.shard_rank;
+          const int tx = tile % W.tiles_x, ty = tile / W.tiles_x;
+          const double x0 = tx * kTile, y0 = ty * kTile, x1 = x0 + kTile, y1 = y0 + kTile;
+          bool touched = false;
+          for (const Rect2& r : rects)
+            if (x0 <= r.x1 && x1 >= r.x0 && y0 <= r.y1 && y1 >= r.y0) touched = true;
+          (touched ? serial : free_tiles).push_back(tile);
+        }
+        if (!free_tiles.empty() && !serial.empty()) {
+          p->tile_order = serial;
+          p->tile_order.insert(p->tile_order.end(), free_tiles.begin(), free_tiles.end());
+          W.serial_tiles = int(serial.size());
+          // the independent class: one sample per item, RNG checkpoints (the Subsurface variants are F_LDS_TOP ones)
+          W.samples_per_item = 1;
+          W.items_per_pixel = spp;
+          W.log2_items_per_pixel = 0;
+          while ((1 << W.log2_items_per_pixel) < W.items_per_pixel) W.log2_items_per_pixel++;
+          W.total_items = (unsigned long long)W.serial_tiles * 64ull + (unsigned long long)(W.num_local_tiles - W.serial_tiles) * W.items_per_pixel * 64ull;
+        } else if (serial.empty()) {
+          // no camera ray can reach a Subsurface shape from this shard's tiles: nothing to do here, the scene stays
+          // "one item per pixel" (rare, and a launch without chains would need the checkpoint prepass for every tile)
+        }
+      }
+    }
+  }
   // packing limits of the kernels: pixel coordinates travel as 16 + 16 bits, the sample-buffer index of a
   // context as 32 bits
   if (p->film_w > 65535 || p->film_h > 65535) {
@@ -1054,9 +1136,12 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // A workgroup claims 512 items at a time; when an item is a pixel's whole sample sequence (serial-RNG scenes) that is
   // tens of milliseconds of its time, and the last claims decide when the launch ends: one 8x8 tile at a time there.
   W.pick_spins = 8;
+  W.fair_period = 8;
+  if (const char* e = getenv("PINE_GPU_FAIR_PERIOD")) W.fair_period = atoi(e);
   if (const char* e = getenv("PINE_GPU_PICK_SPINS")) W.pick_spins = atoi(e) > 0 ? atoi(e) : 1;
   W.pool_items = in_path_rng ? 64 : 512;
   if (const char* e = getenv("PINE_GPU_POOL_ITEMS")) W.pool_items = atoi(e) > 0 ? atoi(e) : W.pool_items;
+  if (W.serial_tiles > 0) W.pool_items = 64;  // tile classes: a claim never straddles the boundary between the classes (a multiple of 64)
   W.progress = nullptr;
   if (prm->flags & PINE_GPU_FLAG_PROGRESS) {
     HIP_OK(hipHostMalloc((void**)&p->h_progress, sizeof(unsigned long long), hipHostMallocMapped));
@@ -1095,7 +1180,13 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     W.pool_items = claim;
   }
 
-  if (W.items_per_pixel > 1) HIP_OK(hipMalloc((void**)&p->d_ckpt, W.total_items * sizeof(ulonglong2)));
+  if (W.items_per_pixel > 1)
+    HIP_OK(hipMalloc((void**)&p->d_ckpt, (size_t)(W.num_local_tiles - W.serial_tiles) * W.items_per_pixel * 64 * sizeof(ulonglong2)));
+  if (!p->tile_order.empty()) {
+    HIP_OK(hipMalloc((void**)&p->d_tile_order, p->tile_order.size() * sizeof(int)));
+    HIP_OK(hipMemcpy(p->d_tile_order, p->tile_order.data(), p->tile_order.size() * sizeof(int), hipMemcpyHostToDevice));
+    W.tile_order = p->d_tile_order;
+  }
   HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
   const size_t fold_slots = queued ? size_t(p->grid) * qctx : size_t(p->grid) * kBlock;
   HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * fold_slots * sizeof(float)));
@@ -1146,7 +1237,7 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
   // (a shard can own no tile at all -- more ranks than 8x8 tiles: nothing to launch, the film / slab stays zero)
   const bool has_work = p->W.num_local_tiles > 0;
   if (has_work && p->W.items_per_pixel > 1) {
-    const unsigned long long n = (unsigned long long)p->W.num_local_tiles * 64ull;
+    const unsigned long long n = (unsigned long long)(p->W.num_local_tiles - p->W.serial_tiles) * 64ull;
     hipLaunchKernelGGL(rng_checkpoint_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                        p->W, p->film_w, p->film_h, p->S.spp, p->d_ckpt);
   }
@@ -1230,7 +1321,7 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   {
     unsigned long long px = 0;
     for (int lt = 0; lt < p->W.num_local_tiles; lt++) {
-      int tile = lt * p->W.shard_world + p->W.shard_rank;
+      int tile = p->tile_order.empty() ? lt * p->W.shard_world + p->W.shard_rank : p->tile_order[size_t(lt)];
       int tx = tile % p->W.tiles_x, ty = tile / p->W.tiles_x;
       int w = std::min(kTile, p->film_w - tx * kTile), h = std::min(kTile, p->film_h - ty * kTile);
       px += (unsigned long long)w * h;
@@ -1239,6 +1330,7 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   }
   out->spp_effective = p->S.spp;
   out->samples_per_item = p->W.samples_per_item;
+  out->serial_tiles = p->W.serial_tiles;
   out->grid_blocks = p->grid;
   out->block_threads = (p->queue_variant >= 0 || p->fast) ? kQBlock : kBlock;
   out->lds_bytes = int(p->lds_bytes);
@@ -1292,9 +1384,22 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
   if (c.t_end > c.t_start && c.t_start)
     fprintf(stderr, "timeline: kernel %.2f ms, work-item pool dry after %.2f ms\n", double(c.t_end - c.t_start) * 1e-5,
             c.t_pool_dry ? double(c.t_pool_dry - c.t_start) * 1e-5 : -1.0);
-  unsigned long long rl[16], rh[16];
-  HIP_OK(hipMemcpyFromSymbol(rl, HIP_SYMBOL(g_region_lanes), sizeof rl));
-  HIP_OK(hipMemcpyFromSymbol(rh, HIP_SYMBOL(g_region_hits), sizeof rh));
+  if (getenv("PINE_GPU_WG_TIMELINE") && c.t_start) {
+    // per workgroup, ms after the launch's start: last whole-pixel item sealed | pool found dry | out | whole-pixel items it claimed
+    for (int b = 0; b < p->grid && b < 1024; b++)
+      fprintf(stderr, "wg %3d: whole-pixel items done %7.2f  pool dry %7.2f  out %7.2f  pixels %llu\n", b,
+              c.wg_t[b][0] ? double(c.wg_t[b][0] - c.t_start) * 1e-5 : -1.0, c.wg_t[b][1] ? double(c.wg_t[b][1] - c.t_start) * 1e-5 : -1.0,
+              c.wg_t[b][2] ? double(c.wg_t[b][2] - c.t_start) * 1e-5 : -1.0, c.wg_t[b][3]);
+  }
+  unsigned long long rl[16] = {0}, rh[16] = {0};
+  {
+    using RegFn = int (*)(unsigned long long*, unsigned long long*);
+    static const RegFn regs[kPineKernelParts] = {pine_gpu_kernel_part_regions_0, pine_gpu_kernel_part_regions_1, pine_gpu_kernel_part_regions_2,
+                                                 pine_gpu_kernel_part_regions_3, pine_gpu_kernel_part_regions_4, pine_gpu_kernel_part_regions_5,
+                                                 pine_gpu_kernel_part_regions_6, pine_gpu_kernel_part_regions_7};
+    for (RegFn f : regs)
+      if (f(rl, rh)) return -1;
+  }
   for (int i = 0; i < 16; i++)
     if (rh[i]) fprintf(stderr, "region %2d: entries %llu avg active lanes %.2f\n", i, rh[i], double(rl[i]) / double(rh[i]));
 #endif
@@ -1318,7 +1423,7 @@ int pine_gpu_plan_read_samples(pine_gpu_plan* p, float* out, int64_t capacity) {
   HIP_OK(hipMemcpy(tmp.data(), p->d_samples, tmp.size() * 4, hipMemcpyDeviceToHost));
   memset(out, 0, size_t(need) * 4);
   for (int lt = 0; lt < p->W.num_local_tiles; lt++) {
-    int tile = lt * p->W.shard_world + p->W.shard_rank;
+    int tile = p->tile_order.empty() ? lt * p->W.shard_world + p->W.shard_rank : p->tile_order[size_t(lt)];
     int tx = tile % p->W.tiles_x, ty = tile / p->W.tiles_x;
     for (int q = 0; q < 64; q++) {
       int px = tx * kTile + (q & 7), py = ty * kTile + (q >> 3);

@@ -26,7 +26,7 @@ constexpr unsigned kFAnalytic = F_AABB | F_OBB | F_SPHERE | F_DISK | F_CONE | F_
 // Diagnostic section timing: per-wave s_memtime deltas summed per section.  Never compiled into the
 // product build; the stamps only go to Counters::section_cycles, which nothing else reads.
 #ifdef PINE_PROFILE_SECTIONS
-__device__ unsigned long long g_region_lanes[16], g_region_hits[16];
+static __device__ unsigned long long g_region_lanes[16], g_region_hits[16];  // (one copy per translation unit: pine_kernels_part.hip reads its own)
 // REGION(id): average number of active lanes at a code region's entry (divergence probe;
 // -DPINE_PROFILE_REGIONS on top, as its global atomics distort the section times)
 #ifndef PINE_PROFILE_REGIONS
@@ -179,10 +179,19 @@ struct WorkParams {
   int items_per_pixel;   // spp / k (a power of two)
   int log2_items_per_pixel;
   unsigned tiles_x_magic;  // ceil(2^32 / tiles_x): see decode_item
-  unsigned long long total_items;  // num_local_tiles * items_per_pixel * 64
+  unsigned long long total_items;  // num_local_tiles * items_per_pixel * 64 (tile classes: see serial_tiles)
+  // Tile classes (Subsurface variants of the stage-queued kernel, plan_build): a scene whose materials draw from the
+  // pixel's RNG inside radiance() makes a pixel's samples sequentially dependent (one item = the whole pixel) -- but only
+  // in pixels whose camera rays can reach such a material.  The host lists the shard's tiles in `tile_order`, those
+  // that can first (`serial_tiles` of them, items [0, serial_tiles * 64): one per pixel, all spp samples); the others
+  // follow as independent items of samples_per_item samples with RNG checkpoints, like a scene without in-path draws.
+  // serial_tiles == 0: one class, as described by samples_per_item / items_per_pixel.
+  const int* tile_order;  // local tile -> tile of the film, or null (local tile * shard_world + shard_rank)
+  int serial_tiles;
   unsigned long long idle_budget_ticks;  // stage-queued kernel: a wave that finds no work for this long (100 MHz wall clock) bails out
   int debug_force_bail;  // test hook (PINE_GPU_FLAG_DEBUG_FORCE_BAIL): the first wave bails out at once
   int trav_min_lanes, trav_min_trips;  // traversal stages (pine_queue_kernel.h): retire / refill when fewer lanes than this still travel, at the earliest after this many trips
+  int fair_period;  // stage-queued kernel, variants with more than two stage queues: every this-many-th pick of a wave serves the shortest non-empty queue (0: never)
   int pick_spins;   // stage-queued kernel: idle polls after which a wave takes a queue's entries although they are fewer than 64
   int pool_items;   // stage-queued kernel: work items a workgroup claims from the global counter at a time
   int max_pixels;   // Subsurface variants: pixels a workgroup has in flight at most
@@ -379,17 +388,26 @@ struct ItemInfo {
   int px, py;
   int chunk;
   unsigned long long sample_base;  // index of sample 0 of this pixel row in the samples buffer / 64-strided
+  unsigned long long ckpt_index;   // the item's RNG checkpoint (items of the independent class)
+  bool serial;                     // an item of the whole-pixel class of a launch with tile classes
   bool valid;
 };
+__device__ __forceinline__ int film_tile_of(const WorkParams& W, int ltile) {
+  return W.tile_order ? W.tile_order[ltile] : ltile * W.shard_world + W.shard_rank;
+}
 __device__ __forceinline__ ItemInfo decode_item(const WorkParams& W, int film_w, int film_h, int spp,
                                                 unsigned long long item) {
   ItemInfo it;
-  const int p = int(item & 63);
-  const unsigned long long tc = item >> 6;
+  const unsigned long long serial_items = (unsigned long long)W.serial_tiles * 64ull;
+  it.serial = item < serial_items;
+  const unsigned long long rel = it.serial ? item : item - serial_items;
+  const int p = int(rel & 63);
+  const unsigned long long tc = rel >> 6;
   // spp and k are powers of two: shifts instead of 64-bit divisions (this runs once per camera sample)
-  const int chunk = int(tc & (unsigned long long)(W.items_per_pixel - 1));
-  const int ltile = int(tc >> W.log2_items_per_pixel);
-  const int tile = ltile * W.shard_world + W.shard_rank;
+  const int chunk = it.serial ? 0 : int(tc & (unsigned long long)(W.items_per_pixel - 1));
+  const int ltile = it.serial ? int(tc) : W.serial_tiles + int(tc >> W.log2_items_per_pixel);
+  const int tile = film_tile_of(W, ltile);
+  it.ckpt_index = rel;
   // tile / tiles_x by multiplication with the rounded-up reciprocal + one fix-up step (exact for any
   // 32-bit tile: the estimate is never more than one too large)
   unsigned ty = unsigned((uint64_t(unsigned(tile)) * W.tiles_x_magic) >> 32);
@@ -409,17 +427,17 @@ __device__ __forceinline__ ItemInfo decode_item(const WorkParams& W, int film_w,
 // RNG the state at sample s is the seed advanced 4*s steps.
 static __global__ void __launch_bounds__(kBlock) rng_checkpoint_kernel(WorkParams W, int film_w, int film_h, int spp,
                                                                ulonglong2* ckpt) {
-  // one thread per (local tile, pixel in tile); walks the whole pixel, storing at chunk starts
+  // one thread per (local tile of the independent class, pixel in tile); walks the whole pixel, storing at chunk starts
   const unsigned long long t = blockIdx.x * (unsigned long long)kBlock + threadIdx.x;
-  const unsigned long long n = (unsigned long long)W.num_local_tiles * 64ull;
+  const unsigned long long n = (unsigned long long)(W.num_local_tiles - W.serial_tiles) * 64ull;
   if (t >= n) return;
   const int p = int(t & 63);
-  const int ltile = int(t >> 6);
-  const int tile = ltile * W.shard_world + W.shard_rank;
+  const int ptile = int(t >> 6);  // (position among the independent tiles: ItemInfo::ckpt_index counts from there)
+  const int tile = film_tile_of(W, W.serial_tiles + ptile);
   const int px = (tile % W.tiles_x) * kTile + (p & 7), py = (tile / W.tiles_x) * kTile + (p >> 3);
   DRng g = rng_seed(hash_pixel(px, py, 0));
   for (int c = 0; c < W.items_per_pixel; c++) {
-    const unsigned long long item = ((unsigned long long)ltile * W.items_per_pixel + c) * 64ull + p;
+    const unsigned long long item = ((unsigned long long)ptile * W.items_per_pixel + c) * 64ull + p;
     ckpt[item] = make_ulonglong2(g.s0, g.s1);
     for (int i = 0; i < 4 * W.samples_per_item; i++) rng_next64(g);
   }
@@ -441,6 +459,9 @@ struct Counters {
   unsigned long long walk_steps;  // BSSRDF random-walk steps (stage-queued kernel, F_SSS variants)
   unsigned long long section_cycles[16];  // diagnostic builds (-DPINE_PROFILE_SECTIONS) only
   unsigned long long t_start, t_pool_dry, t_end;  // ... 100 MHz wall clock: first workgroup in, the work-item pool found empty, last workgroup out
+#ifdef PINE_PROFILE_SECTIONS
+  unsigned long long wg_t[1024][4];  // per workgroup: its last whole-pixel item sealed | pool found dry | out | whole-pixel items claimed
+#endif
 };
 
 
@@ -670,7 +691,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             if (W.items_per_pixel == 1) {
               rng_store(rng_seed(hash_pixel(it.px, it.py, 0)));  // Sampler::start_pixel
             } else {
-              const ulonglong2 c = ckpt[item];
+              const ulonglong2 c = ckpt[it.ckpt_index];
               rng_store(DRng{c.x, c.y});
             }
           }  // else: pixel outside the film (partial border tile): ask again next trip

@@ -68,3 +68,19 @@ extern "C" const PineKernelVariant* PINE_PART_FN(PINE_PART)(int* queue_count, in
   *mega_count = n - nq;
   return g_table;
 }
+
+#ifdef PINE_PROFILE_SECTIONS
+// diagnostic builds: add this part's REGION counters (per-translation-unit device globals) to the caller's totals
+#define PINE_PART_REGIONS_FN_(k) pine_gpu_kernel_part_regions_##k
+#define PINE_PART_REGIONS_FN(k) PINE_PART_REGIONS_FN_(k)
+extern "C" int PINE_PART_REGIONS_FN(PINE_PART)(unsigned long long* lanes, unsigned long long* hits) {
+  unsigned long long rl[16], rh[16];
+  if (hipMemcpyFromSymbol(rl, HIP_SYMBOL(pine_gpu::g_region_lanes), sizeof rl) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(rh, HIP_SYMBOL(pine_gpu::g_region_hits), sizeof rh) != hipSuccess) return -1;
+  for (int i = 0; i < 16; i++) {
+    lanes[i] += rl[i];
+    hits[i] += rh[i];
+  }
+  return 0;
+}
+#endif

@@ -257,6 +257,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   };
   auto push_w = [&](bool to_w, int id) { push_q(QS_W, to_w, id); };
 
+  // samples of a pixel that form one sequential chain (kFork): the whole pixel -- the item itself without tile classes
+  const int chain_spi = W.serial_tiles > 0 ? S.spp : W.samples_per_item;
   SEC_DECL;
   // record a finished closest-hit query in the context and classify the vertex it reaches:
   // emissive / miss / path-length limit -> terminal queue, otherwise -> shade queue
@@ -329,6 +331,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 
   unsigned shadow_count = 0, walk_count = 0;
   unsigned spins = 0;
+  unsigned pick_no = 0;  // picks since this wave's last starvation-guard pick
   unsigned idle_polls = 0;
   // bounded-spin bail-out: record where, raise the workgroup's abort flag, leave
   auto bail = [&](unsigned code, unsigned a, unsigned b) {
@@ -337,6 +340,36 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     counters->bail_code = code;
     counters->bail_a = a;
     counters->bail_b = b;
+  };
+
+  // (kFork) contexts with nothing to do wait in the ring F; take up to `count` of them back into stage T (whole wave)
+  auto wake_free = [&](unsigned count) {
+    if constexpr (kFork) {
+      const unsigned fh = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_HEAD + QS_F]));
+      const unsigned favail = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_TAIL + QS_F])) - fh;
+      if (favail != 0u && count != 0u) {
+        const unsigned want = favail < count ? favail : count;
+        unsigned got = 0;
+        if (lane == 0) got = atomicCAS(&qctl[QC_HEAD + QS_F], fh, fh + want) == fh ? 1u : 0u;  // (lost the race: somebody else woke them)
+        if (__builtin_amdgcn_readfirstlane(got)) {
+          int fid = -1;
+          if (lane < want) {
+            unsigned* slot = &ring[QS_F * kQRing + ((fh + lane) & (kQRing - 1))];
+            unsigned v, tries = 0;
+            while ((v = atomicExch(slot, 0u)) == 0u) {
+              if (++tries > kQSpinLimit) {
+                bail(6, unsigned(QS_F), fh + lane);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            fid = int(v) - 1;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          push2(false, fid >= 0, fid);
+        }
+      }
+    }
   };
 
   // ---- traversal stage with refill (X variants) ----
@@ -477,7 +510,40 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           h_best = hq[q];
         }
       }
-      if (cnt_best >= 64u || (cnt_best > 0u && (busy == 0u || spins >= unsigned(W.pick_spins)))) {
+      // Starvation guard: "the fullest queue" alone never serves a queue that stays short while the others are long -- the
+      // walk queue W when only a few pixels see the Subsurface shape: their sample chains then crawl (measured on C5 with
+      // tile classes: chains that need 20 ms took the whole 155 ms launch).  Every W.fair_period-th pick of a wave takes
+      // the walk queue, however few entries it has.
+      bool fair_pick = false;
+      if constexpr ((F & F_SSS) != 0) {
+        const unsigned period = unsigned(W.fair_period < 0 ? -W.fair_period : W.fair_period);
+        if (period != 0u && ++pick_no >= period) {
+          pick_no = 0;
+          if (W.fair_period > 0) {  // the walk queue
+            if (cq[QS_W] != 0u) {
+              best = QS_W;
+              cnt_best = cq[QS_W];
+              h_best = hq[QS_W];
+              fair_pick = true;
+            }
+          } else {  // (measurement aid) the shortest non-empty queue, whichever it is
+            unsigned cnt_min = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < kNStage; q++) {
+              if (cq[q] != 0u && cq[q] < cnt_min) {
+                cnt_min = cq[q];
+                best = q;
+                h_best = hq[q];
+              }
+            }
+            if (cnt_min != 0xffffffffu) {
+              cnt_best = cnt_min;
+              fair_pick = true;
+            }
+          }
+        }
+      }
+      if (cnt_best >= 64u || fair_pick || (cnt_best > 0u && (busy == 0u || spins >= unsigned(W.pick_spins)))) {
         // count ourselves busy BEFORE taking items out of the queue, so that "all queues empty and
         // nobody busy" really means no work can appear any more (idle pollers never touch the
         // counter: two of them must not keep each other alive)
@@ -833,8 +899,14 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             // plain diffuse, above), so the pixel's RNG state is final for this sample and the NEXT sample can start
             if (W.fork_sealed && !st.sealed() && st.diffuse_length() > 0) {
               st.set_sealed();
-              release = ((st.s_cur() + 1) & (W.samples_per_item - 1)) != 0;
-              if (!release) atomicSub(&qctl[QC_PIXELS], 1u);  // the pixel's last sample is under way: no longer "in flight" for the intake limit
+              release = ((st.s_cur() + 1) & (chain_spi - 1)) != 0;
+              if (!release) {  // the pixel's last sample is under way: no longer "in flight" for the intake limit
+                const unsigned before = atomicSub(&qctl[QC_PIXELS], 1u);
+                (void)before;
+#ifdef PINE_PROFILE_SECTIONS
+                if (before == 1u && blockIdx.x < 1024) counters->wg_t[blockIdx.x][0] = wall_clock64();  // (the workgroup's last whole-pixel item: its last sample sealed)
+#endif
+              }
             }
           }
           if (kX && parked_shadow) {
@@ -906,31 +978,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           if (release) __atomic_store_n(&ring[QS_K * kQRing + rel_pos], 1u, __ATOMIC_RELAXED);
           // contexts with nothing to do wait in F: wake one per token (they enter stage T as empty contexts and find
           // the tokens there)
-          const unsigned fh = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_HEAD + QS_F]));
-          const unsigned favail = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_TAIL + QS_F])) - fh;
-          if (favail != 0u) {
-            const unsigned nrel = unsigned(__popcll(rel_mask));
-            const unsigned want = favail < nrel ? favail : nrel;
-            unsigned got = 0;
-            if (lane == 0) got = atomicCAS(&qctl[QC_HEAD + QS_F], fh, fh + want) == fh ? 1u : 0u;
-            if (__builtin_amdgcn_readfirstlane(got)) {
-              int fid = -1;
-              if (lane < want) {
-                unsigned* slot = &ring[QS_F * kQRing + ((fh + lane) & (kQRing - 1))];
-                unsigned v, tries = 0;
-                while ((v = atomicExch(slot, 0u)) == 0u) {
-                  if (++tries > kQSpinLimit) {
-                    bail(6, unsigned(QS_F), fh + lane);
-                    break;
-                  }
-                  __builtin_amdgcn_s_sleep(1);
-                }
-                fid = int(v) - 1;
-              }
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-              push2(false, fid >= 0, fid);
-            }
-          }
+          wake_free(unsigned(__popcll(rel_mask)));
         }
       }
     } else if (kX && (stage == QS_XS || stage == QS_XC)) {
@@ -1005,6 +1053,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       bool to_shade2 = false, to_term2 = false, to_xc2 = false;
       bool to_free = false;  // (kFork) nothing to do for this context now: it waits in F
       bool fresh_rng = false;  // the context took a new work item this round: its RNG state is in item_rng, not yet in memory
+      bool free_item = false;  // (kFork, tile classes) ... and it is an item of the independent class
+      bool wake_more = false;  // (kFork, tile classes) independent items are at hand: wake contexts that wait in F
       DRng item_rng{0, 0};
       unsigned pxy = 0, sample_base = 0;
       int s_next = 0;
@@ -1092,10 +1142,18 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           pxy = cstu[CF_PXY * kQCtx + id];
           samples[size_t(sample_base) + size_t(s_now) * 64u] = make_float4(Li.x, Li.y, Li.z, float(pv_length + 1));
           s_next = s_now + 1;
-          if ((kFork && st.sealed()) || (s_next & (W.samples_per_item - 1)) == 0) need_item = true;  // (sealed: the pixel's next sample went out as a token)
+          // (sealed: the pixel's next sample went out as a token -- or, with tile classes, the path is a one-sample item
+          // of the independent class, which never owned its pixel's chain)
+          if ((kFork && st.sealed()) || (s_next & ((kFork ? chain_spi : W.samples_per_item) - 1)) == 0) need_item = true;
           else have_path = true;
           if constexpr (kFork)
-            if (!st.sealed() && (s_next & (W.samples_per_item - 1)) == 0) atomicSub(&qctl[QC_PIXELS], 1u);
+            if (!st.sealed() && (s_next & (chain_spi - 1)) == 0) {
+              const unsigned before = atomicSub(&qctl[QC_PIXELS], 1u);
+              (void)before;
+#ifdef PINE_PROFILE_SECTIONS
+              if (before == 1u && blockIdx.x < 1024) counters->wg_t[blockIdx.x][0] = wall_clock64();
+#endif
+            }
         }
       }
       SEC_MARK(7);  // T: terminal result + backward fold + sample store
@@ -1113,6 +1171,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         unsigned long long base = 0;
         unsigned got = 0;
         unsigned kbase = 0, kgot = 0;  // (kFork) sample tokens taken: ring positions [kbase, kbase + kgot)
+        unsigned want_free = 0;        // (kFork) items wanted beyond the tokens, before the in-flight limit
+        unsigned free_items_left = 0;  // (kFork, tile classes) the workgroup's block still has independent items after this round
         if (lane == 0) {
           unsigned tries = 0;
           while (atomicCAS(&qctl[QC_LOCK], 0u, 1u) != 0u) {
@@ -1131,6 +1191,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             kgot = want < kavail ? want : kavail;
             __atomic_store_n(&qctl[QC_HEAD + QS_K], kbase + kgot, __ATOMIC_RELAXED);
             want -= kgot;
+            want_free = want;
             // pixels in flight per workgroup are bounded (W.max_pixels): each one's samples then follow one another
             // quickly, and little is left half-done -- unevenly, workgroup by workgroup -- when the work-item pool runs dry
             const unsigned inflight = lds_load(&qctl[QC_PIXELS]);
@@ -1144,17 +1205,31 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             if (b >= W.total_items) {
 #ifdef PINE_PROFILE_SECTIONS
               atomicCAS(&counters->t_pool_dry, 0ull, wall_clock64());
+              if (blockIdx.x < 1024) counters->wg_t[blockIdx.x][1] = wall_clock64();
 #endif
               __atomic_store_n(&qctl[QC_EXHAUSTED], 1u, __ATOMIC_RELAXED);
             } else {
               post_progress(W, b, 9);
+#ifdef PINE_PROFILE_SECTIONS
+              if (blockIdx.x < 1024) {
+                if (b < (unsigned long long)W.serial_tiles * 64ull) atomicAdd(&counters->wg_t[blockIdx.x][3], 64ull);
+              }
+#endif
               nx = b;
               en = b + W.pool_items < W.total_items ? b + W.pool_items : W.total_items;
             }
           }
           const unsigned long long avail = en - nx;
+          if constexpr (kFork) {
+            // tile classes: the block [nx, en) holds independent one-sample items (no pixel is taken into flight, no limit)
+            // when it lies behind the whole-pixel items -- blocks are 64 items and the class boundary a multiple of 64
+            if (W.serial_tiles > 0 && nx >= (unsigned long long)W.serial_tiles * 64ull) want = want_free;
+          }
           got = want < avail ? want : unsigned(avail);
-          if constexpr (kFork) atomicAdd(&qctl[QC_PIXELS], got);
+          if constexpr (kFork) {
+            if (!(W.serial_tiles > 0 && nx >= (unsigned long long)W.serial_tiles * 64ull)) atomicAdd(&qctl[QC_PIXELS], got);
+            else if (avail > got) free_items_left = 1u;  // independent items at hand: contexts waiting in F can have them
+          }
           base = nx;
           nx += got;
           __atomic_store_n(&qctl[QC_PNEXT], unsigned(nx), __ATOMIC_RELAXED);
@@ -1169,6 +1244,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         if constexpr (kFork) {
           kbase = __shfl(kbase, 0);
           kgot = __shfl(kgot, 0);
+          wake_more |= __shfl(free_items_left, 0) != 0u;
         }
         if (got == 0 && kgot == 0) {
           // global queue exhausted (and no token waits): these contexts retire -- plain variants: they are simply not
@@ -1212,16 +1288,18 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             sample_base = unsigned(itf.sample_base);
             s_next = itf.chunk * W.samples_per_item;
             DRng g;
-            if (W.items_per_pixel == 1) {
+            if (itf.serial || W.items_per_pixel == 1) {
               g = rng_seed(hash_pixel(itf.px, itf.py, 0));
             } else {
-              const ulonglong2 c = ckpt[item];
+              const ulonglong2 c = ckpt[itf.ckpt_index];
               g = DRng{c.x, c.y};
             }
             item_rng = g;
             fresh_rng = true;
+            if constexpr (kFork) free_item = W.serial_tiles > 0 && !itf.serial;
           } else {
-            if constexpr (kFork) atomicSub(&qctl[QC_PIXELS], 1u);  // (counted when claimed)
+            if constexpr (kFork)
+              if (!(W.serial_tiles > 0 && !itf.serial)) atomicSub(&qctl[QC_PIXELS], 1u);  // (counted when claimed)
           }
         }
       }
@@ -1244,6 +1322,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const DRay r = camera_gen_ray(S.cam, pf, f2{lx, ly});
         PackedState st{0};
         st.start_sample(s_next);
+        if constexpr (kFork)
+          if (free_item) st.set_sealed();  // tile classes: a one-sample item of the independent class never owns its pixel's chain
         if constexpr (F & F_SOBOL)
           if (S.tables.kind == 2) st.set_dim(2);  // HaltonSampler::start_pixel / start_next_sample: dimension = 2
         cstu[CF_PXY * kQCtx + id] = pxy;
@@ -1254,13 +1334,19 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       push2(to_shade2, to_term2, id);
       if constexpr (kX) push_q(QS_XC, to_xc2, id);
-      if constexpr (kFork) push_q(QS_F, to_free, id);
+      if constexpr (kFork) {
+        push_q(QS_F, to_free, id);
+        // tile classes: contexts that went to wait while the workgroup's whole-pixel items were at their in-flight limit
+        // are woken by token releases only; once independent items are being handed out they can all work again
+        if (wake_more) wake_free(64u);
+      }
     }
     if (lane == 0) atomicSub(&qctl[QC_BUSY], 1u);
   }
 
 #ifdef PINE_PROFILE_SECTIONS
   if (tid == 0) atomicMax(&counters->t_end, wall_clock64());
+  if (tid == 0 && blockIdx.x < 1024) counters->wg_t[blockIdx.x][2] = wall_clock64();
 #endif
   SEC_FLUSH();
   unsigned long long sc = shadow_count;

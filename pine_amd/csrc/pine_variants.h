@@ -34,6 +34,15 @@ const PineKernelVariant* pine_gpu_kernel_part_4(int* queue_count, int* mega_coun
 const PineKernelVariant* pine_gpu_kernel_part_5(int* queue_count, int* mega_count);
 const PineKernelVariant* pine_gpu_kernel_part_6(int* queue_count, int* mega_count);
 const PineKernelVariant* pine_gpu_kernel_part_7(int* queue_count, int* mega_count);
+// diagnostic builds (-DPINE_PROFILE_SECTIONS): each part adds its REGION counters to the caller's totals
+int pine_gpu_kernel_part_regions_0(unsigned long long*, unsigned long long*);
+int pine_gpu_kernel_part_regions_1(unsigned long long*, unsigned long long*);
+int pine_gpu_kernel_part_regions_2(unsigned long long*, unsigned long long*);
+int pine_gpu_kernel_part_regions_3(unsigned long long*, unsigned long long*);
+int pine_gpu_kernel_part_regions_4(unsigned long long*, unsigned long long*);
+int pine_gpu_kernel_part_regions_5(unsigned long long*, unsigned long long*);
+int pine_gpu_kernel_part_regions_6(unsigned long long*, unsigned long long*);
+int pine_gpu_kernel_part_regions_7(unsigned long long*, unsigned long long*);
 }
 const PineKernelVariant* pine_gpu_fast_variants(int* count);
 

@@ -548,7 +548,9 @@ def test_subsurface_runs_on_the_stage_queued_kernel(path_kernel):
         w, h = sc.camera.film().size
         f, st = _render(sc, 16, 8)
         assert st.block_threads == (256 if path_kernel == "mega" else 1024)
-        assert st.samples_per_item == st.spp_effective  # in-path RNG draws: a pixel's samples stay sequential
+        # in-path RNG draws: a pixel's samples stay sequential -- in every pixel, or (tile classes) in the tiles from which
+        # a camera ray can reach the Subsurface shape
+        assert st.samples_per_item == st.spp_effective or (path_kernel == "queue" and st.serial_tiles > 0)
         ref, _ = oracle.render(sc.describe(), (w, h), 16, 8)
         assert_bit_equal(f, ref, f"subsurface case {i} ({path_kernel})")
 
@@ -615,7 +617,14 @@ def test_traversal_as_stages_or_inside_stages_changes_nothing(oracle, monkeypatc
 
 
 @pytest.mark.parametrize("env", [{}, {"PINE_GPU_NO_FORK": "1"}, {"PINE_GPU_POOL_ITEMS": "16"}, {"PINE_GPU_POOL_ITEMS": "4096"},
-                                 {"PINE_GPU_MAX_PIXELS": "1"}, {"PINE_GPU_MAX_PIXELS": "100000"}])
+                                 {"PINE_GPU_MAX_PIXELS": "1"}, {"PINE_GPU_MAX_PIXELS": "100000"},
+                                 # ... and without tile classes (every pixel a whole-pixel item, as before round 3)
+                                 {"PINE_GPU_NO_TILE_CLASSES": "1"}, {"PINE_GPU_NO_TILE_CLASSES": "1", "PINE_GPU_POOL_ITEMS": "16"},
+                                 {"PINE_GPU_NO_TILE_CLASSES": "1", "PINE_GPU_POOL_ITEMS": "4096"},
+                                 {"PINE_GPU_NO_TILE_CLASSES": "1", "PINE_GPU_MAX_PIXELS": "1"},
+                                 # the stage picker's starvation guard: never / the walk queue at every pick / the shortest queue at every pick
+                                 {"PINE_GPU_FAIR_PERIOD": "0"}, {"PINE_GPU_FAIR_PERIOD": "1"}, {"PINE_GPU_FAIR_PERIOD": "-1"},
+                                 {"PINE_GPU_NO_TILE_CLASSES": "1", "PINE_GPU_FAIR_PERIOD": "0"}])
 def test_sample_tokens_change_nothing(oracle, monkeypatch, path_kernel, env):
     """Subsurface scenes: a pixel's samples are sequentially dependent through the pixel's RNG (the BSSRDF channel pick,
     bxdf.cpp:335), but only until a path's first non-delta bounce -- after it the path draws no RNG value any more, so it
@@ -636,7 +645,13 @@ def test_sample_tokens_change_nothing(oracle, monkeypatch, path_kernel, env):
     for i, (sc, spp, depth) in enumerate(cases):
         w, h = sc.camera.film().size
         f, st = _render(sc, spp, depth)
-        assert st.block_threads == 1024 and st.samples_per_item == st.spp_effective
+        assert st.block_threads == 1024 and (st.samples_per_item == st.spp_effective or st.serial_tiles > 0)
+        if "PINE_GPU_NO_TILE_CLASSES" in env or "PINE_GPU_NO_FORK" in env:
+            assert st.serial_tiles == 0
+        elif i < 2:  # (Diffuse + Subsurface + Emissive only, pinhole camera: the tiles away from the mesh are independent items)
+            assert 0 < st.serial_tiles < ((w + 7) // 8) * ((h + 7) // 8)
+        else:  # a Metal sphere: a delta-capable material, every pixel stays one item
+            assert st.serial_tiles == 0
         ref, _ = oracle.render(sc.describe(), (w, h), spp, depth)
         assert_bit_equal(f, ref, f"sample tokens {env}, case {i}")
 
