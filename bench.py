@@ -13,9 +13,12 @@ N > 1    : 8x8-pixel tiles dealt round-robin to ranks (strong scaling: the film 
            only its own tiles into a slab, the slabs are gathered to rank 0 (direct xGMI sends) and scattered
            into the row-major film there.  The gather + unpack of step i runs on a second stream while the path
            kernel of step i+1 runs (double-buffered slabs).
-At N = 1 the default line also carries a `configs` array: C3 / C4 / C5 measured the same way at reduced
-steps, each with its own roofline entry and its film's md5 checked against the reference's
-(tests/golden/stats_640.json).
+At N = 1 the default line also carries a `configs` array: C2 with the README camera, C3 / C4 /
+C5 measured the same way at reduced steps, each with its own roofline entry and its film's md5 checked against
+the reference's (tests/golden/stats_640.json); `host_resident` (the same renders with the film's device-to-host
+copy inside the clock) and `including_build_and_upload` (one cold render: plan creation = host BVH build + flattening
++ table / scene upload, then the launch and the copy).  At N > 1 the headline stays C2 and `configs` carries C3 --
+BASELINE's 8-GPU workload -- sharded over the same ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,6 +43,9 @@ def _configs():
         # name: (scene builder, requested spp, depth, workload text, key in tests/golden/stats_640.json)
         "c2": (lambda: scenes.cbox((640, 640), "committed"), 256, 8,
                "cbox 640x640 256spp depth=8, as-committed camera, BlueSampler, pine-BVH order", "C2_cbox_640_s256_d8_committed"),
+        "c2r": (lambda: scenes.cbox((640, 640), "readme"), 256, 8,
+                "cbox 640x640 256spp depth=8, README camera [0,1,-4]->[0,1,0] fov 0.25 (README.md:32: the whole room is in view), BlueSampler, pine-BVH order",
+                "C2_cbox_640_s256_d8_readme"),
         "c3": (lambda: scenes.cbox((1920, 1080), "committed"), 1024, 8,
                "cbox 1920x1080 BlueSampler(1024) = 256 effective spp depth=8, as-committed camera, pine-BVH order",
                "C3_cbox_1920x1080_s1024_d8"),
@@ -139,7 +145,40 @@ def cpu_baseline_reference(scene, size, spp, depth, gpu_md5, budget_s=40.0):
         return None
 
 
-def roofline_entry(st, local_samples, verts, traffic=None):
+def pmc_figures(name):
+    """VALU figures of the path kernel from the latest committed PMC summary of this config (profiles/rNN_[cX_]pmc_summary.txt,
+    written by tools/profile_round.sh on the GPU box) -- collected off-line with rocprofv3 --pmc, NOT in this run."""
+    pat = "r*_pmc_summary.txt" if name in ("c2", "c3") else f"r*_{name}_pmc_summary.txt"
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pat)) if name not in ("c2", "c3") or "_c" not in os.path.basename(f)[3:])
+    if not files:
+        return None
+    m = {}
+    for line in open(files[-1]):
+        t = line.split()
+        if len(t) >= 2 and t[0].startswith(("SQ_", "TCC_", "FETCH", "WRITE")):
+            try:
+                m[t[0]] = float(t[1])
+            except ValueError:
+                pass
+    need = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_INSTS_SALU")
+    if any(k not in m for k in need):
+        return None
+    simd_quads = m["SQ_WAVE_CYCLES"] / 4.0  # four resident waves per SIMD for the whole launch (one 1024-thread workgroup per CU)
+    return {
+        # share of the SIMDs' time in which SOME wave has a VALU instruction in flight (sum over a SIMD's four waves: can exceed 1)
+        "valu_active_per_simd": m["SQ_ACTIVE_INST_VALU"] / simd_quads,
+        # lanes doing work per executed VALU instruction
+        "valu_lane_utilisation": m["SQ_THREAD_CYCLES_VALU"] / (m["SQ_ACTIVE_INST_VALU"] * 64.0),
+        # issue slots: measured on gfx950 (tools/valu_rate.hip, profiles/r03_issue_rates.txt) a SIMD issues one full-rate VALU
+        # wave-instruction per ~2.2 cycles and one half-rate (compare, select, shift, v_div_*, f64) or scalar one per ~4
+        "valu_issue_share_at_2_cycles": m["SQ_INSTS_VALU"] * 2.0 / (simd_quads * 4.0),
+        "valu_issue_share_at_4_cycles": m["SQ_INSTS_VALU"] * 4.0 / (simd_quads * 4.0),
+        "salu_issue_share_at_4_cycles": m["SQ_INSTS_SALU"] * 4.0 / (simd_quads * 4.0),
+        "source": os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc passes of an earlier run of this command, not this run)",
+    }
+
+
+def roofline_entry(st, local_samples, verts, traffic=None, name=None):
     """Roofline of the dominant kernel (the path kernel) on this rank: algorithmic bytes per launch =
     192 B x radiance() invocations + 16 B x pixels of this rank's shard, over the kernel's average launch
     duration from HIP events recorded on the launch stream inside the library."""
@@ -147,9 +186,11 @@ def roofline_entry(st, local_samples, verts, traffic=None):
     kernel = "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel"
     alg_bytes = B_VERTEX * verts + 16.0 * local_samples / st.spp_effective
     achieved = alg_bytes / (k_ms * 1e-3) * 1e-9
+    pm = pmc_figures(name) if name else None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_unit": "bytes per launch (rocprofv3 2*FETCH_SIZE+WRITE_SIZE, fabric side incl. Infinity-Cache hits)",
+            "traffic_unit": "bytes per launch (rocprofv3 2*FETCH_SIZE+WRITE_SIZE, fabric side incl. Infinity-Cache hits); read from the latest profiles/rNN_traffic*.json (separate --pmc passes of this command), not measured in this run",
+            "valu_utilisation": pm["valu_active_per_simd"] if pm else None, "valu": pm,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel": kernel, "kernel_ms": k_ms,
             "bytes_per_vertex": B_VERTEX, "note": "algorithmic bytes of the streaming formulation (SURVEY.md 8(d)); the kernel keeps path state in LDS and the fold stack in L2/Infinity Cache, so it is latency/VALU bound, not HBM bound"}
@@ -196,7 +237,8 @@ def side_config(name, steps, warmup, device, fast=False):
     host_film = film.cpu().numpy()
     md5 = hashlib.md5(host_film.tobytes()).hexdigest()
     want = golden_md5(key)
-    rl = roofline_entry(st, st.camera_samples, st.vertices, None if fast else measured_traffic(name, "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel", 1))
+    rl = roofline_entry(st, st.camera_samples, st.vertices, None if fast else measured_traffic(name, "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel", 1),
+                        None if fast else name)
     if fast:
         # distance from the exact film of the same scene (SURVEY.md 8(d)'s metric): rendered here, once
         import numpy as np
@@ -230,49 +272,18 @@ def side_config(name, steps, warmup, device, fast=False):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"], help="the workload (default: BASELINE configs[1])")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 entries of the default line")
-    ap.add_argument("--spi", type=int, default=0, help="samples per work item (0 = auto)")
-    args = ap.parse_args()
-
+def measure(name, steps, warmup, env, spi=0):
+    """K timed renders of one config, sharded over the job's ranks (every rank calls this): W untimed steps, barrier +
+    synchronize, K steps without host synchronisation, barrier + synchronize, MAX over ranks.  Returns a dict on every rank
+    (film / statistics of rank 0's view; totals summed over ranks)."""
     import torch
     import pine_amd
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the PathIntegrator hot path has no CPU fallback")
-    # Rehearsal knobs (not used by the driver): PINE_BENCH_BACKEND=gloo runs the N > 1 code path with the
-    # collectives staged through host memory, PINE_BENCH_DEVICE pins every rank to one GPU -- together
-    # they let a one-GPU box execute the multi-rank logic end to end (tools/rehearse_ranks.sh).
-    backend = os.environ.get("PINE_BENCH_BACKEND", "nccl")
-    if os.environ.get("PINE_BENCH_DEVICE"):
-        local_rank = int(os.environ["PINE_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dist = None
-    use_dist = world > 1 or os.environ.get("PINE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL calls at N=1
-    if use_dist:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    cdev = "cuda" if backend == "nccl" else "cpu"  # where collective buffers live
-
-    build, SPP, DEPTH, workload, stats_key = _configs()[args.config]
+    rank, world, local_rank, dist, use_dist, cdev = env["rank"], env["world"], env["local_rank"], env["dist"], env["use_dist"], env["cdev"]
+    build, SPP, DEPTH, workload, stats_key = _configs()[name]
     scene = build()
     W, H = scene.camera.film().size
     plan = pine_amd.Plan(scene, SPP, DEPTH, device=local_rank, shard_rank=rank, shard_world=world,
-                         samples_per_item=args.spi, timing=True)
+                         samples_per_item=spi, timing=True)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
@@ -329,12 +340,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     plan.stats()  # (discard the warm-up launches' kernel timings)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()  # no host synchronisation inside the timed loop
     barrier()
     dt = time.perf_counter() - t0
@@ -346,7 +357,6 @@ def main():
     # per-kernel HIP-event timings (events recorded on the launch stream inside the library): mean
     # over the timed launches (the library keeps the last 64)
     st = plan.stats()
-    spp_eff = st.spp_effective
     local_samples = st.camera_samples
     verts = st.vertices
     if use_dist:
@@ -355,48 +365,161 @@ def main():
         total_samples, total_verts = float(t[0]), float(t[1])
     else:
         total_samples, total_verts = float(local_samples), float(verts)
+    res = {"name": name, "scene": scene, "plan": plan, "film": film, "st": st, "dt": dt, "steps": steps, "warmup": warmup,
+           "size": (W, H), "spp": SPP, "depth": DEPTH, "workload": workload, "stats_key": stats_key,
+           "local_samples": local_samples, "verts": verts, "total_samples": total_samples, "total_verts": total_verts,
+           "collective": collective, "overlap": bool(overlap) if use_dist else None, "stream": stream}
+    return res
+
+
+def host_side_figures(res, steps, device):
+    """'t_render spans kernel launch -> film resident on host (report with and without host BVH build +
+    table upload)'.  N = 1 only.  (a) the same K renders with the film's device-to-host copy (pinned memory) inside the
+    clock; (b) one cold render: plan creation from the built scene description (host BVH build + flattening, device
+    allocation, upload of scene and sampler tables), the launch, the copy."""
+    import torch
+    import pine_amd
+    W, H = res["size"]
+    plan, film, stream = res["plan"], res["film"], res["stream"]
+    host = torch.empty((H, W, 4), dtype=torch.float32).pin_memory()
+    plan.launch(film.data_ptr(), stream)
+    host.copy_(film, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.launch(film.data_ptr(), stream)
+        host.copy_(film, non_blocking=True)  # (same stream: the copy follows the resolve kernel)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    samples = res["local_samples"]
+    out = {"host_resident": {"value": samples * steps / dt * 1e-6, "unit": "Msamples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                             "what": "launch -> film in pinned host memory (6.55 MB device-to-host copy per render inside the clock); scene resident"}}
+    build, SPP, DEPTH, _, _ = _configs()[res["name"]]
+    scene2 = build()  # (a fresh scene object: its BVH is not built yet)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan2 = pine_amd.Plan(scene2, SPP, DEPTH, device=device)
+    plan2.launch(film.data_ptr(), stream)
+    host.copy_(film, non_blocking=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st2 = plan2.stats()
+    out["including_build_and_upload"] = {
+        "value": samples / dt * 1e-6, "unit": "Msamples/s", "ms": dt * 1e3,
+        "accel_build_host_ms": st2.accel_build_ms, "alloc_and_upload_ms": st2.upload_ms,
+        "what": "ONE cold render: plan creation (host BVH build + flattening, device allocation, upload of scene records and the 320 KB of sampler "
+                "tables), launch, film to pinned host memory; the process's HIP module is already loaded"}
+    plan2.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=["c2", "c2r", "c3", "c4", "c5"], help="the workload (default: BASELINE configs[1])")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other configs' entries of the default line")
+    ap.add_argument("--spi", type=int, default=0, help="samples per work item (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import pine_amd  # noqa: F401
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the PathIntegrator hot path has no CPU fallback")
+    # Rehearsal knobs (not used by the driver): PINE_BENCH_BACKEND=gloo runs the N > 1 code path with the
+    # collectives staged through host memory, PINE_BENCH_DEVICE pins every rank to one GPU -- together
+    # they let a one-GPU box execute the multi-rank logic end to end (tools/rehearse_ranks.sh).
+    backend = os.environ.get("PINE_BENCH_BACKEND", "nccl")
+    if os.environ.get("PINE_BENCH_DEVICE"):
+        local_rank = int(os.environ["PINE_BENCH_DEVICE"])
+    torch.cuda.set_device(local_rank)
+    dist = None
+    use_dist = world > 1 or os.environ.get("PINE_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL calls at N=1
+    if use_dist:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"  # where collective buffers live
+    env = {"rank": rank, "world": world, "local_rank": local_rank, "dist": dist, "use_dist": use_dist, "cdev": cdev}
+
+    res = measure(args.config, args.steps, args.warmup, env, args.spi)
+    st = res["st"]
+    W, H = res["size"]
+    # N > 1: BASELINE names C3 (1920x1080) as the 8-GPU workload; the headline stays C2 so that N = 1 equals the single-GPU
+    # record, and C3 is measured right after it on the same ranks (every rank takes part; rank 0 reports)
+    c3 = None
+    if world > 1 and args.config == "c2" and not args.no_configs:
+        res["plan"].close()
+        res["plan"] = None
+        c3 = measure("c3", max(2, args.steps // 3), 1, env, args.spi)
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = total_samples * args.steps / dt * 1e-6
-        vbar = total_verts / total_samples
-        kernel = "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel"
-        film_md5 = hashlib.md5(film.cpu().numpy().tobytes()).hexdigest()
-        want = golden_md5(stats_key)
-        out = {
-            "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (the reference's scene geometry rebuilt through the API; sampler tables are the published BlueSobol data)",
-            "config": {"workload": workload, "name": args.config,
-                       "film": [W, H], "spp_effective": spp_eff, "max_path_length": DEPTH,
-                       "parallelism": f"tiles8x8-roundrobin x{world}", "collective": collective,
-                       "overlap_gather_with_next_render": bool(overlap) if use_dist else None,
-                       "samples_per_item": st.samples_per_item,
-                       "grid_blocks": st.grid_blocks, "vertices_per_sample": vbar},
-            "roofline": roofline_entry(st, local_samples, verts, measured_traffic(args.config, kernel, world)),
-            "film_md5": film_md5, "reference_md5": want, "film_equals_reference": (film_md5 == want) if want else None,
-            "kernels_ms": {"prepass": st.prepass_ms, "path_trace": st.trace_ms, "resolve": st.resolve_ms, "launches_averaged": st.timed_launches},
-            "plan_ms": {"accel_build_host": st.accel_build_ms, "upload": st.upload_ms,
-                        "note": "one-time host cost of plan creation, outside the timed region (scene resident before it starts)"},
-        }
+        def line_of(r):
+            s_ = r["st"]
+            kernel = "path_queue_kernel" if s_.block_threads == 1024 else "path_trace_kernel"
+            md5 = hashlib.md5(r["film"].cpu().numpy().tobytes()).hexdigest()
+            want = golden_md5(r["stats_key"])
+            return {
+                "value": r["total_samples"] * r["steps"] / r["dt"] * 1e-6, "unit": "Msamples/s", "n_gpus": world,
+                "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["dt"] / r["steps"] * 1e3,
+                "config": {"workload": r["workload"], "name": r["name"],
+                           "film": list(r["size"]), "spp_effective": s_.spp_effective, "max_path_length": r["depth"],
+                           "parallelism": f"tiles8x8-roundrobin x{world}", "collective": r["collective"],
+                           "overlap_gather_with_next_render": r["overlap"],
+                           "samples_per_item": s_.samples_per_item, "serial_tiles": s_.serial_tiles,
+                           "grid_blocks": s_.grid_blocks, "vertices_per_sample": r["total_verts"] / r["total_samples"]},
+                "roofline": roofline_entry(s_, r["local_samples"], r["verts"], measured_traffic(r["name"], kernel, world), r["name"] if world == 1 else None),
+                "film_md5": md5, "reference_md5": want, "film_equals_reference": (md5 == want) if want else None,
+                "kernels_ms": {"prepass": s_.prepass_ms, "path_trace": s_.trace_ms, "resolve": s_.resolve_ms, "launches_averaged": s_.timed_launches},
+                "plan_ms": {"accel_build_host": s_.accel_build_ms, "upload": s_.upload_ms,
+                            "note": "one-time host cost of plan creation, outside the timed region (scene resident before it starts)"},
+            }
+        head = line_of(res)
+        out = {"metric": "Msamples/s", "value": head["value"], "unit": "Msamples/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic (the reference's scene geometry rebuilt through the API; sampler tables are the published BlueSobol data)"}
+        for k in ("config", "roofline", "film_md5", "reference_md5", "film_equals_reference", "kernels_ms", "plan_ms"):
+            out[k] = head[k]
+        film_md5 = head["film_md5"]
+        if c3 is not None:
+            e = line_of(c3)
+            e["config_name"] = "c3"
+            e["note"] = "BASELINE's multi-GPU workload (configs[2]) on the same ranks, measured after the headline; scaling: strong"
+            out["configs"] = [e]
+        if world == 1:
+            try:
+                out.update(host_side_figures(res, max(2, args.steps // 2), local_rank))
+            except Exception as e:  # report, keep the headline
+                out["host_resident"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_configs and args.config == "c2":
-            plan.close()
+            res["plan"].close()
+            res["plan"] = None
             out["configs"] = []
-            for name, k, w, fast in (("c3", 3, 1, False), ("c4", 5, 1, False), ("c5", 2, 1, False),
+            for name, k, w, fast in (("c2r", 5, 1, False), ("c3", 3, 1, False), ("c4", 5, 1, False), ("c5", 2, 1, False),
                                      ("c2", 5, 1, True), ("c4", 5, 1, True), ("c5", 2, 1, True)):
                 try:
                     out["configs"].append(side_config(name, k, w, local_rank, fast))
                 except Exception as e:  # report, keep the headline
                     out["configs"].append({"config": name + ("_fast" if fast else ""), "error": str(e)[:300]})
         if world == 1 and not args.no_cpu:
-            port = cpu_baseline(scene, (W, H), SPP, DEPTH)
-            ref = cpu_baseline_reference(scene, (W, H), SPP, DEPTH, film_md5)
+            port = cpu_baseline(res["scene"], (W, H), res["spp"], res["depth"])
+            ref = cpu_baseline_reference(res["scene"], (W, H), res["spp"], res["depth"], film_md5)
             cb = ref if ref else port
             out["cpu_baseline"] = cb
             if ref:
                 out["cpu_baseline_port"] = port  # this repo's CPU restatement of the same path, for comparison
-            out["speedup_vs_cpu"] = value / cb["value"]
+            out["speedup_vs_cpu"] = out["value"] / cb["value"]
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

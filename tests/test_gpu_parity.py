@@ -469,15 +469,16 @@ def test_c1_full_size_whole_image_md5():
     np.testing.assert_allclose(film[..., :3].mean(axis=(0, 1), dtype=np.float64), st["mean_rgb"], rtol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["C3_cbox_1920x1080_s1024_d8", "C4_classic_10k_cones_720x360_s64_d6", "C5_sss_320_s512_d8",
-                                  "C5_sss_640_s512_d8"])
+@pytest.mark.parametrize("name", ["C2_cbox_640_s256_d8_readme", "C3_cbox_1920x1080_s1024_d8", "C4_classic_10k_cones_720x360_s64_d6",
+                                  "C5_sss_320_s512_d8", "C5_sss_640_s512_d8"])
 def test_other_baseline_configs_whole_image_md5(name):
-    """BASELINE configs C3 (1920x1080, BlueSampler(1024) -> 256 spp), C4 (classic + 10 000 cones) at full size and
+    """C2 with the README camera, BASELINE configs C3 (1920x1080, BlueSampler(1024) -> 256 spp), C4 (classic + 10 000 cones) at full size and
     C5 (Subsurface icosphere, a quarter of the film and BASELINE's 640 x 640): the whole film's md5 equals the REAL
     reference's (both path kernels; the stage-queued one runs the BSSRDF walk as its stage W)."""
     from pine_amd import scenes
     st = json.load(open(os.path.join(GOLDEN, "stats_640.json")))[name]
-    sc = {"C3_": lambda: scenes.cbox((1920, 1080), "committed"),
+    sc = {"C2_": lambda: scenes.cbox((640, 640), "readme"),  # SURVEY.md 8(d): the README camera sees the whole room (V = 5.06)
+          "C3_": lambda: scenes.cbox((1920, 1080), "committed"),
           "C4_": lambda: scenes.classic_cones((720, 360), 100),
           "C5_sss_320": lambda: scenes.sss((320, 320), 3),
           "C5_sss_640": lambda: scenes.sss((640, 640), 3)}[name[:3] if name[1] != "5" else name[:10]]()

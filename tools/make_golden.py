@@ -81,6 +81,9 @@ HALTON_FILMS = {
 
 OTHER_CONFIGS = (
     # the BASELINE configs other than C1 / C2 at full size (whole-image statistics; too big to commit as films)
+    # C2 with the README camera [0,1,-4] -> [0,1,0], fov 0.25 (README.md:32), which sees the whole room
+    # (the as-committed camera leaves half the film empty): V = 5.06 radiance() invocations per sample instead of 2.64
+    ("C2_cbox_640_s256_d8_readme", lambda: scenes.cbox((640, 640), "readme"), 256, 8),
     ("C3_cbox_1920x1080_s1024_d8", lambda: scenes.cbox((1920, 1080), "committed"), 1024, 8),
     ("C4_classic_10k_cones_720x360_s64_d6", lambda: scenes.classic_cones((720, 360), 100), 64, 6),
     ("C5_sss_320_s512_d8", lambda: scenes.sss((320, 320), 3), 512, 8),
