@@ -331,6 +331,8 @@ int pine_gpu_test_rng(int device, uint64_t* out_host, int64_t capacity);        
 int pine_gpu_test_sincos(int device, const float* x_host, int64_t n, float* sin_out, float* cos_out);
 int pine_gpu_test_powlog(int device, const float* x_host, const float* y_host, int64_t n, float* pow_out,
                          float* log_out);                                           /* powf(x, y), logf(x) */
+int pine_gpu_test_atan(int device, const float* y_host, const float* x_host, int64_t n, float* atan2_out,
+                       float* acos_out);                                            /* atan2f(y, x), acosf(x) */
 int pine_gpu_test_shapes(pine_gpu_scene*, int device, const float* rays_host, int64_t nrays,
                          float* out_host, int64_t capacity);                        /* layout of oracle_shapes */
 

@@ -153,6 +153,7 @@ SIGNATURES = {
     "pine_gpu_test_rng": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.c_int64]),
     "pine_gpu_test_sincos": (C.c_int, [C.c_int, c_f_p, C.c_int64, c_f_p, c_f_p]),
     "pine_gpu_test_powlog": (C.c_int, [C.c_int, c_f_p, c_f_p, C.c_int64, c_f_p, c_f_p]),
+    "pine_gpu_test_atan": (C.c_int, [C.c_int, c_f_p, c_f_p, C.c_int64, c_f_p, c_f_p]),
     "pine_gpu_test_shapes": (C.c_int, [C.c_void_p, C.c_int, c_f_p, C.c_int64, c_f_p, C.c_int64]),
     "pine_gpu_film_finalize_u8": (C.c_int, [c_f_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
 }

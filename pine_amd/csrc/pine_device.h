@@ -795,10 +795,10 @@ PINE_HD void shape_surface_info(const DShape* S, f3 p, DSurface& it) {
       const f3 c = ld3(f);
       it.n = normalize(p - c);
       it.p = c + it.n * f[3];
-      // uv = cartesian_to_spherical(n): only shading nodes read it; device libm (not bit-exact)
-      float phi = atan2f(it.n.y, it.n.x);
+      // uv = cartesian_to_spherical(n) (vecmath.h:1209-1215): only shading nodes read it; glibc's atan2f / acosf restated (pine_libm.h)
+      float phi = patan2(it.n.y, it.n.x);
       phi = phi < 0.0f ? kPi * 2 + phi : phi;
-      it.uv = f2{phi, acosf(it.n.z)};
+      it.uv = f2{phi, pacos(it.n.z)};
       break;
     }
     case SHAPE_DISK: if constexpr (!(F & F_DISK)) __builtin_unreachable(); else {  // geometry.cpp:149-155

@@ -220,6 +220,13 @@ __global__ void test_powlog_kernel(const float* x, const float* y, long long n, 
     l[i] = plog(x[i]);
   }
 }
+__global__ void test_atan_kernel(const float* y, const float* x, long long n, float* at2, float* ac) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) {
+    at2[i] = patan2(y[i], x[i]);
+    ac[i] = pacos(x[i]);
+  }
+}
 __constant__ int kTestPixels[6][2] = {{0, 0}, {1, 0}, {3, 5}, {127, 127}, {128, 5}, {639, 639}};
 __global__ void test_sampler_kernel(DTables T, int spp, float* out) {
   // one thread per (pixel, pass); layout identical to oracle_sampler_stream
@@ -1653,6 +1660,24 @@ int pine_gpu_test_powlog(int device, const float* x, const float* y, int64_t n, 
   hipFree(dy);
   hipFree(dp);
   hipFree(dl);
+  return 0;
+}
+int pine_gpu_test_atan(int device, const float* y, const float* x, int64_t n, float* at2, float* ac) {
+  if (need_device(device)) return -1;
+  float *dy, *dx, *da, *dc;
+  HIP_OK(hipMalloc((void**)&dy, n * 4));
+  HIP_OK(hipMalloc((void**)&dx, n * 4));
+  HIP_OK(hipMalloc((void**)&da, n * 4));
+  HIP_OK(hipMalloc((void**)&dc, n * 4));
+  HIP_OK(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(test_atan_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, 0, dy, dx, (long long)n, da, dc);
+  HIP_OK(hipMemcpy(at2, da, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(ac, dc, n * 4, hipMemcpyDeviceToHost));
+  hipFree(dy);
+  hipFree(dx);
+  hipFree(da);
+  hipFree(dc);
   return 0;
 }
 int pine_gpu_test_sampler(int device, int spp_req, float* out, int64_t capacity) {

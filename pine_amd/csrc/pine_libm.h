@@ -373,4 +373,140 @@ PINE_HD float logf_glibc(float x) {  // e_logf.c
   return float(y);
 }
 
+// ------------------------------------------------------------------------------------------------
+// atanf / atan2f / acosf exactly as the host libm computes them (glibc 2.35 s_atanf.c, e_atan2f.c, e_acosf.c: the
+// fdlibm single-precision routines -- argument reduction to one of four atan anchors plus an odd / even split
+// polynomial; the rational approximation of asin for acos -- every operation rounded to binary32, no fused
+// multiply-add: x86-64 glibc has no FMA variant of these three).  On the path: a Sphere's uv (geometry.cpp:72-121
+// via cartesian_to_spherical), read by node graphs that use UV().  Algorithm restated; the coefficients are the
+// published ones.  tools/check_libm_atan.cpp: every binary32 argument of atanf and acosf and 4 x 10^9 (y, x) pairs of
+// atan2f (all special cases, exponent differences around +-60, random) against the container's libm: 0 mismatches.
+// sqrtf is the correctly rounded one in both.
+PINE_HD float atanf_glibc(float x) {
+  const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+  const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f,
+              aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f,
+              aT10 = 1.6285819933e-02f;
+  const int32_t hx = int32_t(asuint(x));
+  const int32_t ix = hx & 0x7fffffff;
+  int id;
+  float hi = 0.0f, lo = 0.0f;
+  if (ix >= 0x4c000000) {  // |x| >= 2^25
+    if (ix > 0x7f800000) return x + x;  // NaN
+    return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+  }
+  if (ix < 0x3ee00000) {  // |x| < 0.4375
+    if (ix < 0x31000000) return x;  // |x| < 2^-29
+    id = -1;
+  } else {
+    x = __builtin_fabsf(x);
+    if (ix < 0x3f980000) {    // |x| < 1.1875
+      if (ix < 0x3f300000) {  // 7/16 <= |x| < 11/16
+        id = 0;
+        x = (2.0f * x - 1.0f) / (2.0f + x);
+      } else {  // 11/16 <= |x| < 19/16
+        id = 1;
+        x = (x - 1.0f) / (x + 1.0f);
+      }
+    } else {
+      if (ix < 0x401c0000) {  // |x| < 2.4375
+        id = 2;
+        x = (x - 1.5f) / (1.0f + 1.5f * x);
+      } else {  // 2.4375 <= |x| < 2^25
+        id = 3;
+        x = -1.0f / x;
+      }
+    }
+    hi = id == 0 ? atanhi[0] : id == 1 ? atanhi[1] : id == 2 ? atanhi[2] : atanhi[3];
+    lo = id == 0 ? atanlo[0] : id == 1 ? atanlo[1] : id == 2 ? atanlo[2] : atanlo[3];
+  }
+  const float z = x * x;
+  const float w = z * z;
+  // the sum over aT[i] z^(i+1) split into its odd and even terms
+  const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  if (id < 0) return x - x * (s1 + s2);
+  const float r = hi - ((x * (s1 + s2) - lo) - x);
+  return hx < 0 ? -r : r;
+}
+PINE_HD float atan2f_glibc(float y, float x) {
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const int32_t hx = int32_t(asuint(x)), hy = int32_t(asuint(y));
+  const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;  // NaN
+  if (hx == 0x3f800000) return atanf_glibc(y);           // x = 1
+  const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);     // 2 * sign(x) + sign(y)
+  if (iy == 0) {                                         // y = 0
+    if (m < 2) return y;
+    return m == 2 ? pi + tiny : -pi - tiny;
+  }
+  if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;  // x = 0
+  if (ix == 0x7f800000) {                                       // x = inf
+    if (iy == 0x7f800000) {
+      switch (m) {
+        case 0: return pi_o_4 + tiny;
+        case 1: return -pi_o_4 - tiny;
+        case 2: return 3.0f * pi_o_4 + tiny;
+        default: return -3.0f * pi_o_4 - tiny;
+      }
+    }
+    switch (m) {
+      case 0: return 0.0f;
+      case 1: return -0.0f;
+      case 2: return pi + tiny;
+      default: return -pi - tiny;
+    }
+  }
+  if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;  // y = inf
+  const int32_t k = (iy - ix) >> 23;
+  float z;
+  if (k > 60) z = pi_o_2 + 0.5f * pi_lo;      // |y / x| > 2^60
+  else if (hx < 0 && k < -60) z = 0.0f;       // |y| / x < -2^60
+  else z = atanf_glibc(__builtin_fabsf(y / x));
+  switch (m) {
+    case 0: return z;
+    case 1: return asfloat(asuint(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+  }
+}
+PINE_HD float acosf_glibc(float x, float (*sqrt_rn)(float) = nullptr) {
+  const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+  const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f, pS4 = 7.9153501429e-04f,
+              pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+  (void)sqrt_rn;
+  const int32_t hx = int32_t(asuint(x));
+  const int32_t ix = hx & 0x7fffffff;
+  if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;  // |x| = 1
+  if (ix > 0x3f800000) return (x - x) / (x - x);                      // |x| > 1: NaN
+  if (ix < 0x3f000000) {                                              // |x| < 0.5
+    if (ix <= 0x23000000) return pio2_hi + pio2_lo;                   // |x| < 2^-57
+    const float z = x * x;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    return pio2_hi - (x - (pio2_lo - r * x));
+  }
+  if (hx < 0) {  // x < -0.5
+    const float z = (1.0f + x) * 0.5f;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float s = __builtin_sqrtf(z);
+    const float r = p / q;
+    const float w = r * s - pio2_lo;
+    return pi - 2.0f * (s + w);
+  }
+  // x > 0.5
+  const float z = (1.0f - x) * 0.5f;
+  const float s = __builtin_sqrtf(z);
+  const float df = asfloat(asuint(s) & 0xfffff000u);
+  const float c = (z - df * df) / (s + df);
+  const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+  const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+  const float r = p / q;
+  const float w = r * s + c;
+  return 2.0f * (df + w);
+}
+
 }  // namespace pine_libm

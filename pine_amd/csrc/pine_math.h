@@ -74,6 +74,8 @@ PINE_HD void psincos(float v, float& sn, float& cs) {
   sn = __sinf(v);
   cs = __cosf(v);
 }
+PINE_HD float patan2(float y, float x) { return atan2f(y, x); }
+PINE_HD float pacos(float v) { return acosf(v); }
 #else
 PINE_HD float psin(float v) { return pine_libm::sinf_glibc(v); }
 PINE_HD float pcos(float v) { return pine_libm::cosf_glibc(v); }
@@ -83,6 +85,9 @@ PINE_HD float plog(float v) { return pine_libm::logf_glibc(v); }
 PINE_HD void psincos(float v, float& sn, float& cs) {
   pine_libm::sincosf_glibc(v, sn, cs);
 }
+// libm-exact atan2 / acos (pine_libm.h): psl::atan2 == std::atan2, psl::acos == std::acos (src/psl/math.h:333-334, 388-389)
+PINE_HD float patan2(float y, float x) { return pine_libm::atan2f_glibc(y, x); }
+PINE_HD float pacos(float v) { return pine_libm::acosf_glibc(v); }
 #endif
 
 // ---- division ------------------------------------------------------------------------------------

@@ -1,9 +1,8 @@
 """GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the reference's golden
 vectors.  Integer streams AND films are compared bit for bit: the device arithmetic is IEEE binary32
 in the reference's operand order with a libm-exact sin/cos (pine_amd/csrc/pine_libm.h), so the stated
-tolerance for the cbox-class scenes is ZERO; scenes using powf/logf/atan2f on the device (Uber
-Schlick term, BSSRDF free flight, sphere uv) are held to per-pixel relative L2 <= 1e-4 on >= 99.9 %
-of pixels -- and are bit-identical too in every case tried so far."""
+tolerance is ZERO for every scene: powf / logf (Uber Schlick term, BSSRDF free flight) and atan2f / acosf (a
+sphere's uv) are glibc's algorithms restated too, so no device-libm call is left on the path."""
 import ctypes as C
 import hashlib
 import json
@@ -80,6 +79,35 @@ def test_device_powf_logf_equal_host_libm():
     assert_bit_equal(lg, hl, "device logf vs libm")
 
 
+def test_device_atan2f_acosf_equal_host_libm():
+    """A Sphere's uv (cartesian_to_spherical, read by node graphs through UV()) on the device == glibc's atan2f / acosf,
+    bit for bit: components of unit vectors, the quadrant / axis special cases, huge and tiny ratios."""
+    from pine_amd import _lib
+    libm = C.CDLL("libm.so.6")
+    libm.atan2f.restype = libm.acosf.restype = C.c_float
+    libm.atan2f.argtypes = [C.c_float, C.c_float]
+    libm.acosf.argtypes = [C.c_float]
+    rng = np.random.default_rng(13)
+    v = rng.normal(size=(200000, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    sp = np.float32([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1e-30, -1e-30, 1e30, 3e-39, np.inf, -np.inf, 0.4375, 0.6875, 1.1875, 2.4375])
+    gy, gx = np.meshgrid(sp, sp)
+    y = np.concatenate([v[:, 1], rng.uniform(-1, 1, 100000) * 10.0 ** rng.uniform(-20, 20, 100000), gy.ravel()]).astype(np.float32)
+    x = np.concatenate([v[:, 0], rng.uniform(-1, 1, 100000) * 10.0 ** rng.uniform(-20, 20, 100000), gx.ravel()]).astype(np.float32)
+    x[200000:250000] = rng.uniform(-1, 1, 50000).astype(np.float32)  # (acosf's domain)
+    a = np.zeros_like(x)
+    c = np.zeros_like(x)
+    _lib.check(_lib.lib.pine_gpu_test_atan(0, y.ctypes.data_as(_lib.c_f_p), x.ctypes.data_as(_lib.c_f_p), x.size,
+                                           a.ctypes.data_as(_lib.c_f_p), c.ctypes.data_as(_lib.c_f_p)))
+    with np.errstate(invalid="ignore"):
+        ha = np.float32([libm.atan2f(float(p), float(q)) for p, q in zip(y, x)])
+        hc = np.float32([libm.acosf(float(q)) for q in x])
+    ok = ~np.isnan(hc)
+    assert np.isnan(c[~ok]).all()
+    assert_bit_equal(a, ha, "device atan2f vs libm")
+    assert_bit_equal(c[ok], hc[ok], "device acosf vs libm")
+
+
 @pytest.mark.parametrize("spp", [1, 16, 256])
 def test_device_sampler_stream(spp):
     from pine_amd import _lib
@@ -110,9 +138,9 @@ def test_device_shape_records(which):
                                              out.ctypes.data_as(_lib.c_f_p), out.size))
     assert_bit_equal(out[..., :3], rec[..., :3], "hit / intersect / tmax")
     hit = rec[..., 1] == 1
-    # p and n bit-exact; uv of the sphere goes through device atan2f/acosf (tolerance 2 ulp-ish)
+    # p, n and uv bit-exact (a sphere's uv goes through glibc's atan2f / acosf, restated in pine_libm.h)
     assert_bit_equal(out[hit][:, 3:9], rec[hit][:, 3:9], "surface p, n")
-    np.testing.assert_allclose(out[hit][:, 9:], rec[hit][:, 9:], rtol=2e-6, atol=2e-6)
+    assert_bit_equal(out[hit][:, 9:], rec[hit][:, 9:], "surface uv")
 
 
 def _render(scene, spp, depth, **kw):

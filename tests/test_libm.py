@@ -25,3 +25,15 @@ def test_powf_logf_match_host_libm(tmp_path):
     assert out.returncode == 0, out.stdout
     for k in ("schlick_mismatch", "logf_mismatch", "pair_mismatch", "special_mismatch"):
         assert f'"{k}": 0' in out.stdout
+
+
+def test_atanf_atan2f_acosf_match_host_libm(tmp_path):
+    """atanf and acosf over ALL 2^32 arguments, atan2f over its special cases, every exponent difference and random
+    pairs (tools/check_libm_atan.cpp; its default run checks 4 x 10^9 pairs)."""
+    exe = tmp_path / "check_libm_atan"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-pthread",
+                           os.path.join(ROOT, "tools", "check_libm_atan.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "5000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    for k in ("atanf_mismatch", "acosf_mismatch", "atan2f_mismatch"):
+        assert f'"{k}": 0' in out.stdout
