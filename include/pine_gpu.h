@@ -240,6 +240,7 @@ typedef struct {
                                     accel; also $PINE_GPU_DEVICE_BVH=1.  pine_gpu_plan_stats.accel_built_on_device says what happened. */
 #define PINE_GPU_FLAG_DEBUG_FORCE_BAIL 0x100 /* test hook: the stage-queued path kernel raises its protocol-failure
                                     bail-out at once; every synchronising entry point must then FAIL (never return the film) */
+#define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are
  * dealt round-robin to `world` ranks (host-side helper; the kernels use the same mapping). */
@@ -316,6 +317,14 @@ int pine_gpu_plan_check(pine_gpu_plan*);
 /* Diagnostic builds only (-DPINE_PROFILE_SECTIONS): per-section wave-cycle sums of the last launch
  * (all zeros in the product build). */
 int pine_gpu_plan_debug_sections(pine_gpu_plan*, uint64_t out[16]);
+/* Test hook (stage-queued kernel): the per-vertex terms of path.cpp:98-121 of every path of a small film.  Called with
+ * out == NULL it switches the log on for the plan's next launches and returns the number of floats; called with a buffer
+ * after a launch it copies the log: 16 floats per radiance() invocation at
+ * [((y * W + x) * spp + sample) * max_path_length + level] = kind (0 miss, 1 emissive, 2 path-length limit, 3 shaded) |
+ * length | direct term (3) | bs.f (3) | cosine | bs.pdf | is_delta | mis | returned light pdf (-1: none) | returned Lo (3)
+ * -- the record `pine_ref vertices` writes from the reference's own objects (tests/golden/vertices_*.npz).  The plan must have
+ * been created with PINE_GPU_FLAG_VERTEX_LOG: only two kernel variants (cbox's kinds; everything but Subsurface) carry the hook. */
+int64_t pine_gpu_plan_vertex_log(pine_gpu_plan*, float* out, int64_t capacity_floats);
 
 /* Per-sample radiance of the last launch: copies spp_eff*W*H float4 (r,g,b,vertices) to host,
  * layout [(y*W+x)*spp + s].  Test/debug aid. */
@@ -333,6 +342,16 @@ int pine_gpu_test_powlog(int device, const float* x_host, const float* y_host, i
                          float* log_out);                                           /* powf(x, y), logf(x) */
 int pine_gpu_test_atan(int device, const float* y_host, const float* x_host, int64_t n, float* atan2_out,
                        float* acos_out);                                            /* atan2f(y, x), acosf(x) */
+/* BVH traversal (bvh.cpp:321-451, 497-548) of the scene's accel for each ray (8 floats: o, d, tmin, tmax), by the nested
+ * loops of the scene-in-LDS kernel variants (flat = 0) or the flat state machine of the others (flat = 1).  Per ray
+ * 2 * cap + 5 words: [count, count test words ...] (cap words), hit, geometry, triangle, tmax bits of the closest-hit query,
+ * then [count, words ...] (cap words) and hit of the any-hit query.  A test word is a top-level primitive's geometry index
+ * or 0x40000000 | triangle index within the mesh entered last: the layout of `pine_ref bvh` (tests/golden/bvh_*.npz). */
+int pine_gpu_test_traverse(pine_gpu_scene*, int device, const float* rays_host, int64_t nrays, int flat, int cap, uint32_t* out_host);
+/* The scene's BVHs after pine_gpu_scene_build_accel: per BVH (top level first, then one per mesh in geometry order) 5 words:
+ * root, root_start, root_count, prim_base (DBvh) and the geometry index of its mesh (-1 for the top level).  Returns their
+ * number, or < 0.  With pine_gpu_scene_accel_dump this is the whole tree (tests compare it with the reference's own). */
+int pine_gpu_scene_accel_bvhs(pine_gpu_scene*, int32_t* out, int64_t capacity_words);
 int pine_gpu_test_shapes(pine_gpu_scene*, int device, const float* rays_host, int64_t nrays,
                          float* out_host, int64_t capacity);                        /* layout of oracle_shapes */
 

@@ -14,6 +14,12 @@
 //   pine_ref shapes  <scene.pscene> <rays.bin> <out.bin>   per-shape hit/intersect records
 //   pine_ref gltf <file.glb> <spp> <depth> <out.film>       the reference's own glTF import + PathIntegrator(BVH)
 //   pine_ref finalize <film.bin> <W> <H> <tonemapper> <out.u8> [out.png]   Film::finalize + flip + gamma + x256 (film.save)
+//   pine_ref bvh     <scene.pscene> <rays.bin> <tree.bin> <trav.bin>   the reference's own BVH (bvh.cpp:30-147, 453-495) as a
+//                                        canonical pre-order stream, and for every ray the primitives BVH::intersect / BVH::hit
+//                                        test, in order, with the result (bvh.cpp:321-451, 497-548)
+//   pine_ref vertices <scene.pscene> <spp> <depth> <out.bin>   per-vertex terms of every path of the film (path.cpp:42-124):
+//                                        radiance() restated around the reference's OWN intersect / light sampler / bxdf
+//                                        objects with a log; the restated loop's film is checked against render()'s
 //   pine_ref prl     <literal>...        psl::stof / stoi / to_string of each literal, and the constant
 //                                        expressions of a cbox-class script evaluated with psl::stof values
 //                                        (pins the PRL front-end's literal and vector arithmetic)
@@ -25,6 +31,10 @@
 #include <pine/core/rng.h>
 #include <pine/impl/integrator/path.h>
 #include <pine/impl/accel/bvh.h>
+// BVHImpl::hit / Intersect are templates over the per-primitive callback whose definitions live in the reference's
+// bvh.cpp, not in its header; the `bvh` command instantiates them with logging callbacks, so that translation unit is
+// compiled as part of this one -- in place, from where it lies (the archive's own bvh.o is then simply not pulled in).
+#include <pine/impl/accel/bvh.cpp>
 #ifdef PINE_REF_WITH_EMBREE
 #include <pine/impl/accel/embree.h>
 #endif
@@ -301,6 +311,52 @@ static void write_file(const char* path, const void* p, size_t n) {
   fclose(f);
 }
 
+// ---- reading the reference's private BVH members without touching its sources: explicit instantiation may name
+// private members (the usual member-pointer idiom); every object below is the reference's own, built by its own code ----
+template <typename Tag, auto Member>
+struct Rob {
+  friend constexpr auto rob(Tag) { return Member; }
+};
+struct TagTbvh { friend constexpr auto rob(TagTbvh); };
+struct TagLbvh { friend constexpr auto rob(TagLbvh); };
+struct TagIndices { friend constexpr auto rob(TagIndices); };
+struct TagNodes { friend constexpr auto rob(TagNodes); };
+template struct Rob<TagTbvh, &BVH::tbvh>;
+template struct Rob<TagLbvh, &BVH::lbvh>;
+template struct Rob<TagIndices, &BVH::indices>;
+template struct Rob<TagNodes, &BVHImpl::nodes>;
+
+// Canonical pre-order stream of one BVHImpl (independent of how nodes are numbered): an inner node is its two child boxes
+// (12 floats: lower, upper of child 0, then of child 1) followed by the two children; a child is either the word
+// 0x80000000 | n and n primitive ids (a leaf, in stored = test order), or the word 0x40000000 and an inner node.
+// `map` turns the BVH's own primitive index into the id written (top level: geometry index; mesh: triangle index).
+template <typename MapFn>
+static void bvh_stream(const BVHImpl& impl, MapFn map, std::vector<uint32_t>& out) {
+  const auto& nodes = impl.*rob(TagNodes{});
+  auto f2u = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+  auto leaf = [&](const auto& n) {
+    out.push_back(0x80000000u | uint32_t(n.primitiveIndices.size()));
+    for (int i : n.primitiveIndices) out.push_back(uint32_t(map(i)));
+  };
+  if (nodes.size() == 0) {
+    out.push_back(0x80000000u);
+    return;
+  }
+  auto rec = [&](auto&& self, int ni) -> void {
+    const auto& n = nodes[ni];
+    if (n.primitiveIndices.size()) return leaf(n);
+    out.push_back(0x40000000u);
+    for (int c = 0; c < 2; c++)
+      for (int k = 0; k < 3; k++) out.push_back(f2u(n.aabbs[c].lower[k]));
+    // (order written: lower0, lower1, then upper0, upper1 -- see below; fixed here once, the reader mirrors it)
+    for (int c = 0; c < 2; c++)
+      for (int k = 0; k < 3; k++) out.push_back(f2u(n.aabbs[c].upper[k]));
+    self(self, n.children[0]);
+    self(self, n.children[1]);
+  };
+  rec(rec, impl.rootIndex);
+}
+
 static const int kPixels[][2] = {{0, 0}, {1, 0}, {3, 5}, {127, 127}, {128, 5}, {639, 639}};
 
 int main(int argc, char** argv) {
@@ -474,6 +530,213 @@ int main(int argc, char** argv) {
     printf("expr 0.7*0.3/0.9 f32 %s\n", hex(F("0.7") * (F("0.3") / F("0.9"))).c_str());   // `/` binds before `*`
     printf("expr 0.7/0.3*0.9 f32 %s\n", hex((F("0.7") / F("0.3")) * F("0.9")).c_str());
     return 0;
+  }
+  if (cmd == "bvh" && argc == 6) {
+    Loaded L;
+    load_pscene(argv[2], L);
+    BVH accel;
+    accel.build(&L.scene);
+    const BVHImpl& tbvh = accel.*rob(TagTbvh{});
+    const auto& lbvh = accel.*rob(TagLbvh{});
+    const auto& indices = accel.*rob(TagIndices{});
+    // tree.bin: number of BVHs, then the top level (ids: geometry indices), then every mesh BVH in lbvh order preceded by
+    // the geometry index of its mesh (ids: triangle indices)
+    std::vector<uint32_t> tree;
+    tree.push_back(uint32_t(1 + lbvh.size()));
+    bvh_stream(tbvh, [&](int i) { return indices[i]; }, tree);
+    for (size_t m = 0; m < lbvh.size(); m++) {
+      tree.push_back(uint32_t(indices[m]));
+      bvh_stream(lbvh[m], [](int i) { return i; }, tree);
+    }
+    write_file(argv[4], tree.data(), tree.size() * 4);
+    // trav.bin: per ray, closest hit then any hit: [n, n test words..., hit, geometry, triangle, tmax bits] [n, words..., hit].
+    // A test word is the geometry index of a top-level primitive (for a mesh: the entry into its BVH) or
+    // 0x40000000 | triangle index inside the mesh entered last.  The callbacks are BVH::intersect's / BVH::hit's own
+    // (bvh.cpp:497-548) with the log added.
+    std::ifstream rf(argv[3], std::ios::binary);
+    rf.seekg(0, std::ios::end);
+    size_t nbytes = rf.tellg();
+    rf.seekg(0);
+    std::vector<float> rays(nbytes / 4);
+    rf.read((char*)rays.data(), nbytes);
+    std::vector<uint32_t> trav;
+    auto& scene = L.scene;
+    for (size_t r = 0; r + 8 <= rays.size(); r += 8) {
+      const float* q = &rays[r];
+      {
+        Ray ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
+        SurfaceInteraction it;
+        std::vector<uint32_t> log;
+        uint32_t geom_index = 0, prim_index = 0;
+        bool hit = tbvh.Intersect(ray, [&](Ray& ray, int i_lbvh) {
+          auto& geometry = scene.geometries[indices[i_lbvh]];
+          log.push_back(uint32_t(indices[i_lbvh]));
+          if (i_lbvh < int(lbvh.size())) {
+            auto& mesh = geometry->shape.as<Mesh>();
+            auto h = lbvh[i_lbvh].Intersect(ray, [&](Ray& ray, int index) {
+              log.push_back(0x40000000u | uint32_t(index));
+              auto hh = mesh.intersect(ray, index);
+              if (hh) prim_index = index;
+              return hh;
+            });
+            if (h) geom_index = indices[i_lbvh];
+            return h;
+          } else {
+            auto h = geometry->intersect(ray, it);
+            if (h) geom_index = indices[i_lbvh];
+            return h;
+          }
+        });
+        trav.push_back(uint32_t(log.size()));
+        trav.insert(trav.end(), log.begin(), log.end());
+        trav.push_back(hit ? 1u : 0u);
+        trav.push_back(hit ? geom_index : 0u);
+        trav.push_back(hit ? prim_index : 0u);
+        uint32_t tb;
+        memcpy(&tb, &ray.tmax, 4);
+        trav.push_back(tb);
+      }
+      {
+        Ray ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
+        std::vector<uint32_t> log;
+        bool hit = tbvh.hit(ray, [&](const Ray& ray, int lbvhIndex) {
+          auto& geometry = scene.geometries[indices[lbvhIndex]];
+          log.push_back(uint32_t(indices[lbvhIndex]));
+          if (lbvhIndex < int(lbvh.size())) {
+            return lbvh[lbvhIndex].hit(ray, [&](const Ray& ray, int index) {
+              log.push_back(0x40000000u | uint32_t(index));
+              return geometry->shape.as<Mesh>().hit(ray, index);
+            });
+          } else {
+            return geometry->hit(ray);
+          }
+        });
+        trav.push_back(uint32_t(log.size()));
+        trav.insert(trav.end(), log.begin(), log.end());
+        trav.push_back(hit ? 1u : 0u);
+      }
+    }
+    write_file(argv[5], trav.data(), trav.size() * 4);
+    printf("{\"bvhs\": %zu, \"tree_words\": %zu, \"rays\": %zu, \"trav_words\": %zu}\n", 1 + lbvh.size(), tree.size(), rays.size() / 8, trav.size());
+    return 0;
+  }
+  if (cmd == "vertices" && argc == 6) {
+    // Per-vertex terms of path.cpp:42-124.  PathIntegrator::radiance keeps them in locals, so the loop is restated here
+    // around the reference's own objects (RTIntegrator::intersect / hit, the LightSampler, Material::sample_bxdf, BXDF::f /
+    // pdf / sample / sample_p, the Sampler): every number below is computed by the reference's code, only the control flow
+    // of radiance() is ours -- and it is checked: the film this loop produces must equal render()'s bit for bit.
+    // One record of 16 floats per radiance() invocation, in call order (depth first = path order):
+    //   0 kind (0 miss, 1 emissive, 2 path-length limit, 3 shaded)   1 pv.length   2-4 direct term (lo after NEE)
+    //   5-7 bs.f   8 cosine   9 bs.pdf   10 bs.is_delta   11 mis applied to the continuation (1 when it returned no light pdf)
+    //   12 light_pdf this invocation returns (-1: none)   13-15 Lo this invocation returns
+    // (fields that do not exist for a kind are 0; 11 is 0 when the vertex has no continuation)
+    Loaded L;
+    load_pscene(argv[2], L);
+    const int spp_req = atoi(argv[3]), depth = atoi(argv[4]);
+    struct Probe : PathIntegrator {
+      using PathIntegrator::PathIntegrator;
+      int max_len = 0;
+      std::vector<float> log;
+      struct VX { int length, diffuse_length; float pdf; bool is_delta; };
+      struct Res { vec3 Lo; psl::optional<float> light_pdf; };
+      void setup(Scene& scene) { RTIntegrator::render(scene); }
+      Res trace(Scene& scene, Ray ray, Sampler& sampler, VX pv) {
+        const size_t at = log.size();
+        log.resize(at + 16, 0.0f);
+        auto put = [&](int k, float v) { log[at + k] = v; };
+        put(1, float(pv.length));
+        put(12, -1.0f);
+        auto result = Res();
+        auto wi = -ray.d;
+        auto& Lo = result.Lo;
+        auto finish = [&](int kind) {
+          put(0, float(kind));
+          put(12, result.light_pdf ? *result.light_pdf : -1.0f);
+          put(13, Lo.x), put(14, Lo.y), put(15, Lo.z);
+          return result;
+        };
+        auto it = intersect(ray);
+        if (scene.mediums.size()) { fprintf(stderr, "vertices: scenes with media are not supported\n"); exit(2); }
+        auto Tr = transmittance(ray.o, ray.d, ray.tmax, sampler);
+        if (!it) {
+          if (scene.env_light) {
+            Lo += Tr * scene.env_light->color(ray.d);
+            if (!pv.is_delta) result.light_pdf = scene.env_light->pdf(ray.d);
+          }
+          return finish(0);
+        }
+        if (it->material().is<EmissiveMaterial>()) {
+          Lo += Tr * it->material().le({*it, wi});
+          if (!pv.is_delta) result.light_pdf = light_sampler.pdf(ray, *it);
+          return finish(1);
+        }
+        if (pv.length + 1 >= max_len) return finish(2);
+        auto bc = BxdfSampleCtx(*it, wi, 0.6f, pv.diffuse_length > 0);
+        auto bxdf = it->material().sample_bxdf(bc, sampler);
+        auto beta = vec3(1.0f);
+        bxdf.sample_p(beta, bc, sampler);
+        auto lo = vec3(0.0f);
+        if (!bxdf.is_delta()) {
+          if (auto ls = light_sampler.sample(it->p, sampler); ls && !hit(it->spawn_ray(ls->wo, ls->distance))) {
+            auto cosine = absdot(ls->wo, it->n);
+            auto tr = transmittance(it->p, ls->wo, ls->distance, sampler);
+            auto wo = it->to_local(ls->wo);
+            if (ls->light->is_delta()) {
+              auto f = bxdf.f(wo);
+              lo += ls->le * tr * cosine * f / ls->pdf;
+            } else {
+              auto f = bxdf.f(wo);
+              auto mis = balance_heuristic(ls->pdf, bxdf.pdf(wo));
+              lo += ls->le * tr * cosine * f / ls->pdf * mis;
+            }
+          }
+        }
+        put(2, lo.x), put(3, lo.y), put(4, lo.z);
+        if (auto bs = bxdf.sample(bc, sampler)) {
+          auto cosine = absdot(bs->wo, it->n);
+          auto nv = VX{pv.length + 1, pv.diffuse_length + (bs->is_delta ? 0 : 1), bs->pdf, bs->is_delta};
+          auto [Li, light_pdf] = trace(scene, it->spawn_ray(bs->wo), sampler, nv);
+          auto mis = light_pdf ? balance_heuristic(bs->pdf, *light_pdf) : 1.0f;
+          lo += Li * bs->f * (cosine / bs->pdf * mis);
+          put(5, bs->f.x), put(6, bs->f.y), put(7, bs->f.z);
+          put(8, cosine), put(9, bs->pdf), put(10, bs->is_delta ? 1.0f : 0.0f), put(11, mis);
+        }
+        Lo += min(Tr * beta * lo, vec3(8));
+        return finish(3);
+      }
+    };
+    L.scene.camera.film().clear();
+    Probe probe(Accel(BVH()), Sampler(BlueSobolSampler(spp_req)), UniformLightSampler(), depth);
+    probe.max_len = depth;
+    probe.setup(L.scene);
+    auto& film = L.scene.camera.film();
+    const int spp = BlueSobolSampler(spp_req).spp();
+    std::vector<float> mine(size_t(L.W) * L.H * 4);
+    std::vector<float> out;  // per path: count of records, then the records
+    struct Access : Probe { using Probe::samplers; };
+    for (int y = 0; y < L.H; y++)
+      for (int x = 0; x < L.W; x++) {
+        const vec2i p(x, y);
+        Sampler& sampler = (probe.*(&Access::samplers))[0].start_pixel(p, 0);
+        auto Lsum = vec3(0.0f);
+        for (int si = 0; si < spp; si++, sampler.start_next_sample()) {
+          auto ray = L.scene.camera.gen_ray((p + sampler.rand2f()) / film.size(), sampler.rand2f());
+          probe.log.clear();
+          Lsum += probe.trace(L.scene, ray, sampler, Probe::VX{0, 0, 0.0f, true}).Lo;
+          out.push_back(float(probe.log.size() / 16));
+          out.insert(out.end(), probe.log.begin(), probe.log.end());
+        }
+        const vec4 px = vec4(Lsum / spp, 1.0f);
+        memcpy(&mine[(size_t(y) * L.W + x) * 4], &px, 16);
+      }
+    // the same film by the reference's own render(): the restated loop must reproduce it bit for bit
+    L.scene.camera.film().clear();
+    auto integ = PathIntegrator(Accel(BVH()), Sampler(BlueSobolSampler(spp_req)), UniformLightSampler(), depth);
+    integ.render(L.scene);
+    const bool same = memcmp(mine.data(), L.scene.camera.film().data(), mine.size() * 4) == 0;
+    write_file(argv[5], out.data(), out.size() * 4);
+    printf("{\"paths\": %d, \"floats\": %zu, \"restated_loop_equals_render\": %s}\n", L.W * L.H * spp, out.size(), same ? "true" : "false");
+    return same ? 0 : 3;
   }
   if (cmd == "shapes" && argc == 5) {
     // For every geometry g in the scene and every ray r (8 floats: o, d, tmin, tmax):

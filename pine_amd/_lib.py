@@ -62,6 +62,7 @@ FLAG_PROGRESS = 2
 FLAG_FAST = 4
 FLAG_DEVICE_BVH = 8
 FLAG_DEBUG_FORCE_BAIL = 0x100
+FLAG_VERTEX_LOG = 0x200
 
 # every symbol include/pine_gpu.h declares, with its signature
 SIGNATURES = {
@@ -148,12 +149,15 @@ SIGNATURES = {
     "pine_gpu_plan_check": (C.c_int, [C.c_void_p]),
     "pine_gpu_plan_read_samples": (C.c_int, [C.c_void_p, c_f_p, C.c_int64]),
     "pine_gpu_plan_debug_sections": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "pine_gpu_plan_vertex_log": (C.c_int64, [C.c_void_p, c_f_p, C.c_int64]),
     "pine_gpu_test_lomuto": (C.c_int, [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pine_gpu_test_sampler": (C.c_int, [C.c_int, C.c_int, c_f_p, C.c_int64]),
     "pine_gpu_test_rng": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.c_int64]),
     "pine_gpu_test_sincos": (C.c_int, [C.c_int, c_f_p, C.c_int64, c_f_p, c_f_p]),
     "pine_gpu_test_powlog": (C.c_int, [C.c_int, c_f_p, c_f_p, C.c_int64, c_f_p, c_f_p]),
     "pine_gpu_test_atan": (C.c_int, [C.c_int, c_f_p, c_f_p, C.c_int64, c_f_p, c_f_p]),
+    "pine_gpu_test_traverse": (C.c_int, [C.c_void_p, C.c_int, c_f_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
+    "pine_gpu_scene_accel_bvhs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]),
     "pine_gpu_test_shapes": (C.c_int, [C.c_void_p, C.c_int, c_f_p, C.c_int64, c_f_p, C.c_int64]),
     "pine_gpu_film_finalize_u8": (C.c_int, [c_f_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
 }

@@ -34,6 +34,8 @@ enum : unsigned {
                           // small when the geometry count is, whatever the meshes' sizes) is staged in LDS as well
   F_XSTAGE = 1u << 15,    // with F_LDS_TOP (stage-queued kernel): traversal is a stage of its own (XS / XC queues, lanes refilled) instead
                           // of a loop inside stages S and T
+  F_VLOG = 1u << 16,      // test hook (stage-queued kernel): the per-vertex log of WorkParams::vertex_log is compiled in -- two twin
+                          // variants only (pine_variants.h), chosen by PINE_GPU_FLAG_VERTEX_LOG; every other variant carries no trace of it
   F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES | F_SOBOL,
 };
 

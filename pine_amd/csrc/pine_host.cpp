@@ -1486,6 +1486,30 @@ int64_t pine_gpu_scene_accel_dump(pine_gpu_scene* s, void* nodes_out, int64_t no
   return int64_t(a.prims.size());
 }
 
+int pine_gpu_scene_accel_bvhs(pine_gpu_scene* s, int32_t* out, int64_t cap) {
+  if (!check(s) || !out) return -1;
+  if (!s->host.accel.built) s->host.build_accel();
+  const FlatAccel& a = s->host.accel;
+  if (cap < int64_t(a.bvhs.size()) * 5) {
+    set_error("capacity too small");
+    return -1;
+  }
+  std::vector<int> mesh_geom(a.bvhs.size(), -1);
+  for (size_t g = 0; g < s->host.geometries.size(); g++) {
+    const DShape& sh = s->host.geometries[g].shape;
+    if (sh.kind == SHAPE_MESH) {
+      int b;
+      memcpy(&b, &sh.f[2], 4);
+      if (b > 0 && size_t(b) < a.bvhs.size()) mesh_geom[size_t(b)] = int(g);
+    }
+  }
+  for (size_t b = 0; b < a.bvhs.size(); b++) {
+    out[5 * b + 0] = a.bvhs[b].root, out[5 * b + 1] = a.bvhs[b].root_start, out[5 * b + 2] = a.bvhs[b].root_count;
+    out[5 * b + 3] = a.bvhs[b].prim_base, out[5 * b + 4] = mesh_geom[b];
+  }
+  return int(a.bvhs.size());
+}
+
 // Film::finalize + tone mapping + to_uint8_array (film.cpp:21-27,66-68; color.cpp:6-23;
 // fileio.cpp:42-54 with flip_y = true, apply_gamma = true)
 int pine_gpu_film_finalize_u8(const float* film, int w, int h, int tonemapper, uint8_t* out) {

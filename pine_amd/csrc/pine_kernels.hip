@@ -271,6 +271,58 @@ __global__ void test_rng_kernel(unsigned long long* out) {
   o[2] = g.s1;
   for (int i = 0; i < 16; i++) o[3 + i] = (unsigned long long)(uint32_t)as_int(rng_nextf(g));
 }
+// The primitives a ray's traversal tests, in order, and its result: the nested loops of the scene-in-LDS variants
+// (FLAT = false: scene_traverse / mesh_traverse) or the flat state machine of the F_LDS_TOP variants (pine_trav.h).
+// One thread per ray, 64 per block; out: per ray `cap` words closest (count, words...), 4 result words (hit, geometry,
+// triangle, tmax bits), `cap` words any-hit, 1 result word.
+template <bool FLAT>
+__global__ void __launch_bounds__(64) test_traverse_kernel(DeviceScene S, const float* rays, long long nrays, int cap, unsigned* out) {
+  constexpr unsigned F = FLAT ? (F_ALL | F_LDS_TOP) : F_ALL;
+  using StackT = typename std::conditional<FLAT, unsigned short, int>::type;
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  StackT* const stack = reinterpret_cast<StackT*>(lds_raw) + threadIdx.x;
+  SceneView V;
+  V.tri_verts = S.tri_verts, V.tri_leaf = S.tri_leaf, V.tri_attrs = S.tri_attrs;
+  V.lds_nodes = nullptr, V.lds_node_count = 0, V.lds_tri_entries = nullptr, V.lds_tri_verts = nullptr;
+  V.stack_top = S.stack_top, V.num_shapes = S.num_shapes;
+  V.leaf = S.leaf, V.nodes = S.nodes, V.shapes = S.shapes, V.materials = S.materials, V.bvhs = S.bvhs, V.prims = nullptr;
+  V.lights = S.lights, V.node_ops = S.node_ops;
+  const long long i = blockIdx.x * 64ll + threadIdx.x;
+  const bool live = i < nrays;
+  const float* q = rays + (live ? i : 0) * 8;
+  unsigned* o = out + (live ? i : 0) * (2ll * cap + 5);
+  for (int pass = 0; pass < 2; pass++) {
+    DRay ray{f3{q[0], q[1], q[2]}, f3{q[3], q[4], q[5]}, q[6], q[7]};
+    TravLog log{o + (pass ? cap + 4 : 0) + 1, 0, cap - 1};
+    bool hit = false;
+    int geom = 0, prim = 0;
+    if constexpr (FLAT) {
+      TravState ts;
+      trav_begin(V, ts);
+      if (!live) ts.done = 1;
+      const DRayOct oct = make_oct(ray);
+      if (pass == 0) trav_trips<false, F, 64>(V, ray, oct, ts, stack, 0, 1 << 30, nullptr, &log);
+      else trav_trips<true, F, 64>(V, ray, oct, ts, stack, 0, 1 << 30, nullptr, &log);
+      hit = ts.hit_geom >= 0;
+      geom = ts.hit_geom, prim = ts.hit_prim;
+    } else if (live) {
+      hit = pass == 0 ? scene_traverse<false, F, 64>(V, ray, stack, geom, prim, &log) : scene_traverse<true, F, 64>(V, ray, stack, geom, prim, &log);
+    }
+    if (live) {
+      o[pass ? cap + 4 : 0] = unsigned(log.n);
+      if (pass == 0) {
+        o[cap] = hit ? 1u : 0u;
+        o[cap + 1] = hit ? unsigned(geom & kPrimIndexMask) : 0u;
+        // (a mesh hit reports the triangle's index within its mesh, as the reference does; elsewhere the word is unused: 0)
+        const bool on_mesh = hit && (geom >> kPrimKindShift) == SHAPE_MESH;
+        o[cap + 2] = on_mesh ? unsigned(prim - S.bvhs[as_int(S.shapes[geom & kPrimIndexMask].f[2])].prim_base) : 0u;
+        o[cap + 3] = __float_as_uint(ray.tmax);
+      } else {
+        o[2 * cap + 4] = hit ? 1u : 0u;
+      }
+    }
+  }
+}
 __global__ void test_shapes_kernel(const DShape* shapes, int num_shapes, const float* rays, long long nrays,
                                    float* out) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -472,6 +524,7 @@ struct pine_gpu_plan {
   const PineFastVariant* fast = nullptr;  // PINE_GPU_FLAG_FAST: the declared-tolerance variant that runs instead (pine_kernels_fast.hip)
   uint32_t* d_ctxg = nullptr;
   ulonglong2* d_ckpt = nullptr;
+  float* d_vertex_log = nullptr;        // test hook (pine_gpu_plan_vertex_log)
   int* d_tile_order = nullptr;          // tile classes (WorkParams::tile_order), or null
   std::vector<int> tile_order;          // ... its host copy (empty: local tile t is film tile t * shard_world + shard_rank)
   float4* d_samples = nullptr;
@@ -557,6 +610,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_ctxg);
   (void)hipFree(p->d_ckpt);
   (void)hipFree(p->d_tile_order);
+  (void)hipFree(p->d_vertex_log);
   (void)hipFree(p->d_samples);
   (void)hipFree(p->d_fold);
   (void)hipFree(p->d_counters);
@@ -916,6 +970,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
       for (int v = 0; v < kNumQueueVariants; v++) {
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
+        if (((F & F_VLOG) != 0) != ((prm->flags & PINE_GPU_FLAG_VERTEX_LOG) != 0)) continue;  // (the test hook's twin variants)
         if ((F & F_LDS_SCENE) && !lds_ok) continue;  // (a scene-in-global variant later in the table is the fallback when LDS is short)
         if ((F & F_LDS_TOP) && A.nodes.size() > 65535) continue;  // 16-bit stack entries
         const size_t rest_bytes = size_t(S.blob_bytes - S.off_shapes);
@@ -1150,6 +1205,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (const char* e = getenv("PINE_GPU_POOL_ITEMS")) W.pool_items = atoi(e) > 0 ? atoi(e) : W.pool_items;
   if (W.serial_tiles > 0) W.pool_items = 64;  // tile classes: a claim never straddles the boundary between the classes (a multiple of 64)
   W.progress = nullptr;
+  W.vertex_log = nullptr;
   if (prm->flags & PINE_GPU_FLAG_PROGRESS) {
     HIP_OK(hipHostMalloc((void**)&p->h_progress, sizeof(unsigned long long), hipHostMallocMapped));
     *p->h_progress = 0;
@@ -1411,6 +1467,36 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
     if (rh[i]) fprintf(stderr, "region %2d: entries %llu avg active lanes %.2f\n", i, rh[i], double(rl[i]) / double(rh[i]));
 #endif
   return 0;
+}
+
+int64_t pine_gpu_plan_vertex_log(pine_gpu_plan* p, float* out, int64_t capacity) {
+  if (!p) {
+    set_error("null argument");
+    return -1;
+  }
+  if (p->queue_variant < 0 || !(kQueueVariants[p->queue_variant].features & F_VLOG)) {
+    set_error("the per-vertex log needs a plan created with PINE_GPU_FLAG_VERTEX_LOG (stage-queued kernel, the two variants compiled with the hook)");
+    return -1;
+  }
+  const int64_t n = int64_t(p->film_w) * p->film_h * p->S.spp * p->S.max_path_length * kVertexLogFloats;
+  if (n > (int64_t(1) << 27)) {
+    set_error("the per-vertex log is meant for small films (at most 2^27 floats)");
+    return -1;
+  }
+  HIP_OK(hipSetDevice(p->device));
+  if (!out) {  // switch the log on: the NEXT launches fill it
+    if (!p->d_vertex_log) HIP_OK(hipMalloc((void**)&p->d_vertex_log, size_t(n) * 4));
+    HIP_OK(hipMemset(p->d_vertex_log, 0, size_t(n) * 4));
+    p->W.vertex_log = p->d_vertex_log;
+    return n;
+  }
+  if (!p->d_vertex_log || capacity < n) {
+    set_error("vertex log not enabled, or capacity too small");
+    return -1;
+  }
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy(out, p->d_vertex_log, size_t(n) * 4, hipMemcpyDeviceToHost));
+  return n;
 }
 
 int pine_gpu_plan_read_samples(pine_gpu_plan* p, float* out, int64_t capacity) {
@@ -1722,6 +1808,43 @@ int pine_gpu_test_rng(int device, uint64_t* out, int64_t capacity) {
   hipFree(d);
   return 0;
 }
+int pine_gpu_test_traverse(pine_gpu_scene* scene, int device, const float* rays, int64_t nrays, int flat, int cap, uint32_t* out) {
+  if (!scene || !rays || !out || cap < 2 || nrays < 0) {
+    set_error("bad argument");
+    return -1;
+  }
+  if (need_device(device)) return -1;
+  // the scene as the kernels see it: a plan's device records (nothing is rendered)
+  pine_gpu_render_params prm{};
+  prm.spp = 1, prm.max_path_length = 2, prm.device = device, prm.shard_rank = 0, prm.shard_world = 1;
+  pine_gpu_plan* p = pine_gpu_plan_create(scene, &prm);
+  if (!p) return -1;
+  int rc = -1;
+  float* dr = nullptr;
+  unsigned* dout = nullptr;
+  const size_t words = size_t(nrays) * (2 * size_t(cap) + 5);
+  do {
+    if (flat && p->S.stack_total > 0 && scene_host(scene).accel.nodes.size() > 65535) {
+      set_error("the flat traversal keeps 16-bit node ids");
+      break;
+    }
+    if (hipMalloc((void**)&dr, std::max<int64_t>(nrays, 1) * 32) != hipSuccess || hipMalloc((void**)&dout, std::max<size_t>(words, 1) * 4) != hipSuccess) break;
+    if (hipMemcpy(dr, rays, nrays * 32, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dout, 0, std::max<size_t>(words, 1) * 4) != hipSuccess) break;
+    const size_t lds = size_t(std::max(1, p->S.stack_total)) * 64 * (flat ? sizeof(unsigned short) : sizeof(int));
+    if (nrays > 0) {
+      if (flat) hipLaunchKernelGGL(test_traverse_kernel<true>, dim3(unsigned((nrays + 63) / 64)), dim3(64), lds, 0, p->S, dr, (long long)nrays, cap, dout);
+      else hipLaunchKernelGGL(test_traverse_kernel<false>, dim3(unsigned((nrays + 63) / 64)), dim3(64), lds, 0, p->S, dr, (long long)nrays, cap, dout);
+    }
+    if (hipMemcpy(out, dout, words * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+    rc = 0;
+  } while (0);
+  if (rc) set_error(std::string("pine_gpu_test_traverse: ") + hipGetErrorString(hipGetLastError()));
+  (void)hipFree(dr);
+  (void)hipFree(dout);
+  pine_gpu_plan_destroy(p);
+  return rc;
+}
+
 int pine_gpu_test_shapes(pine_gpu_scene* scene, int device, const float* rays, int64_t nrays, float* out,
                          int64_t capacity) {
   if (!scene || !rays || !out) {

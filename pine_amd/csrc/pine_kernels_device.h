@@ -197,7 +197,12 @@ struct WorkParams {
   int max_pixels;   // Subsurface variants: pixels a workgroup has in flight at most
   int fork_sealed;  // Subsurface variants: a path that can make no further RNG draw hands its pixel's next sample to another context
   unsigned long long* progress;  // host-mapped word (or null): work items claimed so far, stored now and then (get_progress)
+  // Test hook (pine_gpu_plan_vertex_log; null in every ordinary launch): 16 floats per radiance() invocation at
+  // [((py * film_w + px) * spp + sample) * max_path_length + level] -- the layout of `pine_ref vertices` (oracle/ref_driver.cpp):
+  // kind | length | direct term (3) | bs.f (3) | cosine | bs.pdf | is_delta | mis | returned light pdf (-1: none) | returned Lo (3)
+  float* vertex_log;
 };
+constexpr int kVertexLogFloats = 16;
 // get_progress() (integrator.cpp:17-19): every 16th / 64th pool claim posts the claimed-item count to host memory
 __device__ __forceinline__ void post_progress(const WorkParams& W, unsigned long long claimed, unsigned shift) {
   if (W.progress && ((claimed >> shift) & 15ull) == 0ull)
@@ -210,9 +215,19 @@ __device__ __forceinline__ void post_progress(const WorkParams& W, unsigned long
 // tested inline in stored primitive order, nearer-exit child first.  The stack lives in LDS,
 // lane-interleaved ([slot][thread]) so pushes/pops are bank-conflict free.
 // ------------------------------------------------------------------------------------------------
+// Test hook (pine_gpu_test_traverse): the primitives a traversal tests, in order -- a top-level primitive's geometry
+// index, or 0x40000000 | triangle index inside the mesh entered last.  Null in every kernel (the calls fold away).
+struct TravLog {
+  unsigned* words;
+  int n, cap;
+  __device__ __forceinline__ void put(unsigned w) {
+    if (n < cap) words[n] = w;
+    n++;
+  }
+};
 template <bool ANY, int STRIDE = kBlock, unsigned F = 0, class StackT = int>
 __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh, DRay& ray,
-                                              const DRayOct& oct, StackT* stack, int sp0, int& prim_out) {
+                                              const DRayOct& oct, StackT* stack, int sp0, int& prim_out, TravLog* log = nullptr) {
   bool hit = false;
   auto leaf = [&](int start, int count) -> bool {
     for (int i = start; i < start + count; i++) {
@@ -220,6 +235,7 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
       float v[9];
       int tri;
       fetch_triangle<F>(S, i, v, tri);
+      if (log) log->put(0x40000000u | unsigned(tri - bvh.prim_base));  // (the index within its mesh, as the reference counts)
       if (ANY) {
         if (tri_hit(v, ray)) return true;
       } else if (tri_intersect(v, ray)) {
@@ -277,7 +293,7 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
 // geom_out receives the winning primitive's PACKED word (index | emissive bit | kind).
 template <bool ANY, unsigned F, int STRIDE = kBlock, class StackT = int>
 __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, StackT* stack, int& geom_out,
-                                               int& prim_out) {
+                                               int& prim_out, TravLog* log = nullptr) {
   if (S.num_shapes == 0) return false;
   const DRayOct oct = make_oct(ray);
   const DBvh top = S.bvhs[0];
@@ -290,11 +306,12 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, St
       const int kind = word >> kPrimKindShift;
       bool is_mesh = false;
       if constexpr (F & F_MESH) is_mesh = kind == SHAPE_MESH;
+      if (log) log->put(unsigned(word & kPrimIndexMask));
       if (is_mesh) {
         if constexpr (F & F_MESH) {
           const DBvh mb = S.bvhs[as_int(sh->f[2])];
           int prim = 0;
-          const bool h = mesh_traverse<ANY, STRIDE, F>(S, mb, ray, oct, stack, S.stack_top, prim);
+          const bool h = mesh_traverse<ANY, STRIDE, F>(S, mb, ray, oct, stack, S.stack_top, prim, log);
           if (ANY) {
             if (h) return true;
           } else if (h) {

@@ -88,6 +88,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   constexpr int kNQ = q_num_queues(F);            // rings in LDS
   constexpr int kNStage = q_num_stage_queues(F);  // ... of which the first kNStage are stage queues
   constexpr bool kFork = (F & F_SSS) != 0;        // sample tokens (below)
+  constexpr bool kVlog = (F & F_VLOG) != 0;       // test hook: per-vertex log (WorkParams::vertex_log)
   constexpr int QS_K = kNStage, QS_F = kNStage + 1;
   constexpr bool kTop = (F & F_LDS_TOP) != 0;         // flat traversal (pine_trav.h), node cache, 16-bit per-wave stacks
   constexpr bool kX = kTop && (F & F_XSTAGE) != 0;    // ... as stages of its own: the XS / XC queues
@@ -224,6 +225,11 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     return ctxg + size_t(gridDim.x) * kQCtx * kQCtxGlobalDwords + (size_t(blockIdx.x) * kQRing + pos) * kQTokenDwords;
   };
   auto lds_load = [](const unsigned* p) -> unsigned { return __atomic_load_n(p, __ATOMIC_RELAXED); };
+  // test hook (WorkParams::vertex_log): the record of the radiance() invocation at `level` of sample `s` of pixel pxy
+  auto vlog = [&](unsigned pxy, int s, int level) -> float* {
+    return W.vertex_log + ((size_t(pxy >> 16) * size_t(S.cam.W) + size_t(pxy & 0xffffu)) * size_t(S.spp) + size_t(s)) * size_t(S.max_path_length) * kVertexLogFloats +
+           size_t(level) * kVertexLogFloats;
+  };
 
   // push the contexts of lanes with to_s / to_t to the shade / terminal queue: ballot compaction,
   // and ONE 64-bit LDS atomic per wave reserves the slots in both rings (the two tails are one u64)
@@ -422,6 +428,10 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               cstf[CF_DX * kQCtx + id] = 0.0f;
               cstf[CF_DY * kQCtx + id] = 0.0f;
               cstf[CF_DZ * kQCtx + id] = 0.0f;
+              if (kVlog && W.vertex_log) {
+                float* r = vlog(cstu[CF_PXY * kQCtx + id], st.s_cur(), st.length());
+                r[2] = r[3] = r[4] = 0.0f;
+              }
             }
             to_term = true;
           } else {
@@ -429,6 +439,10 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               float4* q = fold_entry(id, st.length() - 1);
               const float4 e = q[0];
               q[0] = make_float4(0.0f, 0.0f, 0.0f, e.w);
+              if (kVlog && W.vertex_log) {
+                float* r = vlog(cstu[CF_PXY * kQCtx + id], st.s_cur(), st.length() - 1);
+                r[2] = r[3] = r[4] = 0.0f;
+              }
             }
             to_xc = true;  // its new ray waits in the context
           }
@@ -887,6 +901,12 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           float4* q = fold_entry(id, pv_length);
           q[0] = make_float4(nee.x, nee.y, nee.z, bs.f.x);
           q[1] = make_float4(bs.f.y, bs.f.z, cosine / bs.pdf, bs.pdf);
+          if (kVlog && W.vertex_log) {
+            float4* r = reinterpret_cast<float4*>(vlog(pxy, st.s_cur(), pv_length));
+            r[0] = make_float4(3.0f, float(pv_length), nee.x, nee.y);
+            r[1] = make_float4(nee.z, bs.f.x, bs.f.y, bs.f.z);
+            r[2] = make_float4(cosine, bs.pdf, bs.is_delta ? 1.0f : 0.0f, 0.0f);
+          }
           if constexpr (F & F_SSS) {  // this level's BSSRDF beta channel (0 = none): 2 bits in the context's global record
             const int word = pv_length >> 4, sh = 2 * (pv_length & 15);
             cg[4 + word] = (cg[4 + word] & ~(3u << sh)) | (unsigned(beta_channel) << sh);
@@ -931,6 +951,12 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             set(beta, beta_channel - 1, 3.0f);
           }
           const f3 Lo = mk3(0.0f) + vmin(mk3(1.0f) * beta * nee, mk3(8.0f));
+          if (kVlog && W.vertex_log) {
+            float4* r = reinterpret_cast<float4*>(vlog(pxy, st.s_cur(), pv_length));
+            r[0] = make_float4(3.0f, float(pv_length), nee.x, nee.y);
+            r[1] = make_float4(nee.z, 0.0f, 0.0f, 0.0f);
+            r[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          }
           cstf[CF_DX * kQCtx + id] = Lo.x;
           cstf[CF_DY * kQCtx + id] = Lo.y;
           cstf[CF_DZ * kQCtx + id] = Lo.z;
@@ -1115,6 +1141,15 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             const uint2 bf = *reinterpret_cast<const uint2*>(ctx_global(id) + 4);
             beta_flags = (unsigned long long)bf.x | ((unsigned long long)bf.y << 32);
           }
+          if (kVlog && W.vertex_log) {  // the terminal invocation's record (a shaded vertex without continuation: stage S wrote its terms)
+            float* r = vlog(cstu[CF_PXY * kQCtx + id], st.s_cur(), pv_length);
+            if (geom != -2) {
+              r[0] = geom == -1 ? 0.0f : (geom & kPrimEmissiveBit) ? 1.0f : 2.0f;
+              r[1] = float(pv_length);
+            }
+            r[12] = lp_valid ? lp : -1.0f;
+            r[13] = Lo.x, r[14] = Lo.y, r[15] = Lo.z;
+          }
           auto fold_step = [&](const float4& a, const float4& b, int level) {
             const f3 e_nee{a.x, a.y, a.z};
             const f3 e_f{a.w, b.x, b.y};
@@ -1131,6 +1166,12 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             }
             Li = mk3(0.0f) + vmin(mk3(1.0f) * beta * lo, mk3(8.0f));
             lp_valid = false;
+            if (kVlog && W.vertex_log) {
+              float* r = vlog(cstu[CF_PXY * kQCtx + id], st.s_cur(), level);
+              r[11] = mis;
+              r[12] = -1.0f;
+              r[13] = Li.x, r[14] = Li.y, r[15] = Li.z;
+            }
           };
           int level = pv_length - 1;
           for (; level >= 0; level--) {

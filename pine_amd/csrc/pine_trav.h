@@ -71,7 +71,7 @@ __device__ __forceinline__ void trav_begin(const SceneView& S, TravState& ts) {
 // the steps per ray is unchanged: primitives pending > second pending range > node > pop > mesh return.
 template <bool ANY, unsigned F, int STRIDE, class StackT>
 __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const DRayOct& oct, TravState& ts, StackT* stack, int keep_lanes,
-                                           int min_trips, int* lane_trips = nullptr) {
+                                           int min_trips, int* lane_trips = nullptr, TravLog* log = nullptr) {
   for (int trip = 0;; trip++) {
     const unsigned long long travelling = __ballot(ts.done == 0);
     if (travelling == 0) break;
@@ -118,6 +118,7 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
           float v[9];
           int tri;
           fetch_triangle<F>(S, i, v, tri);
+          if (log) log->put(0x40000000u | unsigned(tri - S.bvhs[as_int(S.shapes[ts.mesh_word & kPrimIndexMask].f[2])].prim_base));  // (index within its mesh)
           if (ANY) {
             if (tri_hit(v, ray)) {
               ts.hit_geom = 0;
@@ -135,6 +136,7 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
         const int kind = word >> kPrimKindShift;
         bool is_mesh = false;
         if constexpr (F & F_MESH) is_mesh = kind == SHAPE_MESH;
+        if (log) log->put(unsigned(word & kPrimIndexMask));
         if (is_mesh) {
           if constexpr (F & F_MESH) {
             // descend into the mesh's BVH; the top-level traversal continues when it is exhausted

@@ -80,6 +80,9 @@ const PineKernelVariant* pine_gpu_fast_variants(int* count);
   PINE_Q(5, 14, F_ALL | F_LDS_TOP, 1024, "queue: all features, walk stage, 1024 contexts, BVH top in LDS")                                  \
   /* BVHs of 65 536 nodes and more: 32-bit traversal stack, no node cache */                                                                \
   PINE_Q(6, 15, F_ALL, 1024, "queue: all features, walk stage, 1024 contexts")                                                              \
+  /* test hook: twins of variants 0 and 6 with the per-vertex log compiled in (PINE_GPU_FLAG_VERTEX_LOG; tests/test_bvh_fixtures.py) */     \
+  PINE_Q(7, 16, F_OBB | F_LDS_SCENE | F_VLOG, PINE_QCTX, "queue: rect+transformed box/diffuse, scene in LDS, per-vertex log")                \
+  PINE_Q(6, 17, (F_ALL & ~F_SSS) | F_LDS_REST | F_LDS_TOP | F_VLOG, 1024, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS, per-vertex log") \
   PINE_M(0, 0, kFBoxes | F_LDS_SCENE, 4, "rect+box/diffuse, scene in LDS")                                                                  \
   PINE_M(6, 1, kFAnalytic | F_LDS_SCENE, 2, "analytic shapes/uber, scene in LDS")                                                           \
   PINE_M(6, 2, kFAnalytic, 2, "analytic shapes/uber")                                                                                       \

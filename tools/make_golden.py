@@ -5,6 +5,7 @@ and the reference's outputs, no reference source) are committed and travel to th
 
     python tools/make_golden.py            # everything except the two 640x640 statistics
     python tools/make_golden.py --full     # also C1/C2 whole-image statistics (~1 min of CPU)
+    python tools/make_golden.py --bvh --vertices   # the reference's BVH + traversal orders, per-vertex path terms
 """
 import hashlib
 import json
@@ -164,6 +165,65 @@ def embree_fixtures(tmp):
         del os.environ["PINE_REF_ACCEL"]
 
 
+def bvh_scenes():
+    """Scenes of the BVH fixtures (SURVEY.md 8(c) fixture 4): cbox, the 10 000-cone scene of C4, a mesh scene."""
+    return {"cbox": scenes.cbox((64, 64), "readme"), "cones10k": scenes.classic_cones((720, 360), 100),
+            "sss_mesh": scenes.sss((64, 64), 2, emissive_mesh=True), "zoo": scenes.shapes_zoo((48, 48))}
+
+
+def bvh_rays(scene, n, seed):
+    """n rays for the traversal fixture: camera-like rays (from the camera position into the view cone), rays between
+    random points of the scene's extent, and short ones (finite tmax, as shadow rays have)."""
+    rng = np.random.default_rng(seed)
+    cam = scene.camera
+    frm = np.array(cam.frm, dtype=np.float64)
+    to = np.array(cam.to, dtype=np.float64)
+    rays = np.zeros((n, 8), np.float32)
+    fwd = (to - frm) / np.linalg.norm(to - frm)
+    k = n // 2
+    d = fwd[None, :] + rng.uniform(-0.35, 0.35, (k, 3))
+    rays[:k, 0:3] = frm
+    rays[:k, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:k, 7] = np.finfo(np.float32).max
+    ext = 2.0 if np.linalg.norm(frm) < 6 else 9.0
+    a = rng.uniform(-ext, ext, (n - k, 3)) * [1, 0.5, 1] + [0, 1.0, 1.0 if ext < 3 else 0.0]
+    b = rng.uniform(-ext, ext, (n - k, 3)) * [1, 0.5, 1] + [0, 0.6, 1.0 if ext < 3 else 0.0]
+    dd = b - a
+    ln = np.linalg.norm(dd, axis=1)
+    rays[k:, 0:3] = a
+    rays[k:, 3:6] = dd / ln[:, None]
+    rays[k:, 7] = np.where(rng.uniform(size=n - k) < 0.5, ln * 0.999, np.finfo(np.float32).max).astype(np.float32)
+    return rays
+
+
+def bvh_fixtures(tmp):
+    """tests/golden/bvh_<scene>.npz from `pine_ref bvh`: the reference's own BVH as a canonical pre-order stream and,
+    for 1000 rays, the primitives BVH::intersect / BVH::hit test in order with their results."""
+    for i, (name, sc) in enumerate(bvh_scenes().items()):
+        sp, rp, tp, vp = (os.path.join(tmp, f) for f in ("s.pscene", "r.bin", "tree.bin", "trav.bin"))
+        ps = sc.describe()
+        open(sp, "w").write(ps)
+        rays = bvh_rays(sc, 1000, 77 + i)
+        rays.tofile(rp)
+        info = json.loads(run_ref("bvh", sp, rp, tp, vp).strip().splitlines()[-1])
+        np.savez_compressed(os.path.join(OUT, f"bvh_{name}.npz"), pscene=ps, rays=rays, tree=np.fromfile(tp, dtype=np.uint32),
+                            trav=np.fromfile(vp, dtype=np.uint32))
+        print(name, info, os.path.getsize(os.path.join(OUT, f"bvh_{name}.npz")), "bytes")
+
+
+def vertex_fixture(tmp):
+    """tests/golden/vertices_cbox.npz from `pine_ref vertices` (SURVEY.md 8(c) fixture 5): the per-vertex terms of all
+    256 paths of an 8x8 film at 4 spp, depth 8, README camera (16 floats per radiance() invocation, ref_driver.cpp)."""
+    for name, sc, spp, depth in (("cbox", scenes.cbox((8, 8), "readme"), 4, 8), ("mats", scenes.materials_zoo((8, 8)), 4, 6)):
+        sp, vp = os.path.join(tmp, "s.pscene"), os.path.join(tmp, "v.bin")
+        ps = sc.describe()
+        open(sp, "w").write(ps)
+        info = json.loads(run_ref("vertices", sp, spp, depth, vp).strip().splitlines()[-1])
+        assert info["restated_loop_equals_render"] is True
+        np.savez_compressed(os.path.join(OUT, f"vertices_{name}.npz"), pscene=ps, spp=spp, depth=depth, records=np.fromfile(vp, dtype=np.float32))
+        print(name, info)
+
+
 def gltf_fixture(tmp):
     """SURVEY.md 8(f)4 mesh import: tests/golden/import_test.glb (tools/make_test_glb.py) through the reference's OWN importer
     (`pine_ref gltf`: load_scene -> scene_from_gltf, fileio.cpp:146-330) and PathIntegrator(BVH) -> whole-film statistics."""
@@ -186,6 +246,13 @@ def main():
     if "--gltf" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             gltf_fixture(tmp)
+        return
+    if "--bvh" in sys.argv or "--vertices" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            if "--bvh" in sys.argv:
+                bvh_fixtures(tmp)
+            if "--vertices" in sys.argv:
+                vertex_fixture(tmp)
         return
     if "--embree" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
