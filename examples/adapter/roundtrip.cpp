@@ -6,12 +6,17 @@
 //
 //   roundtrip cbox|zoo          print the mirrored scene
 //   roundtrip cbox|zoo records  print the device records (one line of 32 hex words per geometry, then the camera's 20)
+//   roundtrip cbox|zoo render <W> <H> <spp> <depth> <out.film>   GpuPathIntegrator(BlueSampler(spp), depth).render(scene) on
+//                               GPU 0 -- the call that replaces program_context.cpp:76-81 -- and the scene's own film
+//                               (Array2d<vec4>, row 0 first) written raw: tests/test_adapter.py (-m gpu) compares it with the
+//                               film the real reference rendered of the same scene
 #define private public  // out-of-tree stand-in for `friend struct GpuPathIntegrator;` (see path_gpu.h)
 #include <pine/core/scene.h>
 #undef private
 #include "path_gpu.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,6 +71,19 @@ static Scene zoo(vec2i size) {  // one of every analytic shape kind, Uber and Su
 
 int main(int argc, char** argv) {
   const std::string which = argc > 1 ? argv[1] : "cbox";
+  if (argc == 8 && std::string(argv[2]) == "render") {
+    const vec2i size(atoi(argv[3]), atoi(argv[4]));
+    Scene scene = which == "zoo" ? zoo(size) : cbox(size);
+    scene.camera.film().clear();
+    GpuPathIntegrator integ(Sampler(BlueSobolSampler(atoi(argv[5]))), atoi(argv[6]));
+    integ.render(scene);  // (aborts through SEVERE on any error, as the reference's integrators do)
+    auto& film = scene.camera.film();
+    FILE* f = fopen(argv[7], "wb");
+    if (!f || fwrite(film.data(), 16, size_t(size.x) * size.y, f) != size_t(size.x) * size.y) return 2;
+    fclose(f);
+    printf("rendered %dx%d\n", size.x, size.y);
+    return 0;
+  }
   Scene scene = which == "zoo" ? zoo(vec2i(40, 32)) : cbox(vec2i(48, 48));
   pine_gpu_scene* s = GpuPathIntegrator::mirror(scene);
   if (argc > 2 && std::string(argv[2]) == "records") {

@@ -112,3 +112,22 @@ def test_state_level_records_round_trip_through_the_python_binding(oracle):
     a, _ = oracle.render(s.describe(), (24, 24), 8, 4)
     b, _ = oracle.render(base.describe(), (24, 24), 8, 4)
     assert_bit_equal(a, b, "axis-aligned Rects given as state vs as constructor arguments")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which, name, spp, depth", [("cbox", "cbox_readme_64_s16_d4", 16, 4), ("cbox", "cbox_readme_64_s256_d8", 256, 8)])
+def test_adapter_render_end_to_end_equals_the_reference_film(tmp_path, which, name, spp, depth):
+    """GpuPathIntegrator::render (examples/adapter/path_gpu.h) -- the replacement of program_context.cpp:76-81 -- run for
+    real: a pine::Scene built with the reference's own API, mirrored onto the C ABI, rendered on GPU 0, and the film written
+    into the scene's own pine::Film.  That film must equal the film the real reference rendered of the same scene
+    (tests/golden/film_*.npz), bit for bit.  The binary is built by __graft_entry__.build() where the reference's sources
+    are (examples/adapter/roundtrip.cpp against /root/reference/src + oracle/_ref/libpine_ref.a) and travels."""
+    exe = os.path.join(ROOT, "build", "adapter_roundtrip")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("build/adapter_roundtrip not built (needs the reference sources: __graft_entry__.build() in the build container)")
+    out = tmp_path / "a.film"
+    r = subprocess.run([exe, which, "render", "64", "64", str(spp), str(depth), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    film = np.fromfile(out, dtype=np.float32).reshape(64, 64, 4)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", f"film_{name}.npz"))["film"]
+    assert_bit_equal(film, ref, f"adapter render() vs the reference's film {name}")
