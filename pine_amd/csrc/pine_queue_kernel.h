@@ -100,6 +100,23 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   constexpr int kQCtx = L::ctx, kQRing = L::ring, kQOffCtl = L::off_ctl, kQOffRing = L::off_ring, kQOffState = L::off_state,
                 kQOffSobol = L::off_sobol, kQOffWin = L::off_win, kQOffStack = L::off_stack;
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  // The kernel arguments are ~130 dwords, and the compiler keeps every one it meets inside the persistent loop in an SGPR for
+  // the whole kernel: 80 - 300 of them spilled to VGPR lanes (v_writelane / v_readlane), a few VGPRs gone at 128 per lane.
+  // The cold ones -- the camera (used once per camera sample), the sampler-table pointers, the work decomposition -- are
+  // therefore read where they are used, from the kernel-argument segment itself (scalar loads, K$ hits), through a pointer
+  // the compiler cannot see through: Sk / Wk are S / W, just not hoisted.
+  typedef const __attribute__((address_space(4))) uint32_t* KargPtr;  // (constant address space: the loads are s_load)
+  KargPtr kargs = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kargs));
+  constexpr size_t kWOffset = ((sizeof(DeviceScene) + alignof(WorkParams) - 1) / alignof(WorkParams)) * alignof(WorkParams);
+  // kS(field) / kW(field): that field of S / W, loaded here and now
+  auto kload = [&](size_t byte_offset, auto* out) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(*out) / 4; i++) o[i] = kargs[byte_offset / 4 + i];
+  };
+#define kS(FIELD) ([&] { std::remove_cv_t<decltype(S.FIELD)> v_; kload(offsetof(DeviceScene, FIELD), &v_); return v_; }())
+#define kW(FIELD) ([&] { std::remove_cv_t<decltype(W.FIELD)> v_; kload(kWOffset + offsetof(WorkParams, FIELD), &v_); return v_; }())
   constexpr int kSM = kSmLds | ((F & F_SOBOL) ? kSmSobol : 0);  // sampler front mode (pine_device.h)
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63;
@@ -494,7 +511,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 #ifdef PINE_PROFILE_SECTIONS
   if (tid == 0) atomicCAS(&counters->t_start, 0ull, wall_clock64());
 #endif
-  if (W.debug_force_bail && blockIdx.x == 0 && tid == 0) bail(7, 0, 0);  // test hook: the host must report this launch as failed
+  if (kW(debug_force_bail) && blockIdx.x == 0 && tid == 0) bail(7, 0, 0);  // test hook: the host must report this launch as failed
   __syncthreads();
   while (true) {
     SEC_MARK(10);  // push + busy release
@@ -587,7 +604,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       // may legitimately keep the last long paths of a launch for seconds
       const unsigned long long now = wall_clock64();
       if (idle_polls++ == 0) idle_since = now;
-      if (now - idle_since > W.idle_budget_ticks) {
+      if (now - idle_since > kW(idle_budget_ticks)) {
         if (lane == 0)
           bail(1, lds_load(&qctl[QC_BUSY]),
                (lds_load(&qctl[QC_TAIL]) - lds_load(&qctl[QC_HEAD])) | ((lds_load(&qctl[QC_TAIL + 1]) - lds_load(&qctl[QC_HEAD + 1])) << 16));
@@ -917,7 +934,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           if constexpr (kFork) {
             // sealed: after its first non-delta bounce a path makes no RNG draw any more (a Subsurface vertex is then
             // plain diffuse, above), so the pixel's RNG state is final for this sample and the NEXT sample can start
-            if (W.fork_sealed && !st.sealed() && st.diffuse_length() > 0) {
+            if (kW(fork_sealed) && !st.sealed() && st.diffuse_length() > 0) {
               st.set_sealed();
               release = ((st.s_cur() + 1) & (chain_spi - 1)) != 0;
               if (!release) {  // the pixel's last sample is under way: no longer "in flight" for the intake limit
@@ -1233,17 +1250,17 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             __atomic_store_n(&qctl[QC_HEAD + QS_K], kbase + kgot, __ATOMIC_RELAXED);
             want -= kgot;
             want_free = want;
-            // pixels in flight per workgroup are bounded (W.max_pixels): each one's samples then follow one another
+            // pixels in flight per workgroup are bounded (kW(max_pixels)): each one's samples then follow one another
             // quickly, and little is left half-done -- unevenly, workgroup by workgroup -- when the work-item pool runs dry
             const unsigned inflight = lds_load(&qctl[QC_PIXELS]);
-            const unsigned room = inflight < unsigned(W.max_pixels) ? unsigned(W.max_pixels) - inflight : 0u;
+            const unsigned room = inflight < unsigned(kW(max_pixels)) ? unsigned(kW(max_pixels)) - inflight : 0u;
             if (want > room) want = room;
           }
           unsigned long long nx = (unsigned long long)lds_load(&qctl[QC_PNEXT]) | ((unsigned long long)lds_load(&qctl[QC_PNEXT + 1]) << 32);
           unsigned long long en = (unsigned long long)lds_load(&qctl[QC_PEND]) | ((unsigned long long)lds_load(&qctl[QC_PEND + 1]) << 32);
           if (want != 0u && nx == en && lds_load(&qctl[QC_EXHAUSTED]) == 0u) {
-            const unsigned long long b = atomicAdd(&counters->next_item, (unsigned long long)W.pool_items);
-            if (b >= W.total_items) {
+            const unsigned long long b = atomicAdd(&counters->next_item, (unsigned long long)kW(pool_items));
+            if (b >= kW(total_items)) {
 #ifdef PINE_PROFILE_SECTIONS
               atomicCAS(&counters->t_pool_dry, 0ull, wall_clock64());
               if (blockIdx.x < 1024) counters->wg_t[blockIdx.x][1] = wall_clock64();
@@ -1257,7 +1274,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               }
 #endif
               nx = b;
-              en = b + W.pool_items < W.total_items ? b + W.pool_items : W.total_items;
+              en = b + kW(pool_items) < kW(total_items) ? b + kW(pool_items) : kW(total_items);
             }
           }
           const unsigned long long avail = en - nx;
@@ -1321,7 +1338,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         rank -= kgot;  // (wraps for the lanes served above: they no longer need an item)
         if (need_item && rank < got) {
           const unsigned long long item = base + rank;
-          const ItemInfo itf = decode_item(W, S.cam.W, S.cam.H, S.spp, item);
+          WorkParams Wl;  // (the work decomposition: cold, read from the kernel arguments here)
+          kload(kWOffset, &Wl);
+          const ItemInfo itf = decode_item(Wl, kS(cam.W), kS(cam.H), kS(spp), item);
           if (itf.valid) {  // else: pixel outside the film (border tile): take another item next round
             need_item = false;
             have_path = true;
@@ -1359,8 +1378,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const float jy = rng_nextf(g);
         cg4[0] = make_uint4(uint32_t(g.s0), uint32_t(g.s0 >> 32), uint32_t(g.s1), uint32_t(g.s1 >> 32));
         const int px = int(pxy & 0xffffu), py = int(pxy >> 16);
-        const f2 pf{(float(px) + jx) / float(S.cam.W), (float(py) + jy) / float(S.cam.H)};
-        const DRay r = camera_gen_ray(S.cam, pf, f2{lx, ly});
+        const DCamera cam = kS(cam);
+        const f2 pf{(float(px) + jx) / float(cam.W), (float(py) + jy) / float(cam.H)};
+        const DRay r = camera_gen_ray(cam, pf, f2{lx, ly});
         PackedState st{0};
         st.start_sample(s_next);
         if constexpr (kFork)
