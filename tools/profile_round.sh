@@ -21,6 +21,8 @@ for c in c4 c5; do
   cp gpurun_out/pmc_${tag}_${c}_traffic.json gpurun_out/profiles/${tag}_traffic_${c}.json
   cp gpurun_out/pmc_${tag}_${c}_traffic.json profiles/${tag}_traffic_${c}.json
 done
+# (the bench line reads its VALU figures from the latest profiles/rNN_[cX_]pmc_summary.txt: this round's)
+cp gpurun_out/profiles/${tag}_pmc_summary.txt gpurun_out/profiles/${tag}_c4_pmc_summary.txt gpurun_out/profiles/${tag}_c5_pmc_summary.txt profiles/ 2>/dev/null
 python bench.py --steps 10 --warmup 2 > gpurun_out/profiles/${tag}_bench.json 2> gpurun_out/profiles/${tag}_bench.err
 tail -1 gpurun_out/profiles/${tag}_bench.json | cut -c1-400
 cat gpurun_out/profiles/${tag}_kernel_stats.csv | cut -c1-160
