@@ -772,6 +772,24 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                 cg4[3] = make_float4(wr.d.x, wr.d.y, wr.d.z, wr.tmax);
                 st.set_dim(sampler.dimension);
                 st.set_walk(kWalkRunning);
+                if constexpr (kFork) {
+                  // The channel pick was this sample's LAST draw from the pixel's RNG: whatever the walk does (it draws
+                  // from the sampler), the vertex is then shaded with the BSSRDF lobe, a non-delta bounce, after which the
+                  // path would seal anyway.  Seal NOW and hand the pixel's next sample on: the walk's steps and the second
+                  // pass through this stage leave the pixel's chain (a chain step is T -> XC -> S instead of T -> XC -> S ->
+                  // W ... -> S).
+                  if (kW(fork_sealed) && !st.sealed()) {
+                    st.set_sealed();
+                    release = ((st.s_cur() + 1) & (chain_spi - 1)) != 0;
+                    if (!release) {
+                      const unsigned before = atomicSub(&qctl[QC_PIXELS], 1u);
+                      (void)before;
+#ifdef PINE_PROFILE_SECTIONS
+                      if (before == 1u && blockIdx.x < 1024) counters->wg_t[blockIdx.x][0] = wall_clock64();
+#endif
+                    }
+                  }
+                }
                 cstu[CF_ST * kQCtx + id] = st.v;
                 start_walk = true;
               }  // else sample_p returns nullopt: nothing changes, the vertex is shaded where it was hit
