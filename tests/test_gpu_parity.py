@@ -356,6 +356,36 @@ def test_packed_slabs_unpack_to_the_same_film():
         assert_bit_equal(film.cpu().numpy(), base, f"packed, {world} ranks")
 
 
+def test_tile_classes_under_sharding_and_packed_slabs(path_kernel):
+    """Subsurface scenes with tile classes (the shard's tiles reordered: whole-pixel tiles first): shards still sum to the
+    one-rank film, the packed slab of a rank stays in the shard's NATURAL tile order (what the gather + unpack of the
+    multi-GPU path rely on), per-sample radiance comes back in film order, and a ragged film works."""
+    import torch
+    import pine_amd as pa
+    from pine_amd import scenes
+    sc = scenes.sss((77, 45), 2)
+    base, st = _render(sc, 32, 6)
+    if path_kernel == "queue":
+        assert 0 < st.serial_tiles < 10 * 6
+    for world in (2, 3):
+        tot = np.zeros_like(base)
+        slabs = []
+        for r in range(world):
+            f, st_r = _render(sc, 32, 6, shard_rank=r, shard_world=world)
+            tot += f
+            plan = pa.Plan(sc, 32, 6, shard_rank=r, shard_world=world)
+            slab = torch.full((plan.slab_floats(),), -7.0, dtype=torch.float32, device="cuda")
+            plan.launch_packed(slab.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            slabs.append(slab)
+            plan.close()
+        assert_bit_equal(tot, base, f"subsurface scene, {world} shards")
+        film = torch.full((45, 77, 4), -1.0, dtype=torch.float32, device="cuda")
+        pa.film_unpack((77, 45), world, torch.stack(slabs).data_ptr(), film.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_equal(film.cpu().numpy(), base, f"subsurface scene packed, {world} ranks")
+
+
 def test_edge_cases():
     import pine_amd as pa
     # empty scene: every ray misses -> black film with w = 1 (path.cpp:38,75-81)

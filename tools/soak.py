@@ -23,6 +23,10 @@ configs = [
     ("sss 24x24 x256", scenes.sss((24, 24), 1), 256, 6, {}),
     ("sss + emissive mesh", scenes.sss((40, 40), 2, emissive_mesh=True), 32, 6, {}),
     ("classic20", scenes.classic_cones((180, 90), 20), 16, 6, {}),
+    # tile classes: whole-pixel tiles first, independent items after; a shard; a film of one whole-pixel tile and little else
+    ("sss 200x120 x64", scenes.sss((200, 120), 2), 64, 8, {}),
+    ("sss 96x96 shard 1/3", scenes.sss((96, 96), 2), 64, 8, dict(shard_rank=1, shard_world=3)),
+    ("sss 16x16 x256", scenes.sss((16, 16), 1), 256, 8, {}),
 ]
 plans = []
 for name, sc, spp, d, kw in configs:
