@@ -37,6 +37,7 @@ int pine_gpu_plan_stats_get(pine_gpu_plan*, pine_gpu_plan_stats*) { return fail(
 int pine_gpu_plan_check(pine_gpu_plan*) { return fail(); }
 int pine_gpu_plan_debug_sections(pine_gpu_plan*, uint64_t*) { return fail(); }
 int pine_gpu_plan_read_samples(pine_gpu_plan*, float*, int64_t) { return fail(); }
+int64_t pine_gpu_plan_vertex_log(pine_gpu_plan*, float*, int64_t) { return fail(); }
 int64_t pine_gpu_packed_slab_floats(int film_w, int film_h, int world) {
   if (film_w <= 0 || film_h <= 0 || world < 1) return -1;
   const int64_t tiles = int64_t((film_w + 7) / 8) * ((film_h + 7) / 8);
@@ -58,5 +59,7 @@ int pine_gpu_test_sampler(int, int, float*, int64_t) { return fail(); }
 int pine_gpu_test_rng(int, uint64_t*, int64_t) { return fail(); }
 int pine_gpu_test_sincos(int, const float*, int64_t, float*, float*) { return fail(); }
 int pine_gpu_test_powlog(int, const float*, const float*, int64_t, float*, float*) { return fail(); }
+int pine_gpu_test_atan(int, const float*, const float*, int64_t, float*, float*) { return fail(); }
+int pine_gpu_test_traverse(pine_gpu_scene*, int, const float*, int64_t, int, int, uint32_t*) { return fail(); }
 int pine_gpu_test_shapes(pine_gpu_scene*, int, const float*, int64_t, float*, int64_t) { return fail(); }
 }
