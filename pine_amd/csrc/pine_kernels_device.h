@@ -302,6 +302,16 @@ __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, St
     for (int i = start; i < start + count; i++) {
       REGION(ANY ? 5 : 2);  // leaf primitive test
       const DShape* sh = &S.leaf[i];
+      // the whole record in one batch of loads before the kind is looked at (one round trip instead of kind, then the
+      // kind's fields: C2 13.20 -> 13.06 ms; see pine_trav.h)
+      DShape rec;
+      {
+        const uint4* src = reinterpret_cast<const uint4*>(sh);
+        uint4* dst = reinterpret_cast<uint4*>(&rec);
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = src[q];
+        sh = &rec;
+      }
       const int word = sh->kind;  // (the packed word rides in the copy's kind field)
       const int kind = word >> kPrimKindShift;
       bool is_mesh = false;
