@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PINE_GPU_ABI_VERSION 2
+#define PINE_GPU_ABI_VERSION 3
 
 typedef struct pine_gpu_scene pine_gpu_scene; /* replaces pine::Scene, src/pine/core/scene.h:14-43 */
 typedef struct pine_gpu_plan pine_gpu_plan;   /* a PathIntegrator bound to a scene + device state */
