@@ -210,7 +210,33 @@ def measured_traffic(name, kernel, world):
     return None
 
 
-def side_config(name, steps, warmup, device, fast=False):
+def want_specialised():
+    """The scene-specialised path kernel (PINE_GPU_FLAG_SPECIALIZE: same arithmetic, bit-identical film) is what the bench
+    runs where the scene qualifies; PINE_BENCH_SPECIALIZE=0 measures the precompiled kernels only."""
+    return os.environ.get("PINE_BENCH_SPECIALIZE", "1") != "0"
+
+
+def make_plan(scene, spp, depth, specialize, **kw):
+    """(plan, note): the plan with the scene-specialised kernel if asked for and buildable here, else the precompiled one
+    with the reason (a box without hipcc can still run the bench; the library itself fails loudly, as it should)."""
+    import pine_amd
+    if specialize:
+        try:
+            return pine_amd.Plan(scene, spp, depth, specialize=True, **kw), None
+        except pine_amd.PineError as e:
+            if "specialisation" not in str(e):
+                raise
+            return pine_amd.Plan(scene, spp, depth, **kw), str(e)[:300]
+    return pine_amd.Plan(scene, spp, depth, **kw), None
+
+
+def kernel_note(st, err=None):
+    if st.specialized:
+        return "scene-specialised (PINE_GPU_FLAG_SPECIALIZE: compiled for this scene at plan creation, %.0f ms; bit-identical film)" % st.specialize_ms
+    return "precompiled" + (" (specialisation failed: " + err + ")" if err else "")
+
+
+def side_config(name, steps, warmup, device, fast=False, specialize=None):
     """One of the other BASELINE configs on this GPU, measured like the headline (N = 1): K timed renders
     bracketed by synchronisation, kernel time from the library's HIP events, md5 against the reference's.
     fast=True: the same with PINE_GPU_FLAG_FAST (declared-tolerance arithmetic) -- reported beside the exact
@@ -221,7 +247,9 @@ def side_config(name, steps, warmup, device, fast=False):
     build, spp, depth, text, key = _configs()[name]
     scene = build()
     W, H = scene.camera.film().size
-    plan = pine_amd.Plan(scene, spp, depth, device=device, timing=True, flags=_lib.FLAG_FAST if fast else 0)
+    if specialize is None:
+        specialize = want_specialised() and not fast
+    plan, spec_err = make_plan(scene, spp, depth, specialize, device=device, timing=True, flags=_lib.FLAG_FAST if fast else 0)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(warmup):
@@ -237,6 +265,7 @@ def side_config(name, steps, warmup, device, fast=False):
     host_film = film.cpu().numpy()
     md5 = hashlib.md5(host_film.tobytes()).hexdigest()
     want = golden_md5(key)
+    kernel_used = kernel_note(st, spec_err)
     rl = roofline_entry(st, st.camera_samples, st.vertices, None if fast else measured_traffic(name, "path_queue_kernel" if st.block_threads == 1024 else "path_trace_kernel", 1),
                         None if fast else name)
     if fast:
@@ -262,7 +291,7 @@ def side_config(name, steps, warmup, device, fast=False):
            "value": st.camera_samples * steps / dt * 1e-6, "unit": "Msamples/s", "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "vertices_per_sample": st.vertices / st.camera_samples,
            "walk_steps_per_sample": st.walk_steps / st.camera_samples,
-           "samples_per_item": st.samples_per_item, "roofline": rl,
+           "samples_per_item": st.samples_per_item, "kernel": kernel_used, "roofline": rl,
            "kernels_ms": {"prepass": st.prepass_ms, "path_trace": st.trace_ms, "resolve": st.resolve_ms},
            "plan_ms": {"accel_build_host": st.accel_build_ms, "upload": st.upload_ms},
            "film_md5": md5, "reference_md5": want, "film_equals_reference": (md5 == want) if want else None}
@@ -272,7 +301,7 @@ def side_config(name, steps, warmup, device, fast=False):
     return out
 
 
-def measure(name, steps, warmup, env, spi=0):
+def measure(name, steps, warmup, env, spi=0, specialize=None):
     """K timed renders of one config, sharded over the job's ranks (every rank calls this): W untimed steps, barrier +
     synchronize, K steps without host synchronisation, barrier + synchronize, MAX over ranks.  Returns a dict on every rank
     (film / statistics of rank 0's view; totals summed over ranks)."""
@@ -282,8 +311,8 @@ def measure(name, steps, warmup, env, spi=0):
     build, SPP, DEPTH, workload, stats_key = _configs()[name]
     scene = build()
     W, H = scene.camera.film().size
-    plan = pine_amd.Plan(scene, SPP, DEPTH, device=local_rank, shard_rank=rank, shard_world=world,
-                         samples_per_item=spi, timing=True)
+    plan, spec_err = make_plan(scene, SPP, DEPTH, want_specialised() if specialize is None else specialize, device=local_rank,
+                               shard_rank=rank, shard_world=world, samples_per_item=spi, timing=True)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
@@ -368,7 +397,7 @@ def measure(name, steps, warmup, env, spi=0):
     res = {"name": name, "scene": scene, "plan": plan, "film": film, "st": st, "dt": dt, "steps": steps, "warmup": warmup,
            "size": (W, H), "spp": SPP, "depth": DEPTH, "workload": workload, "stats_key": stats_key,
            "local_samples": local_samples, "verts": verts, "total_samples": total_samples, "total_verts": total_verts,
-           "collective": collective, "overlap": bool(overlap) if use_dist else None, "stream": stream}
+           "collective": collective, "overlap": bool(overlap) if use_dist else None, "stream": stream, "spec_err": spec_err}
     return res
 
 
@@ -395,21 +424,41 @@ def host_side_figures(res, steps, device):
     out = {"host_resident": {"value": samples * steps / dt * 1e-6, "unit": "Msamples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                              "what": "launch -> film in pinned host memory (6.55 MB device-to-host copy per render inside the clock); scene resident"}}
     build, SPP, DEPTH, _, _ = _configs()[res["name"]]
-    scene2 = build()  # (a fresh scene object: its BVH is not built yet)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    plan2 = pine_amd.Plan(scene2, SPP, DEPTH, device=device)
-    plan2.launch(film.data_ptr(), stream)
-    host.copy_(film, non_blocking=True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st2 = plan2.stats()
-    out["including_build_and_upload"] = {
-        "value": samples / dt * 1e-6, "unit": "Msamples/s", "ms": dt * 1e3,
-        "accel_build_host_ms": st2.accel_build_ms, "alloc_and_upload_ms": st2.upload_ms,
-        "what": "ONE cold render: plan creation (host BVH build + flattening, device allocation, upload of scene records and the 320 KB of sampler "
-                "tables), launch, film to pinned host memory; the process's HIP module is already loaded"}
-    plan2.close()
+    specialised = bool(res["st"].specialized)
+
+    def cold(specialize):
+        scene2 = build()  # (a fresh scene object: its BVH is not built yet)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan2, _ = make_plan(scene2, SPP, DEPTH, specialize, device=device)
+        plan2.launch(film.data_ptr(), stream)
+        host.copy_(film, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st2 = plan2.stats()
+        plan2.close()
+        return {"value": samples / dt * 1e-6, "unit": "Msamples/s", "ms": dt * 1e3, "accel_build_host_ms": st2.accel_build_ms,
+                "alloc_and_upload_ms": st2.upload_ms, "specialize_ms": st2.specialize_ms, "specialized": bool(st2.specialized)}
+
+    out["including_build_and_upload"] = cold(specialised)
+    out["including_build_and_upload"]["what"] = (
+        "ONE cold render: plan creation (host BVH build + flattening, device allocation, upload of scene records and the 320 KB of sampler "
+        "tables" + (", the scene's kernel fetched from the on-disk cache and loaded" if specialised else "") + "), launch, film to pinned host memory; "
+        "the process's HIP module is already loaded")
+    if specialised:
+        # ... the same with the precompiled kernel, and with an EMPTY kernel cache (hipcc runs: the first render of a new scene ever)
+        out["including_build_and_upload_precompiled"] = cold(False)
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            keep = os.environ.get("PINE_GPU_CACHE_DIR")
+            os.environ["PINE_GPU_CACHE_DIR"] = tmp
+            try:
+                out["including_build_upload_and_kernel_compile"] = cold(True)
+            finally:
+                if keep is None:
+                    del os.environ["PINE_GPU_CACHE_DIR"]
+                else:
+                    os.environ["PINE_GPU_CACHE_DIR"] = keep
     return out
 
 
@@ -476,6 +525,7 @@ def main():
                            "film": list(r["size"]), "spp_effective": s_.spp_effective, "max_path_length": r["depth"],
                            "parallelism": f"tiles8x8-roundrobin x{world}", "collective": r["collective"],
                            "overlap_gather_with_next_render": r["overlap"],
+                           "kernel": kernel_note(s_, r.get("spec_err")),
                            "samples_per_item": s_.samples_per_item, "serial_tiles": s_.serial_tiles,
                            "grid_blocks": s_.grid_blocks, "vertices_per_sample": r["total_verts"] / r["total_samples"]},
                 "roofline": roofline_entry(s_, r["local_samples"], r["verts"], measured_traffic(r["name"], kernel, world), r["name"] if world == 1 else None),
@@ -502,14 +552,34 @@ def main():
                 out.update(host_side_figures(res, max(2, args.steps // 2), local_rank))
             except Exception as e:  # report, keep the headline
                 out["host_resident"] = {"error": str(e)[:300]}
-        if world == 1 and not args.no_configs and args.config == "c2":
+        if world == 1 and st.specialized:
+            # the same K renders with the precompiled kernel (what a caller without the flag, or a box without hipcc, gets)
             res["plan"].close()
             res["plan"] = None
+            try:
+                g_res = measure(args.config, max(2, args.steps // 2), 1, env, args.spi, specialize=False)
+                g = line_of(g_res)
+                g_res["plan"].close()
+                out["precompiled_kernel"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "kernels_ms", "film_equals_reference")}
+                out["precompiled_kernel"]["roofline_frac"] = g["roofline"]["frac"]
+            except Exception as e:
+                out["precompiled_kernel"] = {"error": str(e)[:300]}
+        if world == 1 and not args.no_configs and args.config == "c2":
+            if res["plan"] is not None:
+                res["plan"].close()
+            res["plan"] = None
             out["configs"] = []
-            for name, k, w, fast in (("c2r", 5, 1, False), ("c3", 3, 1, False), ("c4", 5, 1, False), ("c5", 2, 1, False),
-                                     ("c2", 5, 1, True), ("c4", 5, 1, True), ("c5", 2, 1, True)):
+            spec = want_specialised()
+            for name, k, w, fast, specialize in (("c2r", 5, 1, False, spec), ("c3", 3, 1, False, spec), ("c4", 5, 1, False, spec), ("c5", 2, 1, False, spec),
+                                                 ("c2r", 5, 1, False, False), ("c3", 3, 1, False, False),
+                                                 ("c2", 5, 1, True, False), ("c4", 5, 1, True, False), ("c5", 2, 1, True, False)):
+                if not specialize and not fast and name in ("c2r", "c3") and not spec:
+                    continue  # (already measured with the precompiled kernel above)
                 try:
-                    out["configs"].append(side_config(name, k, w, local_rank, fast))
+                    e = side_config(name, k, w, local_rank, fast, specialize)
+                    if not fast and not specialize and spec and name in ("c2r", "c3"):
+                        e["config"] = name + "_precompiled"
+                    out["configs"].append(e)
                 except Exception as e:  # report, keep the headline
                     out["configs"].append({"config": name + ("_fast" if fast else ""), "error": str(e)[:300]})
         if world == 1 and not args.no_cpu:

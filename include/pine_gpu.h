@@ -240,6 +240,13 @@ typedef struct {
                                     accel; also $PINE_GPU_DEVICE_BVH=1.  pine_gpu_plan_stats.accel_built_on_device says what happened. */
 #define PINE_GPU_FLAG_DEBUG_FORCE_BAIL 0x100 /* test hook: the stage-queued path kernel raises its protocol-failure
                                     bail-out at once; every synchronising entry point must then FAIL (never return the film) */
+#define PINE_GPU_FLAG_SPECIALIZE 0x400 /* compile the path kernel FOR THIS SCENE at plan creation: small scenes (the whole scene in LDS, no
+                                    meshes, a BVH of a few nodes: cbox-class) get their BVH and every primitive record baked
+                                    into the kernel as immediates, the traversal fully unrolled -- same arithmetic, same order,
+                                    bit-identical films, cbox 18 % faster.  Costs one `hipcc --genco` run (seconds; cached on
+                                    disk by content) and needs hipcc and this library's device headers at run time; scenes that
+                                    do not qualify render with the precompiled kernels.  Also $PINE_GPU_SPECIALIZE=1 (every
+                                    plan) / =0 (never). */
 #define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are
@@ -302,7 +309,18 @@ typedef struct {
   int32_t serial_tiles;      /* tile classes (Subsurface scenes): 8x8 tiles of this shard whose pixels are one whole-pixel item each
                               * because a camera ray of theirs can reach a Subsurface shape; the others' samples are independent
                               * items of samples_per_item samples.  0: one class (samples_per_item describes every item) */
+  int32_t specialized;       /* 1: the path kernel was compiled for this scene (PINE_GPU_FLAG_SPECIALIZE); 0: a precompiled one */
+  float specialize_ms;       /* host: generating + compiling (or fetching from the cache) + loading that kernel at plan creation */
 } pine_gpu_plan_stats;
+/* PINE_GPU_FLAG_SPECIALIZE, host half: the text plan creation would compile for this scene (its BVH as straight-line code,
+ * boxes and primitive records as hexadecimal float literals), NUL-terminated into out[0..cap) when it fits; returns its
+ * length, 0 when the scene does not qualify (meshes, a BVH too large to unroll, a non-finite record), < 0 on error.
+ * Needs no GPU: a way to see what was compiled, and the CPU tests' handle on the generator. */
+int64_t pine_gpu_scene_specialized_source(pine_gpu_scene*, char* out, int64_t cap);
+/* ... and the compile step on its own (no GPU needed: hipcc cross-compiles): the scene's kernel for the stage-queued variant
+ * <features, ctx> (pine_variants.h) and `arch` ("gfx950"), through the same cache plan creation uses; the code object's path
+ * into path_out.  Returns 1 on a cache hit, 0 after a compiler run, < 0 on failure.  Build check + tests. */
+int pine_gpu_test_specialize_compile(pine_gpu_scene*, uint32_t features, int ctx, const char* arch, char* path_out, int64_t cap);
 /* The scene's BVH built on HIP device `device` right now (the accel is then reused by every later plan); returns the node
  * count, < 0 on failure.  pine_gpu_scene_accel_dump shows the result: identical to the host build's. */
 int pine_gpu_scene_build_accel_device(pine_gpu_scene*, int device);

@@ -54,6 +54,8 @@ class PlanStats(C.Structure):
         ("upload_ms", C.c_float),
         ("accel_built_on_device", C.c_int32),
         ("serial_tiles", C.c_int32),
+        ("specialized", C.c_int32),
+        ("specialize_ms", C.c_float),
     ]
 
 
@@ -63,12 +65,15 @@ FLAG_FAST = 4
 FLAG_DEVICE_BVH = 8
 FLAG_DEBUG_FORCE_BAIL = 0x100
 FLAG_VERTEX_LOG = 0x200
+FLAG_SPECIALIZE = 0x400
 
 # every symbol include/pine_gpu.h declares, with its signature
 SIGNATURES = {
     "pine_gpu_last_error": (C.c_char_p, []),
     "pine_gpu_progress": (C.c_float, []),
     "pine_gpu_abi_version": (C.c_int, []),
+    "pine_gpu_test_specialize_compile": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_char_p, C.c_char_p, C.c_int64]),
+    "pine_gpu_scene_specialized_source": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "pine_gpu_mat4_identity": (None, [f16]),
     "pine_gpu_mat4_translate": (None, [f3, f16]),
     "pine_gpu_mat4_scale": (None, [f3, f16]),

@@ -555,8 +555,11 @@ class Plan:
     """A PathIntegrator bound to a scene with all device state resident (bench / multi-GPU)."""
 
     def __init__(self, scene, spp, max_path_length, device=0, shard_rank=0, shard_world=1,
-                 samples_per_item=0, timing=False, sampler="blue", flags=0):
-        """spp: an int (BlueSampler(spp), or SobolSampler(spp) with sampler="sobol") or a sampler object."""
+                 samples_per_item=0, timing=False, sampler="blue", flags=0, specialize=False):
+        """spp: an int (BlueSampler(spp), or SobolSampler(spp) with sampler="sobol") or a sampler object.
+        specialize: PINE_GPU_FLAG_SPECIALIZE -- compile the path kernel for this scene when it qualifies (stats().specialized)."""
+        if specialize:
+            flags = int(flags) | _lib.FLAG_SPECIALIZE
         if scene.camera is None:
             raise PineError("scene has no camera")
         self.scene = scene
@@ -627,9 +630,12 @@ class PathIntegrator:
     """PathIntegrator(sampler, max_path_length).render(scene) -- the convenience overload a .pine
     script uses (program_context.cpp:79-81); pine-BVH traversal order, UniformLightSampler."""
 
-    def __init__(self, sampler, max_path_length, device=0, flags=0, devices=None):
+    def __init__(self, sampler, max_path_length, device=0, flags=0, devices=None, specialize=False):
         """devices: a list of HIP device ordinals -- the film is rendered by all of them from this one process
-        (pine_gpu_path_render_devices); default: the single `device`."""
+        (pine_gpu_path_render_devices); default: the single `device`.
+        specialize: PINE_GPU_FLAG_SPECIALIZE (the path kernel compiled for the scene when it qualifies; same film)."""
+        if specialize:
+            flags = int(flags) | _lib.FLAG_SPECIALIZE
         if max_path_length <= 0:  # path.cpp:12-13
             raise PineError(f"`PathIntegrator` expect `max_path_length` to be positive, get {max_path_length}")
         self.sampler, self.max_path_length, self.device, self.flags = sampler, int(max_path_length), device, int(flags)

@@ -1,6 +1,7 @@
 // pine_amd/csrc/pine_host.cpp -- host side of the C ABI: scene container, shape constructors,
 // host matrix math, pine's BVH build flattened for the GPU, film finalize.  No GPU calls here.
 #include "pine_host.h"
+#include "pine_specialize.h"
 #include "pine_bvh_build.h"
 
 #include <algorithm>
@@ -1508,6 +1509,43 @@ int pine_gpu_scene_accel_bvhs(pine_gpu_scene* s, int32_t* out, int64_t cap) {
     out[5 * b + 3] = a.bvhs[b].prim_base, out[5 * b + 4] = mesh_geom[b];
   }
   return int(a.bvhs.size());
+}
+
+int64_t pine_gpu_scene_specialized_source(pine_gpu_scene* s, char* out, int64_t cap) {
+  if (!check(s)) return -1;
+  if (!s->host.accel.built) s->host.build_accel();
+  const FlatAccel& a = s->host.accel;
+  std::vector<DShape> shapes;
+  for (auto& g : s->host.geometries) shapes.push_back(g.shape);
+  std::vector<int> words = a.prims;
+  for (size_t i = size_t(a.top_prim_begin); i < words.size(); i++) {
+    const DShape& sh = shapes[size_t(words[i])];
+    words[i] |= (s->host.materials[size_t(sh.material)].kind == MAT_EMISSIVE ? kPrimEmissiveBit : 0) | (sh.kind << kPrimKindShift);
+  }
+  const std::string text = a.top_prim_begin == 0 ? generate_baked_scene(a, shapes, words) : std::string();
+  if (out && cap > int64_t(text.size())) memcpy(out, text.c_str(), text.size() + 1);
+  return int64_t(text.size());
+}
+
+int pine_gpu_test_specialize_compile(pine_gpu_scene* s, uint32_t features, int ctx, const char* arch, char* path_out, int64_t cap) {
+  if (!check(s) || !arch) return -1;
+  const int64_t n = pine_gpu_scene_specialized_source(s, nullptr, 0);
+  if (n <= 0) {
+    if (n == 0) set_error("the scene does not qualify for specialisation");
+    return -1;
+  }
+  std::string text(size_t(n) + 1, '\0');
+  pine_gpu_scene_specialized_source(s, &text[0], n + 1);
+  text.resize(size_t(n));
+  const std::string dir = library_dir() + "/..";
+  std::string path, err;
+  bool hit = false;
+  if (!compile_baked_kernel(text, features, ctx, arch, dir + "/csrc", dir + "/../include", path, err, &hit)) {
+    set_error(err);
+    return -1;
+  }
+  if (path_out && cap > int64_t(path.size())) memcpy(path_out, path.c_str(), path.size() + 1);
+  return hit ? 1 : 0;
 }
 
 // Film::finalize + tone mapping + to_uint8_array (film.cpp:21-27,66-68; color.cpp:6-23;

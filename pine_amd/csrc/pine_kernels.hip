@@ -37,6 +37,7 @@
 
 #include "../../include/pine_gpu.h"
 #include "pine_device.h"
+#include "pine_specialize.h"
 #include "pine_variants.h"
 #include "pine_host.h"
 
@@ -545,7 +546,47 @@ struct pine_gpu_plan {
   unsigned long long* h_progress = nullptr;  // host-mapped progress word (PINE_GPU_FLAG_PROGRESS)
   float accel_build_ms = 0.0f, upload_ms = 0.0f;  // host-side cost of plan creation (reported by stats_get)
   bool accel_on_device = false;
+  // PINE_GPU_FLAG_SPECIALIZE: the queue kernel compiled for this scene (pine_specialize.h); null: the precompiled variant
+  hipModule_t spec_module = nullptr;
+  hipFunction_t spec_fn = nullptr;
+  float specialize_ms = 0.0f;
 };
+
+// PINE_GPU_FLAG_SPECIALIZE / $PINE_GPU_SPECIALIZE (pine_specialize.h): when the scene has no meshes and its BVH is small
+// enough to unroll, compile the chosen stage-queued variant with the scene baked in and use it instead.  A scene that does not qualify keeps the precompiled kernel (not an error); a qualifying scene whose kernel
+// cannot be built (no hipcc, no headers, no cache directory) fails the plan: the caller asked for it.
+static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vector<DShape>& shapes, const std::vector<int>& packed_prims,
+                           const pine_gpu_render_params* prm) {
+  bool want = (prm->flags & PINE_GPU_FLAG_SPECIALIZE) != 0;
+  if (const char* e = getenv("PINE_GPU_SPECIALIZE")) want = atoi(e) != 0;
+  if (!want || p->queue_variant < 0 || (prm->flags & (PINE_GPU_FLAG_FAST | PINE_GPU_FLAG_VERTEX_LOG))) return 0;
+  const PineKernelVariant& V = kQueueVariants[p->queue_variant];
+  if (V.features & F_XSTAGE) return 0;  // (chosen for scenes with meshes only; those do not qualify)
+  const auto t0 = std::chrono::steady_clock::now();
+  // (packed_prims: the words of A.prims from top_prim_begin on; a scene without meshes has top_prim_begin == 0)
+  if (A.top_prim_begin != 0) return 0;
+  const std::string baked = generate_baked_scene(A, shapes, packed_prims);
+  if (baked.empty()) return 0;
+  const std::string dir = library_dir() + "/..";
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, prm->device));
+  std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
+  if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
+  std::string path, err;
+  if (!compile_baked_kernel(baked, V.features, V.ctx, arch, dir + "/csrc", dir + "/../include", path, err)) {
+    set_error(err);
+    return -1;
+  }
+  std::string image;
+  if (!read_file(path, image) || image.empty()) {
+    set_error("scene specialisation: cannot read " + path);
+    return -1;
+  }
+  HIP_OK(hipModuleLoadData(&p->spec_module, image.data()));
+  HIP_OK(hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(V.features, V.ctx).c_str()));
+  p->specialize_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
 
 static int plan_check_counters(const Counters& c) {
   if (c.bail_count == 0) return 0;
@@ -614,6 +655,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   (void)hipFree(p->d_samples);
   (void)hipFree(p->d_fold);
   (void)hipFree(p->d_counters);
+  if (p->spec_module) (void)hipModuleUnload(p->spec_module);
   if (p->h_progress) (void)hipHostFree(p->h_progress);
   for (auto& slot : p->ev)
     for (auto& e : slot)
@@ -1003,6 +1045,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     }
   }
 
+  if (plan_specialize(p, A, shapes, packed_prims, prm)) return -1;
+
   if (p->variant < 0 && p->queue_variant < 0) {  // (only experiment builds lack the all-features megakernel)
     set_error("no kernel variant covers this scene");
     return -1;
@@ -1311,8 +1355,11 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
     const ulonglong2* ckpt = p->d_ckpt;
     void* args[] = {&p->S, &p->W, &ckpt, &p->d_samples, &p->d_fold, &p->d_ctxg, &p->d_counters};
     HIP_OK(hipLaunchKernel(p->fast->fn, dim3(p->grid), dim3(kQBlock), args, p->lds_bytes, stream));
-  } else if (p->queue_variant >= 0)
-  {
+  } else if (p->spec_fn) {
+    const ulonglong2* ckpt = p->d_ckpt;
+    void* args[] = {&p->S, &p->W, &ckpt, &p->d_samples, &p->d_fold, &p->d_ctxg, &p->d_counters};
+    HIP_OK(hipModuleLaunchKernel(p->spec_fn, unsigned(p->grid), 1, 1, kQBlock, 1, 1, unsigned(p->lds_bytes), stream, args, nullptr));
+  } else if (p->queue_variant >= 0) {
     const ulonglong2* ckpt = p->d_ckpt;
     void* args[] = {&p->S, &p->W, &ckpt, &p->d_samples, &p->d_fold, &p->d_ctxg, &p->d_counters};
     HIP_OK(hipLaunchKernel(kQueueVariants[p->queue_variant].fn, dim3(p->grid), dim3(kQBlock), args, p->lds_bytes, stream));
@@ -1394,6 +1441,8 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   out->spp_effective = p->S.spp;
   out->samples_per_item = p->W.samples_per_item;
   out->serial_tiles = p->W.serial_tiles;
+  out->specialized = p->spec_fn ? 1 : 0;
+  out->specialize_ms = p->specialize_ms;
   out->grid_blocks = p->grid;
   out->block_threads = (p->queue_variant >= 0 || p->fast) ? kQBlock : kBlock;
   out->lds_bytes = int(p->lds_bytes);

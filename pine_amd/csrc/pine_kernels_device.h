@@ -1042,5 +1042,12 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
 }
 
 }  // namespace pine_gpu
+#ifdef PINE_BAKED_SCENE
+// generated at plan creation (pine_specialize.h) and found on the include path of that compile: namespace-less text
+// that defines scene_traverse_baked<ANY, F>(ray, geom_out)
+namespace pine_gpu {
+#include "pine_baked_scene.inc"
+}
+#endif
 #include "pine_trav.h"
 #include "pine_queue_kernel.h"

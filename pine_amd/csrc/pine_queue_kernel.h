@@ -92,6 +92,13 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   constexpr int QS_K = kNStage, QS_F = kNStage + 1;
   constexpr bool kTop = (F & F_LDS_TOP) != 0;         // flat traversal (pine_trav.h), node cache, 16-bit per-wave stacks
   constexpr bool kX = kTop && (F & F_XSTAGE) != 0;    // ... as stages of its own: the XS / XC queues
+#ifdef PINE_BAKED_SCENE  /* scene-specialised build (pine_specialize.h): the scene's BVH and leaf records are immediates */
+  constexpr bool kBaked = true;
+  static_assert(!kX, "scenes with meshes are not specialised");
+#else
+  constexpr bool kBaked = false;
+#endif
+  constexpr bool kFlat = kTop && !kBaked;  // rays are traced by the flat traversal (a specialised build: by the scene's own code)
   static_assert(!(F & F_LDS_REST) || kTop, "F_LDS_REST is an option of the F_LDS_TOP variants");
   static_assert(!(F & F_XSTAGE) || kTop, "F_XSTAGE is an option of the F_LDS_TOP variants");
   constexpr int kQCtxGlobalDwords = q_ctx_global_dwords(F);
@@ -330,7 +337,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     if constexpr (kX) {
       cstf[CF_TMAX * kQCtx + id] = tmax;
       to_xc = true;  // traced by stage XC
-    } else if constexpr (kTop) {
+    } else if constexpr (kFlat) {
       // the flat traversal, here and now: every lane of the wave to its end
       TravState ts;
       trav_begin(V, ts);
@@ -346,7 +353,11 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
     } else {
       int geom = -1, prim = 0;
+#ifdef PINE_BAKED_SCENE
+      const bool hit = scene_traverse_baked<false, F>(ray, geom);
+#else
       const bool hit = scene_traverse<false, F, kStride>(V, ray, stack, geom, prim);
+#endif
       SEC_MARK(6);  // closest-hit traversal
       finish_hit(id, hit, ray.tmax, geom, prim, st, to_shade, to_term);
     }
@@ -814,14 +825,18 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         bool have_shadow = false;
         DRay shadow_ray{};
         auto shadow_test = [&](const DRay& sr) -> bool {
-          if constexpr (kTop) {
+          if constexpr (kFlat) {
             have_shadow = true;
             shadow_ray = sr;
             return false;  // evaluated as if visible; cleared below when the ray turns out occluded
           } else {
             DRay r = sr;
             int g2, p2;
+#ifdef PINE_BAKED_SCENE
+            return scene_traverse_baked<true, F>(r, g2);
+#else
             return scene_traverse<true, F, kStride>(V, r, stack, g2, p2);
+#endif
           }
         };
         f3 nee = mk3(0.0f);
@@ -914,7 +929,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         // ---- X variants: the shadow ray is traced by stage XS; the fold entry / result below hold the direct term as if
         // visible, and XS clears it when the ray turns out occluded ----
         const bool parked_shadow = kX && have_shadow;
-        if constexpr (kTop && !kX) {
+        if constexpr (kFlat && !kX) {
           // ... or (F_LDS_TOP variants without traversal stages) here, now that the BSDF has been sampled and little is live
           if (__ballot(have_shadow) != 0) {
             TravState sts;
