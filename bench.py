@@ -232,7 +232,8 @@ def make_plan(scene, spp, depth, specialize, **kw):
 
 def kernel_note(st, err=None):
     if st.specialized:
-        return "scene-specialised (PINE_GPU_FLAG_SPECIALIZE: compiled for this scene at plan creation, %.0f ms; bit-identical film)" % st.specialize_ms
+        return "scene-specialised (PINE_GPU_FLAG_SPECIALIZE: compiled for this scene at plan creation -- %s; %.0f ms; bit-identical film)" % (
+            "exact feature set + BVH and primitive records baked in" if st.specialized == 2 else "exact feature set", st.specialize_ms)
     return "precompiled" + (" (specialisation failed: " + err + ")" if err else "")
 
 

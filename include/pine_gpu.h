@@ -240,13 +240,15 @@ typedef struct {
                                     accel; also $PINE_GPU_DEVICE_BVH=1.  pine_gpu_plan_stats.accel_built_on_device says what happened. */
 #define PINE_GPU_FLAG_DEBUG_FORCE_BAIL 0x100 /* test hook: the stage-queued path kernel raises its protocol-failure
                                     bail-out at once; every synchronising entry point must then FAIL (never return the film) */
-#define PINE_GPU_FLAG_SPECIALIZE 0x400 /* compile the path kernel FOR THIS SCENE at plan creation: small scenes (the whole scene in LDS, no
-                                    meshes, a BVH of a few nodes: cbox-class) get their BVH and every primitive record baked
-                                    into the kernel as immediates, the traversal fully unrolled -- same arithmetic, same order,
-                                    bit-identical films, cbox 18 % faster.  Costs one `hipcc --genco` run (seconds; cached on
-                                    disk by content) and needs hipcc and this library's device headers at run time; scenes that
-                                    do not qualify render with the precompiled kernels.  Also $PINE_GPU_SPECIALIZE=1 (every
-                                    plan) / =0 (never). */
+#define PINE_GPU_FLAG_SPECIALIZE 0x400 /* compile the path kernel FOR THIS SCENE at plan creation: (1) with exactly the scene's feature
+                                    set (shape kinds, material lobes, node programs, light kinds, sampler) instead of the
+                                    nearest precompiled superset; (2) small scenes without meshes (at most 10 primitives:
+                                    cbox-class) get their BVH and every primitive record baked into the kernel as immediates,
+                                    the traversal fully unrolled.  Same arithmetic, same order: bit-identical films; cbox 20 %
+                                    faster.  Costs one `hipcc --genco` run (seconds; cached on disk by content) and needs
+                                    hipcc and this library's device headers at run time.  A scene with nothing to gain
+                                    renders with the precompiled kernel (plan stats: `specialized`); a kernel that cannot be
+                                    built fails the plan.  Also $PINE_GPU_SPECIALIZE=1 (every plan) / =0 (never). */
 #define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are
@@ -309,8 +311,11 @@ typedef struct {
   int32_t serial_tiles;      /* tile classes (Subsurface scenes): 8x8 tiles of this shard whose pixels are one whole-pixel item each
                               * because a camera ray of theirs can reach a Subsurface shape; the others' samples are independent
                               * items of samples_per_item samples.  0: one class (samples_per_item describes every item) */
-  int32_t specialized;       /* 1: the path kernel was compiled for this scene (PINE_GPU_FLAG_SPECIALIZE); 0: a precompiled one */
+  int32_t specialized;       /* PINE_GPU_FLAG_SPECIALIZE: 0 a precompiled kernel runs; 1 a kernel compiled for this scene's exact feature
+                              * set; 2 ... with the scene's BVH and primitive records baked in as well */
   float specialize_ms;       /* host: generating + compiling (or fetching from the cache) + loading that kernel at plan creation */
+  uint32_t kernel_features;  /* feature bits (pine_device.h F_*) of the path kernel in use */
+  int32_t reserved;
 } pine_gpu_plan_stats;
 /* PINE_GPU_FLAG_SPECIALIZE, host half: the text plan creation would compile for this scene (its BVH as straight-line code,
  * boxes and primitive records as hexadecimal float literals), NUL-terminated into out[0..cap) when it fits; returns its

@@ -56,6 +56,8 @@ class PlanStats(C.Structure):
         ("serial_tiles", C.c_int32),
         ("specialized", C.c_int32),
         ("specialize_ms", C.c_float),
+        ("kernel_features", C.c_uint32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -549,31 +549,40 @@ struct pine_gpu_plan {
   // PINE_GPU_FLAG_SPECIALIZE: the queue kernel compiled for this scene (pine_specialize.h); null: the precompiled variant
   hipModule_t spec_module = nullptr;
   hipFunction_t spec_fn = nullptr;
+  unsigned spec_features = 0;  // ... its feature set (the scene's own), and whether the scene's BVH is baked in
+  bool spec_baked = false;
   float specialize_ms = 0.0f;
 };
 
-// PINE_GPU_FLAG_SPECIALIZE / $PINE_GPU_SPECIALIZE (pine_specialize.h): when the scene has no meshes and its BVH is small
-// enough to unroll, compile the chosen stage-queued variant with the scene baked in and use it instead.  A scene that does not qualify keeps the precompiled kernel (not an error); a qualifying scene whose kernel
-// cannot be built (no hipcc, no headers, no cache directory) fails the plan: the caller asked for it.
+// PINE_GPU_FLAG_SPECIALIZE / $PINE_GPU_SPECIALIZE (pine_specialize.h): compile the stage-queued kernel FOR THIS SCENE.
+//  (1) its exact feature set: the precompiled variants are a handful of supersets (pine_variants.h) -- a scene of spheres
+//      under a point light runs the everything-but-Subsurface kernel and pays for every shape kind, node programs and the
+//      Sobol sampler in registers (38 spilled VGPRs).  `need` is what plan_build found in the scene; the LDS layout flags
+//      (and F_SSS, which sizes the per-context records) stay those of the chosen variant, so every buffer size computed
+//      from it stays right.
+//  (2) if the scene has no meshes and its BVH is small enough to unroll: the BVH and primitive records baked in.
+// Nothing to gain (the variant IS the exact set, nothing to bake): the precompiled kernel runs.  A kernel that cannot be
+// built (no hipcc, no headers, no cache directory) fails the plan: the caller asked for it.
 static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vector<DShape>& shapes, const std::vector<int>& packed_prims,
-                           const pine_gpu_render_params* prm) {
+                           const pine_gpu_render_params* prm, unsigned need) {
   bool want = (prm->flags & PINE_GPU_FLAG_SPECIALIZE) != 0;
   if (const char* e = getenv("PINE_GPU_SPECIALIZE")) want = atoi(e) != 0;
   if (!want || p->queue_variant < 0 || (prm->flags & (PINE_GPU_FLAG_FAST | PINE_GPU_FLAG_VERTEX_LOG))) return 0;
   const PineKernelVariant& V = kQueueVariants[p->queue_variant];
-  if (V.features & F_XSTAGE) return 0;  // (chosen for scenes with meshes only; those do not qualify)
   const auto t0 = std::chrono::steady_clock::now();
-  // (packed_prims: the words of A.prims from top_prim_begin on; a scene without meshes has top_prim_begin == 0)
-  if (A.top_prim_begin != 0) return 0;
-  const std::string baked = generate_baked_scene(A, shapes, packed_prims);
-  if (baked.empty()) return 0;
+  const unsigned kLayout = F_LDS_SCENE | F_LDS_TOP | F_LDS_REST | F_XSTAGE | F_SSS;
+  const unsigned exact = (V.features & kLayout) | need;
+  std::string baked;
+  if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0 && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr)
+    baked = generate_baked_scene(A, shapes, packed_prims);  // (F_XSTAGE: chosen for scenes with meshes only; those do not qualify)
+  if (baked.empty() && exact == V.features) return 0;
   const std::string dir = library_dir() + "/..";
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));
   std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
   if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
   std::string path, err;
-  if (!compile_baked_kernel(baked, V.features, V.ctx, arch, dir + "/csrc", dir + "/../include", path, err)) {
+  if (!compile_baked_kernel(baked, exact, V.ctx, arch, dir + "/csrc", dir + "/../include", path, err)) {
     set_error(err);
     return -1;
   }
@@ -583,7 +592,9 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
     return -1;
   }
   HIP_OK(hipModuleLoadData(&p->spec_module, image.data()));
-  HIP_OK(hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(V.features, V.ctx).c_str()));
+  HIP_OK(hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(exact, V.ctx).c_str()));
+  p->spec_features = exact;
+  p->spec_baked = !baked.empty();
   p->specialize_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }
@@ -1045,7 +1056,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     }
   }
 
-  if (plan_specialize(p, A, shapes, packed_prims, prm)) return -1;
+  if (plan_specialize(p, A, shapes, packed_prims, prm, need)) return -1;
 
   if (p->variant < 0 && p->queue_variant < 0) {  // (only experiment builds lack the all-features megakernel)
     set_error("no kernel variant covers this scene");
@@ -1441,7 +1452,9 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   out->spp_effective = p->S.spp;
   out->samples_per_item = p->W.samples_per_item;
   out->serial_tiles = p->W.serial_tiles;
-  out->specialized = p->spec_fn ? 1 : 0;
+  out->specialized = p->spec_fn ? (p->spec_baked ? 2 : 1) : 0;
+  out->kernel_features = p->spec_fn ? p->spec_features : p->fast ? p->fast->features : p->queue_variant >= 0 ? kQueueVariants[p->queue_variant].features
+                                                                                         : p->variant >= 0 ? kVariants[p->variant].features : 0u;
   out->specialize_ms = p->specialize_ms;
   out->grid_blocks = p->grid;
   out->block_threads = (p->queue_variant >= 0 || p->fast) ? kQBlock : kBlock;

@@ -111,28 +111,33 @@ def test_specialised_cbox_equals_the_reference_film(name, look, boxes):
     sc = scenes.cbox((64, 64), look, boxes)
     assert sc.describe() == ps
     film, st = _render(sc, spp, depth, specialize=True)
-    assert st.specialized == 1 and st.specialize_ms > 0
+    assert st.specialized == 2 and st.specialize_ms > 0  # (2: feature set + baked scene)
     assert_bit_equal(film, ref, f"specialised kernel vs the reference's film {name}")
 
 
 @pytest.mark.gpu
 def test_specialised_random_scenes_equal_the_precompiled_kernels():
-    """Seeded random scenes (every analytic shape, every material, BVHs with one and with two inner children): where the
-    scene qualifies the specialised film equals the generic one; where it does not the flag changes nothing."""
+    """Seeded random scenes (every analytic shape, every material and light kind, meshes, BVHs with one and with two inner
+    children).  Level 2 (at most 10 primitives, no mesh): feature set + baked scene.  Level 1 (everything else): the scene's
+    exact feature set with the generic traversal.  Either way the film equals the precompiled kernel's, bit for bit."""
     from pine_amd import scenes
-    done = 0
-    for seed in range(3000, 3030):
+    done = {1: 0, 2: 0}
+    for seed in range(3000, 3040):
         sc, spp, depth, sampler = scenes.random_scene(seed, variety=True)
-        if not _source(sc):
+        level = 2 if _source(sc) else 1
+        if done[level] >= 5:
             continue
         a, st = _render(sc, spp, depth, sampler=sampler, specialize=True)
         b, st0 = _render(sc, spp, depth, sampler=sampler)
         assert st0.specialized == 0
-        assert_bit_equal(a, b, f"random scene {seed}: specialised vs precompiled")
-        done += st.specialized
-        if done >= 6:
+        assert_bit_equal(a, b, f"random scene {seed}: specialised (level {level}) vs precompiled")
+        assert st.specialized in (0, level)  # (0: the precompiled variant already is the scene's feature set)
+        if st.specialized:
+            assert st.kernel_features & ~st0.kernel_features == 0 and (level == 2 or st.kernel_features != st0.kernel_features)
+            done[level] += 1
+        if done[1] >= 5 and done[2] >= 5:
             break
-    assert done >= 6
+    assert done[1] >= 5 and done[2] >= 5, done
 
 
 @pytest.mark.gpu
@@ -145,20 +150,27 @@ def test_specialise_under_sharding_and_by_environment(monkeypatch):
     total = np.zeros_like(whole)
     for rank in range(3):
         part, st = _render(sc, 16, 5, shard_rank=rank, shard_world=3, specialize=True)
-        assert st.specialized == 1
+        assert st.specialized == 2
         total += part
     assert_bit_equal(total, whole, "specialised shards sum to the whole film")
     monkeypatch.setenv("PINE_GPU_SPECIALIZE", "1")
     f, st = _render(sc, 16, 5)
-    assert st.specialized == 1
+    assert st.specialized == 2
     assert_bit_equal(f, whole, "PINE_GPU_SPECIALIZE=1")
     monkeypatch.setenv("PINE_GPU_SPECIALIZE", "0")
     f, st = _render(sc, 16, 5, specialize=True)
     assert st.specialized == 0
-    # a scene that does not qualify renders with the precompiled kernel, flag or not
+    # a scene with nothing to gain (a mesh: nothing to bake; its variant already is its feature set) renders with the
+    # precompiled kernel, flag or not
     monkeypatch.delenv("PINE_GPU_SPECIALIZE")
     f, st = _render(scenes.sss((32, 32), 1), 8, 4, specialize=True)
     assert st.specialized == 0
+    # a Subsurface mesh among other kinds: the everything kernel is replaced by the scene's own feature set (walk stage,
+    # sample tokens and traversal stages included)
+    sc = scenes.random_scene(4001, variety=2)[0]
+    a, st = _render(sc, 16, 6, specialize=True)
+    b, st0 = _render(sc, 16, 6)
+    assert_bit_equal(a, b, "exact feature set vs the all-features kernel")
 
 
 @pytest.mark.gpu
