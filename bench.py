@@ -472,7 +472,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the other configs' entries of the default line")
     ap.add_argument("--spi", type=int, default=0, help="samples per work item (0 = auto)")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline loop: no host-side figures, no precompiled-kernel leg, "
+                    "no other configs, no CPU leg (counter passes: every path-kernel dispatch of the run is the headline's)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu = args.no_configs = True
 
     import torch
     import pine_amd  # noqa: F401
@@ -548,12 +552,12 @@ def main():
             e["config_name"] = "c3"
             e["note"] = "BASELINE's multi-GPU workload (configs[2]) on the same ranks, measured after the headline; scaling: strong"
             out["configs"] = [e]
-        if world == 1:
+        if world == 1 and not args.headline_only:
             try:
                 out.update(host_side_figures(res, max(2, args.steps // 2), local_rank))
             except Exception as e:  # report, keep the headline
                 out["host_resident"] = {"error": str(e)[:300]}
-        if world == 1 and st.specialized:
+        if world == 1 and st.specialized and not args.headline_only:
             # the same K renders with the precompiled kernel (what a caller without the flag, or a box without hipcc, gets)
             res["plan"].close()
             res["plan"] = None

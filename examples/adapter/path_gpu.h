@@ -97,7 +97,7 @@ struct GpuPathIntegrator {
   void render(Scene& scene) {
     auto* s = mirror(scene);
     auto& film = scene.camera.film();
-    pine_gpu_render_params prm{sampler.spp(), max_path_length, /*device*/ 0, /*rank*/ 0, /*world*/ 1, 0, 0,
+    pine_gpu_render_params prm{sampler.spp(), max_path_length, /*device*/ 0, /*rank*/ 0, /*world*/ 1, 0, specialize ? PINE_GPU_FLAG_SPECIALIZE : 0,
                                sampler.is<SobolSampler>() ? PINE_GPU_SAMPLER_SOBOL : sampler.is<HaltonSampler>() ? PINE_GPU_SAMPLER_HALTON : PINE_GPU_SAMPLER_BLUE};
     // film.data() is Array2d<vec4>: W*H float4, row 0 first -- exactly the layout the ABI writes (array.h:51-55)
     const int rc = pine_gpu_path_render(s, &prm, &film.data()[0][0]);
@@ -108,6 +108,9 @@ struct GpuPathIntegrator {
 
   Sampler sampler;
   int max_path_length;
+  // compile the path kernel for the scene at hand (its exact feature set; small scenes baked in): same film, cbox 20 %
+  // faster, seconds of hipcc the first time a scene's geometry is seen (cached on disk)
+  bool specialize = false;
 };
 
 }  // namespace pine

@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
     Scene scene = which == "zoo" ? zoo(size) : cbox(size);
     scene.camera.film().clear();
     GpuPathIntegrator integ(Sampler(BlueSobolSampler(atoi(argv[5]))), atoi(argv[6]));
+    integ.specialize = getenv("ROUNDTRIP_SPECIALIZE") != nullptr;  // (the test renders both ways)
     integ.render(scene);  // (aborts through SEVERE on any error, as the reference's integrators do)
     auto& film = scene.camera.film();
     FILE* f = fopen(argv[7], "wb");

@@ -36,6 +36,8 @@ enum : unsigned {
                           // of a loop inside stages S and T
   F_VLOG = 1u << 16,      // test hook (stage-queued kernel): the per-vertex log of WorkParams::vertex_log is compiled in -- two twin
                           // variants only (pine_variants.h), chosen by PINE_GPU_FLAG_VERTEX_LOG; every other variant carries no trace of it
+  F_BAKED = 1u << 17,     // scene-specialised builds (pine_specialize.h): the scene's BVH and primitive records are baked into the kernel
+                          // (a -DPINE_BAKED_SCENE compile; the bit only makes such a kernel's name its own in profiles)
   F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES | F_SOBOL,
 };
 

@@ -1540,7 +1540,7 @@ int pine_gpu_test_specialize_compile(pine_gpu_scene* s, uint32_t features, int c
   const std::string dir = library_dir() + "/..";
   std::string path, err;
   bool hit = false;
-  if (!compile_baked_kernel(text, features, ctx, arch, dir + "/csrc", dir + "/../include", path, err, &hit)) {
+  if (!compile_baked_kernel(text, features | (1u << 17) /* F_BAKED (pine_device.h) */, ctx, arch, dir + "/csrc", dir + "/../include", path, err, &hit)) {
     set_error(err);
     return -1;
   }

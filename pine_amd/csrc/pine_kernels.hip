@@ -571,11 +571,12 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
   const PineKernelVariant& V = kQueueVariants[p->queue_variant];
   const auto t0 = std::chrono::steady_clock::now();
   const unsigned kLayout = F_LDS_SCENE | F_LDS_TOP | F_LDS_REST | F_XSTAGE | F_SSS;
-  const unsigned exact = (V.features & kLayout) | need;
+  unsigned exact = (V.features & kLayout) | need;
   std::string baked;
   if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0 && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr)
     baked = generate_baked_scene(A, shapes, packed_prims);  // (F_XSTAGE: chosen for scenes with meshes only; those do not qualify)
   if (baked.empty() && exact == V.features) return 0;
+  if (!baked.empty()) exact |= F_BAKED;
   const std::string dir = library_dir() + "/..";
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));

@@ -94,7 +94,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   constexpr bool kX = kTop && (F & F_XSTAGE) != 0;    // ... as stages of its own: the XS / XC queues
 #ifdef PINE_BAKED_SCENE  /* scene-specialised build (pine_specialize.h): the scene's BVH and leaf records are immediates */
   constexpr bool kBaked = true;
-  static_assert(!kX, "scenes with meshes are not specialised");
+  static_assert(!kX, "scenes with meshes are not baked");
+  static_assert((F & F_BAKED) != 0, "a baked build instantiates the F_BAKED name");
 #else
   constexpr bool kBaked = false;
 #endif

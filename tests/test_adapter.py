@@ -115,8 +115,9 @@ def test_state_level_records_round_trip_through_the_python_binding(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("specialize", [False, True])
 @pytest.mark.parametrize("which, name, spp, depth", [("cbox", "cbox_readme_64_s16_d4", 16, 4), ("cbox", "cbox_readme_64_s256_d8", 256, 8)])
-def test_adapter_render_end_to_end_equals_the_reference_film(tmp_path, which, name, spp, depth):
+def test_adapter_render_end_to_end_equals_the_reference_film(tmp_path, which, name, spp, depth, specialize):
     """GpuPathIntegrator::render (examples/adapter/path_gpu.h) -- the replacement of program_context.cpp:76-81 -- run for
     real: a pine::Scene built with the reference's own API, mirrored onto the C ABI, rendered on GPU 0, and the film written
     into the scene's own pine::Film.  That film must equal the film the real reference rendered of the same scene
@@ -126,7 +127,8 @@ def test_adapter_render_end_to_end_equals_the_reference_film(tmp_path, which, na
     if not os.access(exe, os.X_OK):
         pytest.skip("build/adapter_roundtrip not built (needs the reference sources: __graft_entry__.build() in the build container)")
     out = tmp_path / "a.film"
-    r = subprocess.run([exe, which, "render", "64", "64", str(spp), str(depth), str(out)], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, **({"ROUNDTRIP_SPECIALIZE": "1"} if specialize else {}))  # GpuPathIntegrator::specialize = true
+    r = subprocess.run([exe, which, "render", "64", "64", str(spp), str(depth), str(out)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     film = np.fromfile(out, dtype=np.float32).reshape(64, 64, 4)
     ref = np.load(os.path.join(ROOT, "tests", "golden", f"film_{name}.npz"))["film"]
