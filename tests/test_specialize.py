@@ -74,10 +74,11 @@ def test_specialised_kernel_compiles_for_gfx950_and_is_cached(tmp_path, monkeypa
     assert os.listdir(tmp_path / "cache") == [os.path.basename(out.value.decode())]  # (the build directory is gone)
     # the key is the GEOMETRY (BVH + records): the same room under another camera and lamp colour is the same kernel ...
     out2 = C.create_string_buffer(1024)
-    assert _lib.lib.pine_gpu_test_specialize_compile(scenes.cbox((48, 32), "committed")._h, 258, 1536, b"gfx950", out2, 1024) == 1
+    same_room, other_room = scenes.cbox((48, 32), "committed"), scenes.cbox((64, 64), "readme", False)
+    assert _lib.lib.pine_gpu_test_specialize_compile(same_room._h, 258, 1536, b"gfx950", out2, 1024) == 1
     assert out2.value == out.value
     # ... and another scene is another kernel
-    assert _lib.lib.pine_gpu_test_specialize_compile(scenes.cbox((64, 64), "readme", False)._h, 258, 1536, b"gfx950", out2, 1024) == 0
+    assert _lib.lib.pine_gpu_test_specialize_compile(other_room._h, 258, 1536, b"gfx950", out2, 1024) == 0
     assert out2.value != out.value
     # no compiler: an error that says so, not a silent fallback
     monkeypatch.setenv("PINE_GPU_HIPCC", "/nonexistent/hipcc")
