@@ -371,6 +371,11 @@ int pine_gpu_test_atan(int device, const float* y_host, const float* x_host, int
  * then [count, words ...] (cap words) and hit of the any-hit query.  A test word is a top-level primitive's geometry index
  * or 0x40000000 | triangle index within the mesh entered last: the layout of `pine_ref bvh` (tests/golden/bvh_*.npz). */
 int pine_gpu_test_traverse(pine_gpu_scene*, int device, const float* rays_host, int64_t nrays, int flat, int cap, uint32_t* out_host);
+/* ... and the BAKED traversal of a plan created with PINE_GPU_FLAG_SPECIALIZE (plan stats: specialized == 2) on the same kind of
+ * rays: per ray 4 words -- hit, geometry, tmax bits of the closest-hit query, result of the any-hit query.  Must equal the
+ * corresponding words of pine_gpu_test_traverse for every finite ray (tests/test_specialize.py: axis-parallel and grazing rays,
+ * origins on the walls, zero direction components). */
+int pine_gpu_plan_test_traverse_baked(pine_gpu_plan*, const float* rays_host, int64_t nrays, uint32_t* out_host);
 /* The scene's BVHs after pine_gpu_scene_build_accel: per BVH (top level first, then one per mesh in geometry order) 5 words:
  * root, root_start, root_count, prim_base (DBvh) and the geometry index of its mesh (-1 for the top level).  Returns their
  * number, or < 0.  With pine_gpu_scene_accel_dump this is the whole tree (tests compare it with the reference's own). */

@@ -1532,6 +1532,36 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
   return 0;
 }
 
+int pine_gpu_plan_test_traverse_baked(pine_gpu_plan* p, const float* rays, int64_t nrays, uint32_t* out) {
+  if (!p || !rays || !out || nrays <= 0) {
+    set_error("null argument");
+    return -1;
+  }
+  if (!p->spec_module || !p->spec_baked) {
+    set_error("the plan has no baked scene (PINE_GPU_FLAG_SPECIALIZE, a scene that qualifies)");
+    return -1;
+  }
+  HIP_OK(hipSetDevice(p->device));
+  hipFunction_t fn;
+  HIP_OK(hipModuleGetFunction(&fn, p->spec_module, "pine_baked_traverse_test"));
+  float* dr = nullptr;
+  unsigned* dout = nullptr;
+  int rc = -1;
+  do {
+    if (hipMalloc((void**)&dr, size_t(nrays) * 32) != hipSuccess || hipMalloc((void**)&dout, size_t(nrays) * 16) != hipSuccess) break;
+    if (hipMemcpy(dr, rays, size_t(nrays) * 32, hipMemcpyHostToDevice) != hipSuccess) break;
+    long long n = nrays;
+    void* args[] = {&dr, &n, &dout};
+    if (hipModuleLaunchKernel(fn, unsigned((nrays + 63) / 64), 1, 1, 64, 1, 1, 0, nullptr, args, nullptr) != hipSuccess) break;
+    if (hipMemcpy(out, dout, size_t(nrays) * 16, hipMemcpyDeviceToHost) != hipSuccess) break;
+    rc = 0;
+  } while (0);
+  if (rc) set_error(std::string("pine_gpu_plan_test_traverse_baked: ") + hipGetErrorString(hipGetLastError()));
+  (void)hipFree(dr);
+  (void)hipFree(dout);
+  return rc;
+}
+
 int64_t pine_gpu_plan_vertex_log(pine_gpu_plan* p, float* out, int64_t capacity) {
   if (!p) {
     set_error("null argument");

@@ -29,22 +29,28 @@ def test_generated_text_holds_the_scene():
     sc = scenes.cbox((64, 64), "readme")
     text = _source(sc)
     assert "scene_traverse_baked" in text
-    # one record per primitive of the scene, each float as an exact hexadecimal literal of the device record
+    # one record per primitive that goes through the generic tests (here: the two transformed boxes), each float an exact
+    # hexadecimal literal of the device record; the axis-aligned Rects are inline code over their non-zero components
     from pine_amd import _lib
     nshapes = len(sc.describe().split("\nshape ")) - 1
+    recs = 0
     for g in range(nshapes):
         rec = (C.c_float * 32)()
         _lib.check(_lib.lib.pine_gpu_scene_shape_record(sc._h, g, rec))
-        line = next(l for l in text.splitlines() if l.startswith(f"__device__ static constexpr float kBakedRec{g}[30]"))
-        vals = [float.fromhex(t.rstrip("f")) for t in line[line.index("{") + 1:line.index("}")].split(", ")]
+        line = [l for l in text.splitlines() if l.startswith(f"__device__ static constexpr float kBakedRec{g}[30]")]
+        if not line:
+            continue
+        vals = [float.fromhex(t.rstrip("f")) for t in line[0][line[0].index("{") + 1:line[0].index("}")].split(", ")]
         assert np.array_equal(np.float32(vals).view(np.uint32), np.frombuffer(rec, dtype=np.uint32)[:30]), g
-    # every leaf primitive is tested exactly once per visit of its leaf, in stored order: the order of first appearance in
-    # the text is the BVH's primitive order
+        recs += 1
+    assert recs == 2 and text.count("const float denom = ") == nshapes - 2
+    # every leaf primitive is tested exactly once per visit of its leaf, in stored order: the packed words assigned in the
+    # text, in order of appearance, are the BVH's primitive order
     prims = np.zeros(64, dtype=np.int32)
     nodes = np.zeros(64 * 16, dtype=np.float32)
     n = _lib.lib.pine_gpu_scene_accel_dump(sc._h, nodes.ctypes.data_as(C.c_void_p), nodes.nbytes, prims.ctypes.data_as(C.POINTER(C.c_int32)), 64)
-    order = [int(l.split("kBakedRec")[1].split("[")[0]) for l in text.splitlines() if "rec.f[k] = kBakedRec" in l]
-    assert sorted(order) == sorted(prims[:n].tolist()) and len(order) == n
+    order = [int(l.split("geom_out = ")[1].split(";")[0]) & 0x03ffffff for l in text.splitlines() if "geom_out = " in l]
+    assert order == prims[:n].tolist()
 
 
 def test_scenes_that_do_not_qualify_generate_nothing():
@@ -114,6 +120,66 @@ def test_specialised_cbox_equals_the_reference_film(name, look, boxes):
     film, st = _render(sc, spp, depth, specialize=True)
     assert st.specialized == 2 and st.specialize_ms > 0  # (2: feature set + baked scene)
     assert_bit_equal(film, ref, f"specialised kernel vs the reference's film {name}")
+
+
+def _adversarial_rays(rng, lo, hi, n):
+    """Rays that probe what the axis-aligned Rect code relies on: zero direction components (signed), axis-parallel and
+    diagonal directions, origins exactly on the walls' planes and edges, grazing directions with tiny components (huge or
+    overflowing t), short and zero-length spans, and plain random ones."""
+    lo, hi = np.float32(lo), np.float32(hi)
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    k = n // 8
+    grid = np.float32([lo[0], hi[0], 0.0, lo[1], hi[1], 1.0, lo[2], hi[2], 0.5, -0.0])
+    o[:2 * k] = rng.choice(grid, (2 * k, 3))                       # origins on planes, edges, corners
+    o[2 * k:3 * k, rng.integers(0, 3)] = rng.choice(grid, k)       # ... one coordinate on a plane
+    d[k:4 * k] = np.where(rng.random((3 * k, 3)) < 0.45, np.float32(0.0), d[k:4 * k])     # zero components
+    d[k:2 * k] = np.where(rng.random((k, 3)) < 0.3, np.float32(-0.0), d[k:2 * k])          # ... negative zeros
+    d[4 * k:5 * k] *= np.float32(10.0) ** rng.integers(-44, -20, (k, 3)).astype(np.float32)  # tiny / denormal components
+    d[5 * k:6 * k] = rng.choice(np.float32([-1, 0, 1]), (k, 3))    # axes and diagonals
+    norm = np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)
+    d = np.where(norm > 0, d / np.maximum(norm, 1e-300), d).astype(np.float32)
+    d[4 * k:5 * k, 0] = np.float32(1e-42)                          # (a denormal after normalisation, too)
+    tmin = np.zeros(n, dtype=np.float32)
+    tmax = np.full(n, np.float32(3.0e38))
+    tmax[6 * k:7 * k] = rng.uniform(0, 3, k).astype(np.float32)
+    tmax[7 * k:7 * k + k // 2] = 0.0
+    tmin[7 * k + k // 2:] = rng.uniform(0, 0.5, n - 7 * k - k // 2).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([o, d, tmin[:, None], tmax[:, None]], axis=1), dtype=np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["cbox", "cbox_rects", "axis_room"])
+def test_baked_traversal_equals_the_generic_one_ray_by_ray(which):
+    """The traversal compiled into a specialised kernel against the generic nested traversal (itself pinned against the
+    reference's BVH, tests/test_bvh_fixtures.py): same hit, same geometry, same t bits, same any-hit answer for every ray."""
+    import pine_amd as pa
+    from pine_amd import _lib, scenes
+    if which == "axis_room":
+        # every kind of axis-aligned Rect: each normal direction, flipped and not, both edge orders, negative edges, non-unit lengths
+        sc = pa.Scene()
+        sc.add("w", pa.Diffuse([0.7, 0.7, 0.7]))
+        for pos, ex, ey, flip in (([0, 0, 1], [2, 0, 0], [0, 0, 2], True), ([0, 2, 1], [0, 0, -2], [3, 0, 0], False), ([-1, 1, 1], [0, 0, 2], [0, -2, 0], True),
+                                  ([1, 1, 1], [0, 0.5, 0], [0, 0, 2], False), ([0, 1, 2], [2, 0, 0], [0, 2, 0], True), ([0.25, 0.5, 0.75], [0, 0, -0.3], [0.7, 0, 0], False),
+                                  ([0.3, 1.0, 1.2], [0.4, 0.1, 0], [0, 0, 0.5], False)):  # (the last one is NOT axis-aligned: generic path)
+            sc.add(pa.Rect(pos, ex, ey, flip), "w")
+        sc.add(pa.Rect([0.0, 1.9, 1], [0.5, 0, 0], [0, 0, 0.5]), pa.Emissive([20.0, 18.0, 15.0]))
+        sc.set(pa.ThinLenCamera(pa.Film([16, 16]), [0, 1, -4], [0, 1, 0], 0.25))
+    else:
+        sc = scenes.cbox((16, 16), "readme", which == "cbox")
+    rays = _adversarial_rays(np.random.default_rng(5), [-1, 0, 0], [1, 2, 2], 40000)
+    cap = 40
+    gen = np.zeros((len(rays), 2 * cap + 5), dtype=np.uint32)
+    _lib.check(_lib.lib.pine_gpu_test_traverse(sc._h, 0, rays.ctypes.data_as(_lib.c_f_p), len(rays), 0, cap, gen.ctypes.data_as(C.POINTER(C.c_uint32))))
+    plan = pa.Plan(sc, 1, 1, specialize=True)
+    assert plan.stats().specialized == 2
+    baked = np.zeros((len(rays), 4), dtype=np.uint32)
+    _lib.check(_lib.lib.pine_gpu_plan_test_traverse_baked(plan._h, rays.ctypes.data_as(_lib.c_f_p), len(rays), baked.ctypes.data_as(C.POINTER(C.c_uint32))))
+    plan.close()
+    want = np.stack([gen[:, cap], gen[:, cap + 1], gen[:, cap + 3], gen[:, 2 * cap + 4]], axis=1)
+    bad = np.nonzero((want != baked).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], rays[bad[:5]], want[bad[:5]], baked[bad[:5]])
+    assert 0.2 < want[:, 0].mean() < 0.99 and want[:, 3].mean() > 0.1  # (the rays do hit things, and miss)
 
 
 @pytest.mark.gpu

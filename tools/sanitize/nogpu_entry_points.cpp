@@ -62,4 +62,5 @@ int pine_gpu_test_powlog(int, const float*, const float*, int64_t, float*, float
 int pine_gpu_test_atan(int, const float*, const float*, int64_t, float*, float*) { return fail(); }
 int pine_gpu_test_traverse(pine_gpu_scene*, int, const float*, int64_t, int, int, uint32_t*) { return fail(); }
 int pine_gpu_test_shapes(pine_gpu_scene*, int, const float*, int64_t, float*, int64_t) { return fail(); }
+int pine_gpu_plan_test_traverse_baked(pine_gpu_plan*, const float*, int64_t, uint32_t*) { return fail(); }
 }
