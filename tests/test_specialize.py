@@ -93,6 +93,21 @@ def test_specialised_kernel_compiles_for_gfx950_and_is_cached(tmp_path, monkeypa
     assert "hipcc" in _lib.last_error()
 
 
+def test_prebuilt_kernel_of_the_cornell_box_travels_with_the_package(monkeypatch):
+    """__graft_entry__.build() leaves the Cornell box's kernel in pine_amd/lib/kernel_cache/: found there (same content key)
+    before any compiler is looked for."""
+    from pine_amd import _lib, scenes
+    cache = os.path.join(os.path.dirname(_lib.LIB_PATH), "kernel_cache")
+    if not os.path.isdir(cache) or not os.listdir(cache):
+        pytest.skip("pine_amd/lib/kernel_cache is empty (build() has not run)")
+    monkeypatch.delenv("PINE_GPU_CACHE_DIR", raising=False)
+    monkeypatch.setenv("PINE_GPU_HIPCC", "/nonexistent/hipcc")  # (not needed: must not be looked for)
+    sc = scenes.cbox((640, 640), "committed")
+    out = C.create_string_buffer(1024)
+    assert _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024) == 1, _lib.last_error()
+    assert os.path.dirname(os.path.realpath(out.value.decode())) == os.path.realpath(cache)
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 def _render(scene, spp, depth, **kw):
     import torch
