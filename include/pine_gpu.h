@@ -249,6 +249,9 @@ typedef struct {
                                     hipcc and this library's device headers at run time.  A scene with nothing to gain
                                     renders with the precompiled kernel (plan stats: `specialized`); a kernel that cannot be
                                     built fails the plan.  Also $PINE_GPU_SPECIALIZE=1 (every plan) / =0 (never). */
+#define PINE_GPU_FLAG_SPECIALIZE_NO_BAKE 0x800 /* with PINE_GPU_FLAG_SPECIALIZE: the exact feature set only, never the baked scene --
+                                    for geometry that changes from render to render (an animation): a baked kernel is keyed by
+                                    the geometry and would be compiled per frame, a feature-set kernel once */
 #define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are

@@ -68,6 +68,7 @@ FLAG_DEVICE_BVH = 8
 FLAG_DEBUG_FORCE_BAIL = 0x100
 FLAG_VERTEX_LOG = 0x200
 FLAG_SPECIALIZE = 0x400
+FLAG_SPECIALIZE_NO_BAKE = 0x800
 
 # every symbol include/pine_gpu.h declares, with its signature
 SIGNATURES = {

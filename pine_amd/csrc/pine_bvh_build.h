@@ -42,6 +42,11 @@ struct SplitDecision {
 PINE_HD int build_bucket_of(float c, float lo, float hi) {
   const float o = c - lo, d = hi - lo;
   const float rel = d > 0.0f ? o / d : o;  // AABB::relative_position bbox.cpp:55-59
+  // (bounds so large that hi - lo or a centroid overflows make `rel` NaN, infinite or negative: the reference's int() of that
+  //  is undefined behaviour and indexes its bucket array with it; here such a primitive lands in an end bucket.  For finite
+  //  geometry 0 <= rel <= 1 and nothing changes.)
+  if (!(rel >= 0.0f)) return 0;
+  if (rel >= 1.0f) return kBuildBuckets - 1;
   int b = int(float(kBuildBuckets) * rel);
   return b >= kBuildBuckets ? kBuildBuckets - 1 : b;
 }

@@ -549,6 +549,7 @@ struct pine_gpu_plan {
   // PINE_GPU_FLAG_SPECIALIZE: the queue kernel compiled for this scene (pine_specialize.h); null: the precompiled variant
   hipModule_t spec_module = nullptr;
   hipFunction_t spec_fn = nullptr;
+  std::string spec_image;
   unsigned spec_features = 0;  // ... its feature set (the scene's own), and whether the scene's BVH is baked in
   bool spec_baked = false;
   float specialize_ms = 0.0f;
@@ -573,7 +574,7 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
   const unsigned kLayout = F_LDS_SCENE | F_LDS_TOP | F_LDS_REST | F_XSTAGE | F_SSS;
   unsigned exact = (V.features & kLayout) | need;
   std::string baked;
-  if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0 && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr)
+  if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0 && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_NO_BAKE) && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr)
     baked = generate_baked_scene(A, shapes, packed_prims);  // (F_XSTAGE: chosen for scenes with meshes only; those do not qualify)
   if (baked.empty() && exact == V.features) return 0;
   if (!baked.empty()) exact |= F_BAKED;
@@ -592,7 +593,8 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
     set_error("scene specialisation: cannot read " + path);
     return -1;
   }
-  HIP_OK(hipModuleLoadData(&p->spec_module, image.data()));
+  p->spec_image = std::move(image);  // (kept for the module's lifetime: the runtime may build the program lazily from it)
+  HIP_OK(hipModuleLoadData(&p->spec_module, p->spec_image.data()));
   HIP_OK(hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(exact, V.ctx).c_str()));
   p->spec_features = exact;
   p->spec_baked = !baked.empty();

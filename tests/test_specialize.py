@@ -53,6 +53,30 @@ def test_generated_text_holds_the_scene():
     assert order == prims[:n].tolist()
 
 
+def test_literals_are_exact_for_denormals_signed_zeros_and_huge_values(tmp_path, monkeypatch):
+    """Record floats are written from their bits (not with printf's locale-dependent %a): denormals, -0 and values next to
+    FLT_MAX come back bit for bit, and the compiler accepts them.  (Bounds this large used to crash the host BVH build: the
+    bucket index of an overflowing centroid, bvh.cpp:66-68, was undefined behaviour.)"""
+    import pine_amd as pa
+    from pine_amd import _lib
+    s = pa.Scene()
+    s.add("w", pa.Diffuse([0.7, 0.7, 0.7]))
+    s.add(pa.Sphere([1e-40, -0.0, 3.4e38], 1.17549435e-38), "w")
+    s.add(pa.Rect([0.0, 1.9, 1], [0.5, 0, 0], [0, 0, 0.5]), pa.Emissive([20.0, 18.0, 15.0]))
+    s.set(pa.ThinLenCamera(pa.Film([16, 16]), [0, 1, -4], [0, 1, 0], 0.25))
+    text = _source(s)
+    line = next(l for l in text.splitlines() if l.startswith("__device__ static constexpr float kBakedRec0[30]"))
+    vals = [float.fromhex(t.rstrip("f")) for t in line[line.index("{") + 1:line.index("}")].split(", ")]
+    rec = (C.c_float * 32)()
+    _lib.check(_lib.lib.pine_gpu_scene_shape_record(s._h, 0, rec))
+    assert np.array_equal(np.float32(vals).view(np.uint32), np.frombuffer(rec, dtype=np.uint32)[:30])
+    assert "0x0.022d84p-126f" in line and "-0x0p+0f" in line
+    if os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc"):
+        monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))
+        out = C.create_string_buffer(1024)
+        assert _lib.lib.pine_gpu_test_specialize_compile(s._h, 0x104, 1536, b"gfx950", out, 1024) == 0, _lib.last_error()
+
+
 def test_scenes_that_do_not_qualify_generate_nothing():
     import pine_amd as pa
     from pine_amd import scenes
@@ -226,7 +250,7 @@ def test_specialised_random_scenes_equal_the_precompiled_kernels():
 def test_specialise_under_sharding_and_by_environment(monkeypatch):
     import torch
     import pine_amd as pa
-    from pine_amd import scenes
+    from pine_amd import _lib, scenes
     sc = scenes.cbox((72, 40), "readme")
     whole, _ = _render(sc, 16, 5)
     total = np.zeros_like(whole)
@@ -242,6 +266,14 @@ def test_specialise_under_sharding_and_by_environment(monkeypatch):
     monkeypatch.setenv("PINE_GPU_SPECIALIZE", "0")
     f, st = _render(sc, 16, 5, specialize=True)
     assert st.specialized == 0
+    monkeypatch.delenv("PINE_GPU_SPECIALIZE")
+    # the feature set only (geometry that changes every render): cbox without its boxes is Rects only -> F_OBB dropped
+    rects = scenes.cbox((72, 40), "readme", False)
+    a, st = _render(rects, 16, 5, flags=_lib.FLAG_SPECIALIZE | _lib.FLAG_SPECIALIZE_NO_BAKE)
+    b, _ = _render(rects, 16, 5)
+    assert st.specialized == 1 and st.kernel_features & 0xff == 0
+    assert_bit_equal(a, b, "feature-set kernel without the baked scene")
+    monkeypatch.setenv("PINE_GPU_SPECIALIZE", "0")
     # a scene with nothing to gain (a mesh: nothing to bake; its variant already is its feature set) renders with the
     # precompiled kernel, flag or not
     monkeypatch.delenv("PINE_GPU_SPECIALIZE")
