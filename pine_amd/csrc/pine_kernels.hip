@@ -583,19 +583,28 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));
   std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
   if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
-  std::string path, err;
-  if (!compile_baked_kernel(baked, exact, V.ctx, arch, dir + "/csrc", dir + "/../include", path, err)) {
-    set_error(err);
+  // (two attempts: a cached code object the runtime refuses -- a file cut short by a full disk, another ROCm's output -- is
+  //  removed and compiled afresh, once)
+  for (int attempt = 0;; attempt++) {
+    std::string path, err;
+    bool from_cache = false;
+    if (!compile_baked_kernel(baked, exact, V.ctx, arch, dir + "/csrc", dir + "/../include", path, err, &from_cache)) {
+      set_error(err);
+      return -1;
+    }
+    hipError_t e = hipErrorInvalidImage;
+    if (read_file(path, p->spec_image) && code_object_is_whole(p->spec_image)) {  // (kept for the module's lifetime: the runtime may build the program lazily from it)
+      e = hipModuleLoadData(&p->spec_module, p->spec_image.data());
+      if (e == hipSuccess) e = hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(exact, V.ctx).c_str());
+    }
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    if (p->spec_module) (void)hipModuleUnload(p->spec_module);
+    p->spec_module = nullptr, p->spec_fn = nullptr;
+    if (attempt == 0 && from_cache && unlink(path.c_str()) == 0) continue;
+    set_error("scene specialisation: the runtime does not load " + path + " (" + hipGetErrorString(e) + ")");
     return -1;
   }
-  std::string image;
-  if (!read_file(path, image) || image.empty()) {
-    set_error("scene specialisation: cannot read " + path);
-    return -1;
-  }
-  p->spec_image = std::move(image);  // (kept for the module's lifetime: the runtime may build the program lazily from it)
-  HIP_OK(hipModuleLoadData(&p->spec_module, p->spec_image.data()));
-  HIP_OK(hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(exact, V.ctx).c_str()));
   p->spec_features = exact;
   p->spec_baked = !baked.empty();
   p->specialize_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -288,6 +288,22 @@ def test_specialise_under_sharding_and_by_environment(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_a_damaged_cache_entry_is_replaced(monkeypatch, tmp_path):
+    import pine_amd as pa
+    from pine_amd import scenes
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))
+    sc = scenes.cbox((32, 32), "readme")
+    a, st = _render(sc, 4, 3, specialize=True)
+    (entry,) = os.listdir(tmp_path)
+    good = os.path.getsize(tmp_path / entry)
+    with open(tmp_path / entry, "r+b") as f:  # cut short, as by a full disk
+        f.truncate(good // 3)
+    b, st = _render(sc, 4, 3, specialize=True)
+    assert st.specialized == 2 and os.path.getsize(tmp_path / entry) == good
+    assert_bit_equal(a, b, "after recompiling a damaged cache entry")
+
+
+@pytest.mark.gpu
 def test_specialise_fails_loudly_without_a_compiler(monkeypatch, tmp_path):
     import pine_amd as pa
     from pine_amd import scenes
