@@ -327,7 +327,8 @@ typedef struct {
 int64_t pine_gpu_scene_specialized_source(pine_gpu_scene*, char* out, int64_t cap);
 /* ... and the compile step on its own (no GPU needed: hipcc cross-compiles): the scene's kernel for the stage-queued variant
  * <features, ctx> (pine_variants.h; the kernel's name carries features | F_BAKED) and `arch` ("gfx950"), through the same cache
- * plan creation uses; the code object's path into path_out.  Returns 1 on a cache hit, 0 after a compiler run, < 0 on failure.  Build check + tests. */
+ * plan creation uses; the code object's path into path_out.  A null scene compiles level 1: <features, ctx> as given, generic
+ * traversal (tools/compile_sweep.py walks feature combinations with it).  Returns 1 on a cache hit, 0 after a compiler run, < 0 on failure.  Build check + tests. */
 int pine_gpu_test_specialize_compile(pine_gpu_scene*, uint32_t features, int ctx, const char* arch, char* path_out, int64_t cap);
 /* The scene's BVH built on HIP device `device` right now (the accel is then reused by every later plan); returns the node
  * count, < 0 on failure.  pine_gpu_scene_accel_dump shows the result: identical to the host build's. */

@@ -1528,19 +1528,23 @@ int64_t pine_gpu_scene_specialized_source(pine_gpu_scene* s, char* out, int64_t 
 }
 
 int pine_gpu_test_specialize_compile(pine_gpu_scene* s, uint32_t features, int ctx, const char* arch, char* path_out, int64_t cap) {
-  if (!check(s) || !arch) return -1;
-  const int64_t n = pine_gpu_scene_specialized_source(s, nullptr, 0);
-  if (n <= 0) {
-    if (n == 0) set_error("the scene does not qualify for specialisation");
-    return -1;
+  if (!arch || (s && !check(s))) return -1;
+  std::string text;  // (no scene: level 1, the feature set alone with the generic traversal)
+  if (s) {
+    const int64_t n = pine_gpu_scene_specialized_source(s, nullptr, 0);
+    if (n <= 0) {
+      if (n == 0) set_error("the scene does not qualify for specialisation");
+      return -1;
+    }
+    text.assign(size_t(n) + 1, '\0');
+    pine_gpu_scene_specialized_source(s, &text[0], n + 1);
+    text.resize(size_t(n));
+    features |= 1u << 17;  // F_BAKED (pine_device.h)
   }
-  std::string text(size_t(n) + 1, '\0');
-  pine_gpu_scene_specialized_source(s, &text[0], n + 1);
-  text.resize(size_t(n));
   const std::string dir = library_dir() + "/..";
   std::string path, err;
   bool hit = false;
-  if (!compile_baked_kernel(text, features | (1u << 17) /* F_BAKED (pine_device.h) */, ctx, arch, dir + "/csrc", dir + "/../include", path, err, &hit)) {
+  if (!compile_baked_kernel(text, features, ctx, arch, dir + "/csrc", dir + "/../include", path, err, &hit)) {
     set_error(err);
     return -1;
   }

@@ -117,6 +117,20 @@ def test_specialised_kernel_compiles_for_gfx950_and_is_cached(tmp_path, monkeypa
     assert "hipcc" in _lib.last_error()
 
 
+@pytest.mark.parametrize("features, ctx", [(0x100, 1536), (0x6080, 1024), (0x3a14, 1024), (0xe020, 1024)])
+def test_feature_sets_without_a_precompiled_variant_compile(tmp_path, monkeypatch, features, ctx):
+    """Level 1 compiles `need | layout` for whatever a scene contains (Rects only; analytic Subsurface shapes without a mesh;
+    sphere + cone + node programs + other shapes + Sobol; a bare mesh with traversal stages): the kernel template must
+    instantiate for sets no precompiled variant has.  tools/compile_sweep.py walks many more."""
+    from pine_amd import _lib
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))
+    out = C.create_string_buffer(1024)
+    assert _lib.lib.pine_gpu_test_specialize_compile(None, features, ctx, b"gfx950", out, 1024) == 0, _lib.last_error()[-1500:]
+    assert f"path_queue_kernelILj{features}ELi{ctx}E".encode() in open(out.value.decode(), "rb").read()
+
+
 def test_prebuilt_kernel_of_the_cornell_box_travels_with_the_package(monkeypatch):
     """__graft_entry__.build() leaves the Cornell box's kernel in pine_amd/lib/kernel_cache/: found there (same content key)
     before any compiler is looked for."""
