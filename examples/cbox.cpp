@@ -33,7 +33,8 @@ int main(int argc, char** argv) {
     scene.set(ThinLenCamera(Film({size, size}, Uncharted2()), {0, 0, 0}, {0, 0, 1}, 0.4f));
 
     auto t0 = std::chrono::steady_clock::now();
-    PathIntegrator(BlueSampler(spp), depth).render(scene);
+    // (CBOX_SPECIALIZE=1: the kernel compiled for this scene -- same film)
+    PathIntegrator(BlueSampler(spp), depth).specialize(getenv("CBOX_SPECIALIZE") != nullptr).render(scene);
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     auto& film = scene.camera.film();
     FILE* f = fopen(argv[5], "wb");

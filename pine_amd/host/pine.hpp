@@ -232,8 +232,14 @@ class PathIntegrator {
     devices_ = std::move(devices);
     return *this;
   }
+  // compile the path kernel for the scene at hand (PINE_GPU_FLAG_SPECIALIZE: exact feature set, small scenes baked in; same film)
+  PathIntegrator& specialize(bool on = true) {
+    flags_ = on ? (flags_ | PINE_GPU_FLAG_SPECIALIZE) : (flags_ & ~PINE_GPU_FLAG_SPECIALIZE);
+    return *this;
+  }
   void render(Scene& scene) {
     pine_gpu_render_params p{};
+    p.flags = flags_;
     p.spp = sampler_.requested;
     p.max_path_length = max_path_length_;
     p.device = device_;
@@ -250,6 +256,7 @@ class PathIntegrator {
  private:
   Sampler sampler_;
   int max_path_length_, device_;
+  int flags_ = 0;
   std::vector<int> devices_;
 };
 
