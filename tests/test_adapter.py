@@ -133,3 +133,20 @@ def test_adapter_render_end_to_end_equals_the_reference_film(tmp_path, which, na
     film = np.fromfile(out, dtype=np.float32).reshape(64, 64, 4)
     ref = np.load(os.path.join(ROOT, "tests", "golden", f"film_{name}.npz"))["film"]
     assert_bit_equal(film, ref, f"adapter render() vs the reference's film {name}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specialize", [False, True])
+def test_cpp_facade_example_renders_the_reference_film(tmp_path, specialize):
+    """examples/cbox.cpp (scenes/cbox.pine written against pine_amd/host/pine.hpp, built by __graft_entry__.build()): its film
+    equals the film the real reference rendered of the as-committed Cornell box; PathIntegrator::specialize() changes nothing."""
+    exe = os.path.join(ROOT, "build", "cbox_cpp")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("build/cbox_cpp not built")
+    out = tmp_path / "c.film"
+    env = dict(os.environ, **({"CBOX_SPECIALIZE": "1"} if specialize else {}))
+    r = subprocess.run([exe, os.path.join(ROOT, "pine_amd", "data", "bluesobol_u8.bin"), "64", "16", "4", str(out)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    film = np.fromfile(out, dtype=np.float32).reshape(64, 64, 4)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "film_cbox_committed_64_s16_d4.npz"))["film"]
+    assert_bit_equal(film, ref, "C++ facade example vs the reference's film")
