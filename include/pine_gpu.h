@@ -252,6 +252,11 @@ typedef struct {
 #define PINE_GPU_FLAG_SPECIALIZE_NO_BAKE 0x800 /* with PINE_GPU_FLAG_SPECIALIZE: the exact feature set only, never the baked scene --
                                     for geometry that changes from render to render (an animation): a baked kernel is keyed by
                                     the geometry and would be compiled per frame, a feature-set kernel once */
+#define PINE_GPU_FLAG_SPECIALIZE_ASYNC 0x1000 /* with PINE_GPU_FLAG_SPECIALIZE: plan creation does not wait for the compiler -- it runs on a
+                                    background thread while the precompiled kernel renders; the first launch after it has
+                                    finished (and every later one) runs the scene's own kernel.  The films are the same either
+                                    way.  A build that fails leaves the precompiled kernel in place (plan stats: specialized
+                                    == -1); destroying the plan waits for a build in progress. */
 #define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are
@@ -314,8 +319,9 @@ typedef struct {
   int32_t serial_tiles;      /* tile classes (Subsurface scenes): 8x8 tiles of this shard whose pixels are one whole-pixel item each
                               * because a camera ray of theirs can reach a Subsurface shape; the others' samples are independent
                               * items of samples_per_item samples.  0: one class (samples_per_item describes every item) */
-  int32_t specialized;       /* PINE_GPU_FLAG_SPECIALIZE: 0 a precompiled kernel runs; 1 a kernel compiled for this scene's exact feature
-                              * set; 2 ... with the scene's BVH and primitive records baked in as well */
+  int32_t specialized;       /* PINE_GPU_FLAG_SPECIALIZE: 0 a precompiled kernel runs (no gain possible, or -- _ASYNC -- the build is still
+                              * running); 1 a kernel compiled for this scene's exact feature set; 2 ... with the scene's BVH and
+                              * primitive records baked in as well; -1 (_ASYNC) the build failed, the precompiled kernel keeps running */
   float specialize_ms;       /* host: generating + compiling (or fetching from the cache) + loading that kernel at plan creation */
   uint32_t kernel_features;  /* feature bits (pine_device.h F_*) of the path kernel in use */
   int32_t reserved;

@@ -69,6 +69,7 @@ FLAG_DEBUG_FORCE_BAIL = 0x100
 FLAG_VERTEX_LOG = 0x200
 FLAG_SPECIALIZE = 0x400
 FLAG_SPECIALIZE_NO_BAKE = 0x800
+FLAG_SPECIALIZE_ASYNC = 0x1000
 
 # every symbol include/pine_gpu.h declares, with its signature
 SIGNATURES = {

@@ -34,6 +34,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <thread>
 
 #include "../../include/pine_gpu.h"
 #include "pine_device.h"
@@ -552,6 +553,17 @@ struct pine_gpu_plan {
   std::string spec_image;
   unsigned spec_features = 0;  // ... its feature set (the scene's own), and whether the scene's BVH is baked in
   bool spec_baked = false;
+  struct SpecRequest {  // what to compile (filled at plan creation)
+    std::string baked;
+    unsigned features = 0;
+    int ctx = 0;
+    std::string arch;
+    std::chrono::steady_clock::time_point t0;
+  } spec_request;
+  // PINE_GPU_FLAG_SPECIALIZE_ASYNC: the build runs on spec_thread; a launch adopts its result
+  std::atomic<int> spec_state{0};  // kSpecNone / kSpecBuilding / kSpecBuilt (waiting to be adopted) / kSpecAdopted / kSpecFailed
+  std::thread spec_thread;
+  std::string spec_async_error;
   float specialize_ms = 0.0f;
 };
 
@@ -564,6 +576,8 @@ struct pine_gpu_plan {
 //  (2) if the scene has no meshes and its BVH is small enough to unroll: the BVH and primitive records baked in.
 // Nothing to gain (the variant IS the exact set, nothing to bake): the precompiled kernel runs.  A kernel that cannot be
 // built (no hipcc, no headers, no cache directory) fails the plan: the caller asked for it.
+enum : int { kSpecNone = 0, kSpecBuilding, kSpecBuilt, kSpecAdopted, kSpecFailed };
+static int plan_adopt_kernel(pine_gpu_plan* p, bool compile_here);
 static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vector<DShape>& shapes, const std::vector<int>& packed_prims,
                            const pine_gpu_render_params* prm, unsigned need) {
   bool want = (prm->flags & PINE_GPU_FLAG_SPECIALIZE) != 0;
@@ -578,36 +592,57 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
     baked = generate_baked_scene(A, shapes, packed_prims);  // (F_XSTAGE: chosen for scenes with meshes only; those do not qualify)
   if (baked.empty() && exact == V.features) return 0;
   if (!baked.empty()) exact |= F_BAKED;
-  const std::string dir = library_dir() + "/..";
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));
   std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
   if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
-  // (two attempts: a cached code object the runtime refuses -- a file cut short by a full disk, another ROCm's output -- is
-  //  removed and compiled afresh, once)
+  p->spec_request = {baked, exact, V.ctx, arch, t0};
+  if (prm->flags & PINE_GPU_FLAG_SPECIALIZE_ASYNC) {
+    // the compiler runs beside the first renders (host work only: files and a child process); a launch adopts the kernel
+    // once it is there.  Until then -- and for good if the build fails -- the precompiled kernel renders the same film.
+    p->spec_state.store(kSpecBuilding);
+    p->spec_thread = std::thread([p]() {
+      std::string path, err;
+      const bool ok = compile_baked_kernel(p->spec_request.baked, p->spec_request.features, p->spec_request.ctx, p->spec_request.arch,
+                                           library_dir() + "/../csrc", library_dir() + "/../../include", path, err);
+      p->spec_async_error = err;
+      p->spec_state.store(ok ? kSpecBuilt : kSpecFailed);
+    });
+    return 0;
+  }
+  return plan_adopt_kernel(p, true);
+}
+
+// Load the plan's scene-specialised kernel (compiling it first unless the background thread has) and make it the one that
+// launches.  (Two attempts: a cached code object the runtime refuses -- a file cut short by a full disk, another ROCm's
+// output -- is removed and compiled afresh, once.)
+static int plan_adopt_kernel(pine_gpu_plan* p, bool compile_here) {
+  const auto& R = p->spec_request;
+  const std::string dir = library_dir() + "/..";
   for (int attempt = 0;; attempt++) {
     std::string path, err;
     bool from_cache = false;
-    if (!compile_baked_kernel(baked, exact, V.ctx, arch, dir + "/csrc", dir + "/../include", path, err, &from_cache)) {
+    // (after a background build this is a cache hit)
+    if (!compile_baked_kernel(R.baked, R.features, R.ctx, R.arch, dir + "/csrc", dir + "/../include", path, err, &from_cache)) {
       set_error(err);
       return -1;
     }
     hipError_t e = hipErrorInvalidImage;
     if (read_file(path, p->spec_image) && code_object_is_whole(p->spec_image)) {  // (kept for the module's lifetime: the runtime may build the program lazily from it)
       e = hipModuleLoadData(&p->spec_module, p->spec_image.data());
-      if (e == hipSuccess) e = hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(exact, V.ctx).c_str());
+      if (e == hipSuccess) e = hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(R.features, R.ctx).c_str());
     }
     if (e == hipSuccess) break;
     (void)hipGetLastError();
     if (p->spec_module) (void)hipModuleUnload(p->spec_module);
     p->spec_module = nullptr, p->spec_fn = nullptr;
-    if (attempt == 0 && from_cache && unlink(path.c_str()) == 0) continue;
+    if (attempt == 0 && compile_here && from_cache && unlink(path.c_str()) == 0) continue;
     set_error("scene specialisation: the runtime does not load " + path + " (" + hipGetErrorString(e) + ")");
     return -1;
   }
-  p->spec_features = exact;
-  p->spec_baked = !baked.empty();
-  p->specialize_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  p->spec_features = R.features;
+  p->spec_baked = !R.baked.empty();
+  p->specialize_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - R.t0).count();
   return 0;
 }
 
@@ -663,6 +698,7 @@ int pine_gpu_set_table_path(const char* path) {
 
 void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   if (!p) return;
+  if (p->spec_thread.joinable()) p->spec_thread.join();  // (PINE_GPU_FLAG_SPECIALIZE_ASYNC: a build still running is waited for -- seconds at most)
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_blob);
   (void)hipFree(p->d_tri);
@@ -1358,6 +1394,15 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
   hipStream_t stream = (hipStream_t)stream_;
   HIP_OK(hipSetDevice(p->device));
   (void)hipGetLastError();  // (HIP's last error is sticky: what the check at the end reports must come from THIS launch's calls)
+  if (p->spec_state.load() == kSpecBuilt) {
+    // the background build has finished: this launch and every later one run the scene's own kernel.  (A code object the
+    // runtime refuses leaves the precompiled kernel in place -- same film; plan stats say which one runs.)
+    if (plan_adopt_kernel(p, false) == 0) p->spec_state.store(kSpecAdopted);
+    else {
+      p->spec_async_error = pine_gpu_last_error();
+      p->spec_state.store(kSpecFailed);
+    }
+  }
   g_progress.store(0.0f);
   const size_t film_bytes = size_t(p->film_w) * p->film_h * sizeof(float4);
   if (p->W.shard_world > 1 && !packed) HIP_OK(hipMemsetAsync(film_dev, 0, film_bytes, stream));
@@ -1464,7 +1509,7 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   out->spp_effective = p->S.spp;
   out->samples_per_item = p->W.samples_per_item;
   out->serial_tiles = p->W.serial_tiles;
-  out->specialized = p->spec_fn ? (p->spec_baked ? 2 : 1) : 0;
+  out->specialized = p->spec_fn ? (p->spec_baked ? 2 : 1) : p->spec_state.load() == kSpecFailed ? -1 : 0;
   out->kernel_features = p->spec_fn ? p->spec_features : p->fast ? p->fast->features : p->queue_variant >= 0 ? kQueueVariants[p->queue_variant].features
                                                                                          : p->variant >= 0 ? kVariants[p->variant].features : 0u;
   out->specialize_ms = p->specialize_ms;

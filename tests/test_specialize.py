@@ -310,6 +310,56 @@ def test_specialise_under_sharding_and_by_environment(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_asynchronous_specialisation_swaps_the_kernel_in_between_launches(monkeypatch, tmp_path):
+    """PINE_GPU_FLAG_SPECIALIZE_ASYNC: plan creation returns at once, the precompiled kernel renders while hipcc runs on a
+    background thread, a later launch adopts the scene's kernel; every film along the way is the same film."""
+    import time
+    import torch
+    import pine_amd as pa
+    from pine_amd import _lib, scenes
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))  # (empty: the compiler must run)
+    sc = scenes.cbox((48, 48), "readme")
+    want, _ = _render(sc, 8, 4)
+    t0 = time.perf_counter()
+    plan = pa.Plan(sc, 8, 4, flags=_lib.FLAG_SPECIALIZE | _lib.FLAG_SPECIALIZE_ASYNC)
+    created = time.perf_counter() - t0
+    film = torch.zeros((48, 48, 4), device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    seen = set()
+    deadline = time.perf_counter() + 120
+    while time.perf_counter() < deadline:
+        film.fill_(-1.0)
+        plan.launch(film.data_ptr(), stream)
+        torch.cuda.synchronize()
+        plan.check()
+        level = plan.stats().specialized
+        seen.add(level)
+        assert_bit_equal(film.cpu().numpy(), want, f"film at specialisation level {level}")
+        if level == 2 and len(seen) > 1 or level < 0:
+            break
+        if level == 2:
+            break
+        time.sleep(0.02)
+    plan.close()
+    assert 2 in seen, seen
+    assert 0 in seen and created < 0.5, (seen, created)  # (the first launches ran the precompiled kernel; creation did not wait)
+    # a build that fails: no exception, the precompiled kernel keeps rendering, stats say so
+    monkeypatch.setenv("PINE_GPU_HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path / "other"))
+    plan = pa.Plan(sc, 8, 4, flags=_lib.FLAG_SPECIALIZE | _lib.FLAG_SPECIALIZE_ASYNC)
+    level = 0
+    deadline = time.perf_counter() + 60
+    while level == 0 and time.perf_counter() < deadline:
+        plan.launch(film.data_ptr(), stream)
+        torch.cuda.synchronize()
+        level = plan.stats().specialized
+        time.sleep(0.02)
+    assert level == -1
+    assert_bit_equal(film.cpu().numpy(), want, "film after a failed background build")
+    plan.close()
+
+
+@pytest.mark.gpu
 def test_a_damaged_cache_entry_is_replaced(monkeypatch, tmp_path):
     import pine_amd as pa
     from pine_amd import scenes
