@@ -590,7 +590,7 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
   std::string baked;
   if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0 && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_NO_BAKE) && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr)
     baked = generate_baked_scene(A, shapes, packed_prims);  // (F_XSTAGE: chosen for scenes with meshes only; those do not qualify)
-  if (baked.empty() && exact == V.features) return 0;
+  if (baked.empty() && exact == V.features && getenv("PINE_GPU_SPECIALIZE_FORCE") == nullptr) return 0;  // (FORCE: experiments through $PINE_GPU_SPECIALIZE_EXTRA)
   if (!baked.empty()) exact |= F_BAKED;
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));
