@@ -233,7 +233,9 @@ def make_plan(scene, spp, depth, specialize, **kw):
 def kernel_note(st, err=None):
     if st.specialized:
         return "scene-specialised (PINE_GPU_FLAG_SPECIALIZE: compiled for this scene at plan creation -- %s; %.0f ms; bit-identical film)" % (
-            "exact feature set + BVH and primitive records baked in" if st.specialized == 2 else "exact feature set", st.specialize_ms)
+            ("exact feature set + BVH and primitive records baked in" if not (st.kernel_features & 0x8000) else
+             "exact feature set + the top-level BVH and its primitive records baked in (the mesh stays with the flat traversal)") if st.specialized == 2 else "exact feature set",
+            st.specialize_ms)
     return "precompiled" + (" (specialisation failed: " + err + ")" if err else "")
 
 
@@ -576,13 +578,13 @@ def main():
             out["configs"] = []
             spec = want_specialised()
             for name, k, w, fast, specialize in (("c2r", 5, 1, False, spec), ("c3", 3, 1, False, spec), ("c4", 5, 1, False, spec), ("c5", 2, 1, False, spec),
-                                                 ("c2r", 5, 1, False, False), ("c3", 3, 1, False, False),
+                                                 ("c2r", 5, 1, False, False), ("c3", 3, 1, False, False), ("c5", 2, 1, False, False),
                                                  ("c2", 5, 1, True, False), ("c4", 5, 1, True, False), ("c5", 2, 1, True, False)):
-                if not specialize and not fast and name in ("c2r", "c3") and not spec:
+                if not specialize and not fast and name in ("c2r", "c3", "c5") and not spec:
                     continue  # (already measured with the precompiled kernel above)
                 try:
                     e = side_config(name, k, w, local_rank, fast, specialize)
-                    if not fast and not specialize and spec and name in ("c2r", "c3"):
+                    if not fast and not specialize and spec and name in ("c2r", "c3", "c5"):
                         e["config"] = name + "_precompiled"
                     out["configs"].append(e)
                 except Exception as e:  # report, keep the headline

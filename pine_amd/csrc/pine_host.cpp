@@ -1522,7 +1522,8 @@ int64_t pine_gpu_scene_specialized_source(pine_gpu_scene* s, char* out, int64_t 
     const DShape& sh = shapes[size_t(words[i])];
     words[i] |= (s->host.materials[size_t(sh.material)].kind == MAT_EMISSIVE ? kPrimEmissiveBit : 0) | (sh.kind << kPrimKindShift);
   }
-  const std::string text = a.top_prim_begin == 0 ? generate_baked_scene(a, shapes, words) : std::string();
+  // (no mesh: the whole scene; exactly one mesh: its top level, for the traversal-stage variants)
+  const std::string text = a.top_prim_begin == 0 ? generate_baked_scene(a, shapes, words) : a.bvhs.size() == 2 ? generate_baked_scene(a, shapes, words, true) : std::string();
   if (out && cap > int64_t(text.size())) memcpy(out, text.c_str(), text.size() + 1);
   return int64_t(text.size());
 }

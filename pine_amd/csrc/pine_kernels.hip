@@ -588,8 +588,12 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
   const unsigned kLayout = F_LDS_SCENE | F_LDS_TOP | F_LDS_REST | F_XSTAGE | F_SSS;
   unsigned exact = (V.features & kLayout) | need;
   std::string baked;
-  if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0 && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_NO_BAKE) && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr)
-    baked = generate_baked_scene(A, shapes, packed_prims);  // (F_XSTAGE: chosen for scenes with meshes only; those do not qualify)
+  if (!(prm->flags & PINE_GPU_FLAG_SPECIALIZE_NO_BAKE) && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr) {
+    if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0) baked = generate_baked_scene(A, shapes, packed_prims);
+    // one mesh under a small top level, traversal stages (C5's class): the top level as code, the mesh left to the flat traversal
+    else if ((V.features & F_XSTAGE) && A.bvhs.size() == 2 && getenv("PINE_GPU_SPECIALIZE_NO_TOP") == nullptr)
+      baked = generate_baked_scene(A, shapes, packed_prims, true);
+  }
   if (baked.empty() && exact == V.features && getenv("PINE_GPU_SPECIALIZE_FORCE") == nullptr) return 0;  // (FORCE: experiments through $PINE_GPU_SPECIALIZE_EXTRA)
   if (!baked.empty()) exact |= F_BAKED;
   hipDeviceProp_t prop;
@@ -1288,6 +1292,9 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // traversal waits on memory (10 000 cones: 9.8 ms without, 10.9 ms with) -- so there a wave runs its rays to the end.
   W.trav_min_lanes = (S.lds_nodes > 0 && size_t(S.lds_nodes) * 10 >= A.nodes.size() * 9) ? 48 : 0;  // (nearly) all nodes in LDS
   W.trav_min_trips = 8;
+  // (a kernel with the top level baked in, pine_specialize.h: most rays end in the code part and free their lanes at once;
+  //  refilling after three trips instead of eight: C5 107.3 -> 100.2 ms)
+  if (!p->spec_request.baked.empty() && (p->spec_request.features & F_XSTAGE)) W.trav_min_trips = 3;
   if (const char* e = getenv("PINE_GPU_TRAV_MIN_LANES")) W.trav_min_lanes = atoi(e);
   if (const char* e = getenv("PINE_GPU_TRAV_MIN_TRIPS")) W.trav_min_trips = atoi(e) > 0 ? atoi(e) : 1;
   // Subsurface is the only in-path user of the RNG and only before a path's first non-delta bounce: such a path hands its

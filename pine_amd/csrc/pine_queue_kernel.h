@@ -92,7 +92,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   constexpr int QS_K = kNStage, QS_F = kNStage + 1;
   constexpr bool kTop = (F & F_LDS_TOP) != 0;         // flat traversal (pine_trav.h), node cache, 16-bit per-wave stacks
   constexpr bool kX = kTop && (F & F_XSTAGE) != 0;    // ... as stages of its own: the XS / XC queues
-#ifdef PINE_BAKED_SCENE  /* scene-specialised build (pine_specialize.h): the scene's BVH and leaf records are immediates */
+#if defined(PINE_BAKED_SCENE) && !defined(PINE_BAKED_TOP)  /* scene-specialised build (pine_specialize.h): the scene's BVH and leaf records are immediates */
   constexpr bool kBaked = true;
   static_assert(!kX, "scenes with meshes are not baked");
   static_assert((F & F_BAKED) != 0, "a baked build instantiates the F_BAKED name");
@@ -354,7 +354,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
     } else {
       int geom = -1, prim = 0;
-#ifdef PINE_BAKED_SCENE
+#if defined(PINE_BAKED_SCENE) && !defined(PINE_BAKED_TOP)
       const bool hit = scene_traverse_baked<false, F>(ray, geom);
 #else
       const bool hit = scene_traverse<false, F, kStride>(V, ray, stack, geom, prim);
@@ -441,8 +441,55 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         }
         oct = make_oct(ray);
         trav_begin(V, ts);
+#ifdef PINE_BAKED_TOP
+        {
+          // The top level as code, once per ray (pine_specialize.h): its primitives are tested here, in pine's order, and the
+          // flat machine gets the mesh's BVH alone.  TravState's return-to-the-top-level fields are free in this mode and
+          // carry the first pass's results: r_pa / r_pan = tmax and hit after ALL top-level primitives, r_pb = "a primitive
+          // stored after the mesh was accepted", r_next = 1 "the mesh's place was reached".
+          static_assert(kX, "the top level is baked for the traversal-stage variants");
+          BakedMesh bm{false, 0.0f, -1};
+          int g = -1;
+          ts.done = 1;
+          ts.r_next = 0;
+          if (ANY) {
+            const bool occluded = scene_traverse_baked_top<true, F, 0>(ray, g, bm);
+            ts.hit_geom = occluded ? 0 : -1;
+            if (occluded) bm.reached = false;
+          } else {
+            const bool hit = scene_traverse_baked_top<false, F, 0>(ray, g, bm);
+            ts.hit_geom = hit ? g : -1;
+            if (bm.reached) {
+              ts.r_pa = __float_as_int(ray.tmax), ts.r_pan = ts.hit_geom;
+              ts.r_pb = (ts.hit_geom != bm.geom) ? 1 : 0;  // (an accepted primitive replaces the hit word: ids are unique)
+              ray.tmax = bm.t;
+              ts.hit_geom = bm.geom;
+            }
+          }
+          if (bm.reached) {
+            const DBvh mb = V.bvhs[1];
+            ts.r_next = 1;
+            ts.done = 0;
+            ts.mesh_base = 0;
+            ts.mesh_word = kBakedMeshWord;
+            ts.pb = ts.pbn = 0;
+            if (mb.root_count > 0) ts.next = -1, ts.pa = mb.root_start, ts.pan = mb.root_count;
+            else ts.next = mb.root, ts.pa = ts.pan = 0;
+          }
+        }
+#endif
         fresh = false;
       }
+#ifdef PINE_BAKED_TOP
+      // Most rays end in the top-level code (they never reach the mesh): while fewer than the refill threshold travel and the
+      // queue has rays, the finished lanes are retired and refilled at once -- the trips start on a full wave.
+      bool run_trips = true;
+      if (__popcll(__ballot(ts.done == 0)) < trav_keep_lanes) {
+        const unsigned h0 = __builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_HEAD + Q]));
+        if (__builtin_amdgcn_readfirstlane(lds_load(&qctl[QC_TAIL + Q])) != h0) run_trips = false;
+      }
+      if (run_trips)
+#endif
       trav_trips<ANY, F, kStride>(V, ray, oct, ts, stack, trav_keep_lanes, trav_min_trips);
       SEC_MARK(ANY ? 3 : 6);
       // ---- retire ----
@@ -476,6 +523,25 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             to_xc = true;  // its new ray waits in the context
           }
         } else {
+#ifdef PINE_BAKED_TOP
+          if (ts.r_next == 1) {  // the ray went through the mesh's BVH
+            if (ts.hit_geom != kBakedMeshWord) {
+              // no triangle accepted: every bound of the first pass was the reference's -- its result stands
+              ray.tmax = __int_as_float(ts.r_pa), ts.hit_geom = ts.r_pan;
+            } else if (ts.r_pb && __int_as_float(ts.r_pa) < ray.tmax) {
+              // a triangle at ray.tmax, and a primitive stored AFTER the mesh had been accepted against the larger bound with
+              // a SMALLER t (were the first pass's final tmax not below the triangle's, no such primitive could pass the
+              // reference's test `t < tmax` either: whatever the reference accepts, the first pass accepted or bettered):
+              // replay the top level with the mesh's result in its place (the reference's own sequence)
+              DRay rr{ray.o, ray.d, 0.0f, cstf[CF_TMAX * kQCtx + id]};
+              BakedMesh bm{true, ray.tmax, -1};
+              int g = -1;
+              const bool hit = scene_traverse_baked_top<false, F, 1>(rr, g, bm);
+              ray.tmax = rr.tmax;
+              ts.hit_geom = hit ? g : -1;
+            }
+          }
+#endif
           finish_hit(id, ts.hit_geom >= 0, ray.tmax, ts.hit_geom, ts.hit_prim, st, to_shade, to_term);
         }
       }
@@ -833,7 +899,7 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           } else {
             DRay r = sr;
             int g2, p2;
-#ifdef PINE_BAKED_SCENE
+#if defined(PINE_BAKED_SCENE) && !defined(PINE_BAKED_TOP)
             return scene_traverse_baked<true, F>(r, g2);
 #else
             return scene_traverse<true, F, kStride>(V, r, stack, g2, p2);

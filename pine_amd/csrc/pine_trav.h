@@ -89,6 +89,10 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
           if (ts.sp > (ts.mesh_base >= 0 ? ts.mesh_base : 0)) {
             ts.next = int(stack[(--ts.sp) * STRIDE]);
           } else if (ts.mesh_base >= 0) {
+#ifdef PINE_BAKED_TOP  /* scene-specialised build, one mesh: the top level is code (pine_specialize.h) and the r_ fields carry its results */
+            ts.done = 1;
+          } else if (false) {
+#endif
             // mesh exhausted: back to the top-level leaf it was a primitive of (whatever that state needs next --
             // its pending primitives, its node, or a pop -- the next step does)
             ts.next = ts.r_next, ts.pa = ts.r_pa, ts.pan = ts.r_pan, ts.pb = ts.r_pb, ts.pbn = ts.r_pbn;

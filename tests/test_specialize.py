@@ -81,7 +81,9 @@ def test_literals_are_exact_for_denormals_signed_zeros_and_huge_values(tmp_path,
 def test_scenes_that_do_not_qualify_generate_nothing():
     import pine_amd as pa
     from pine_amd import scenes
-    assert _source(scenes.sss((32, 32), 1)) == ""  # a mesh
+    assert _source(_two_mesh_scene()) == ""  # two meshes
+    top = _source(scenes.sss((32, 32), 1))  # ONE mesh: its top level only (for the traversal-stage variants)
+    assert "scene_traverse_baked_top" in top and "#define PINE_BAKED_TOP 1" in top and top.count("the mesh: traversed by the flat machine") == 1
     assert _source(scenes.classic_cones((90, 45), 200)) == ""  # too many primitives to unroll
     s = pa.Scene()
     s.add(pa.Plane([0, 0, 0], [0, 1, 0]), pa.Diffuse([0.5, 0.5, 0.5]))  # fine: finite records
@@ -268,6 +270,39 @@ def test_specialised_random_scenes_equal_the_precompiled_kernels():
     assert done[1] >= 5 and done[2] >= 5, done
 
 
+def _two_mesh_scene():
+    import pine_amd as pa
+    from pine_amd import scenes
+    sc = pa.Scene()
+    sc.add("w", pa.Diffuse([0.8, 0.8, 0.8]))
+    sc.add("skin", pa.Subsurface([0.9, 0.8, 0.7], 0.2, [20.0, 30.0, 40.0]))
+    sc.add(pa.Rect([0, 0, 1], [2, 0, 0], [0, 0, 2], True), "w")
+    for x in (-0.4, 0.4):
+        v, f = scenes.icosphere(1, 0.3, (x, 0.5, 1.0))
+        sc.add(pa.Mesh(v, f), "skin")
+    sc.add(pa.Rect([0.0, 1.9, 1], [0.5, 0, 0], [0, 0, 0.5]), pa.Emissive([20.0, 18.0, 15.0]))
+    sc.set(pa.ThinLenCamera(pa.Film([32, 32]), [0, 1, -4], [0, 1, 0], 0.25))
+    return sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level, skin", [(1, "sss"), (2, "sss"), (2, "glossy_emissive"), (3, "sss")])
+def test_one_mesh_scenes_bake_their_top_level(oracle, level, skin):
+    """A scene with ONE mesh under a small top level (BASELINE's Subsurface icosphere): the top-level BVH becomes code run once
+    per ray, the flat traversal keeps the mesh.  Primitives stored after the mesh in pine's order are
+    settled by replaying the top level with the mesh's hit in its place: the film is the oracle's, bit for bit -- closed
+    rooms (every ray that hits the mesh also hit a wall behind it), an emissive mesh, walk stage and sample tokens included."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    kw = {} if skin == "sss" else dict(skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True)
+    sc = scenes.sss((40, 40), level, **kw)
+    a, st = _render(sc, 16, 6, specialize=True)
+    ref, _ = oracle.render(sc.describe(), (40, 40), 16, 6)
+    if st.block_threads == 1024 and (st.kernel_features & 0x8000):  # (traversal stages chosen: the mesh's BVH fits the LDS cache)
+        assert st.specialized == 2
+    assert_bit_equal(a, ref, f"top level baked, icosphere level {level}, {skin}")
+
+
 @pytest.mark.gpu
 def test_specialise_under_sharding_and_by_environment(monkeypatch):
     import torch
@@ -296,10 +331,10 @@ def test_specialise_under_sharding_and_by_environment(monkeypatch):
     assert st.specialized == 1 and st.kernel_features & 0xff == 0
     assert_bit_equal(a, b, "feature-set kernel without the baked scene")
     monkeypatch.setenv("PINE_GPU_SPECIALIZE", "0")
-    # a scene with nothing to gain (a mesh: nothing to bake; its variant already is its feature set) renders with the
+    # a scene with nothing to gain (two meshes: nothing to bake; its variant already is its feature set) renders with the
     # precompiled kernel, flag or not
     monkeypatch.delenv("PINE_GPU_SPECIALIZE")
-    f, st = _render(scenes.sss((32, 32), 1), 8, 4, specialize=True)
+    f, st = _render(_two_mesh_scene(), 8, 4, specialize=True)
     assert st.specialized == 0
     # a Subsurface mesh among other kinds: the everything kernel is replaced by the scene's own feature set (walk stage,
     # sample tokens and traversal stages included)
