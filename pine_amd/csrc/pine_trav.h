@@ -113,7 +113,16 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
     // primitive arm runs once for whoever has found a leaf meanwhile; those lanes sit the second node step out.  The order of
     // a ray's steps is unchanged.  10 000 cones: 7.10 -> 6.82 ms (three steps: 6.83).  In the traversal STAGES (lanes refilled;
     // mesh scenes) two steps are neutral (C5 131.9 -> 131.4 ms) and three or four cost 5 - 9 %: one step there.
-    constexpr int kNodeReps = (F & F_XSTAGE) != 0 ? 1 : 2;
+    // ... and two again where the top level is code and the trips are the mesh's alone (pine_specialize.h: node arm and
+    // triangle arm only): C5 100.7 -> 94.8 ms (three: 96.5).
+#ifndef PINE_NODE_REPS_X
+#ifdef PINE_BAKED_TOP
+#define PINE_NODE_REPS_X 2
+#else
+#define PINE_NODE_REPS_X 1
+#endif
+#endif
+    constexpr int kNodeReps = (F & F_XSTAGE) != 0 ? PINE_NODE_REPS_X : 2;
 #pragma unroll
     for (int rep = 0; rep < kNodeReps; rep++) {
     if (rep > 0) next_step();
