@@ -1,7 +1,10 @@
 """GPU: fuzz the BAKED traversal of scene-specialised kernels against the CPU oracle: seeded random rooms of
 axis-aligned Rects in every orientation (flipped or not, either edge order, negative edges, walls that overlap, touch and share
 edges -- exact ties in t), plus a few other shapes, seen by cameras inside and outside, on the axes and off.
-usage: python tools/fuzz_baked.py N [first_seed]   -- every film must match bit for bit, every plan must be level 2."""
+usage: python tools/fuzz_baked.py N [first_seed] [mesh]  -- every film must match bit for bit, every plan must be level 2.
+With `mesh`: each room also holds ONE mesh (an icosphere or a few loose triangles; Subsurface, Diffuse, Glossy or Emissive) anywhere
+-- inside, through a wall, outside -- so that it lands before, between and after the Rects in pine's order: the top level is
+baked, the mesh stays with the flat traversal, and the replay rule of DESIGN.md 4.9 item 3 is exercised."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +14,8 @@ from oracle import oracle
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
+with_mesh = len(sys.argv) > 3 and sys.argv[3] == "mesh"
+from pine_amd.scenes import icosphere
 stream = torch.cuda.current_stream().cuda_stream
 bad = baked = 0
 for seed in range(base, base + n):
@@ -32,7 +37,19 @@ for seed in range(base, base + n):
         ey[va] = float(r.choice(np.float32([-2, -1, 0.5, 1, 2, 3]))) if r.random() < 0.7 else f(-2, 2) or 1.0
         pos = [q(), q() + 1.0, q() + 1.0] if r.random() < 0.7 else [f(-1, 1), f(0, 2), f(0, 2)]
         s.add(pa.Rect(pos, ex, ey, bool(r.integers(0, 2))), pick())
-    for i in range(int(r.integers(0, 10 - nrect - 1 + 1))):
+    if with_mesh:
+        nrect = min(nrect, 6)
+        kind = int(r.integers(0, 4))
+        mat = [pa.Subsurface([f(0.5, 1), f(0.5, 1), f(0.5, 1)], f(0.0, 0.4), [f(5, 40), f(5, 40), f(5, 40)]), pa.Diffuse([f(0.2, 0.9)] * 3),
+               pa.Glossy([0.9, 0.5, 0.3], f(0.05, 0.4)), pa.Emissive([f(1, 5), f(1, 5), f(1, 5)])][kind]
+        c = (f(-1.2, 1.2), f(-0.2, 2.2), f(-0.2, 2.2))
+        if r.random() < 0.7:
+            vs, fs = icosphere(int(r.integers(0, 3)), f(0.15, 0.6), c)
+        else:
+            vs = np.float32([[c[0] + f(-0.5, 0.5), c[1] + f(-0.5, 0.5), c[2] + f(-0.5, 0.5)] for _ in range(6)])
+            fs = np.uint32([[0, 1, 2], [2, 3, 4], [3, 4, 5], [0, 2, 5]])
+        s.add(pa.Mesh(vs, fs), mat)
+    for i in range(int(r.integers(0, 10 - nrect - 1 + 1 - (1 if with_mesh else 0)))):
         k = int(r.integers(0, 4))
         c = [f(-0.8, 0.8), f(0.2, 1.6), f(0.4, 1.8)]
         if k == 0: s.add(pa.Sphere(c, f(0.1, 0.4)), pick())
@@ -61,6 +78,7 @@ for seed in range(base, base + n):
     ref, _ = oracle.render(s.describe(), (w, h), spp, depth)
     a = film.cpu().numpy()
     mism = int((a.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
+    st_feat = 0
     baked += level == 2
     bad += mism != 0
     print(f"{seed} {w}x{h} spp {spp} depth {depth} rects {nrect} level {level}: mismatched pixels {mism} mean {float(a[..., :3].mean()):.4f}", flush=True)
