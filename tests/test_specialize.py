@@ -291,15 +291,18 @@ def test_one_mesh_scenes_bake_their_top_level(oracle, level, skin):
     """A scene with ONE mesh under a small top level (BASELINE's Subsurface icosphere): the top-level BVH becomes code run once
     per ray, the flat traversal keeps the mesh.  Primitives stored after the mesh in pine's order are
     settled by replaying the top level with the mesh's hit in its place: the film is the oracle's, bit for bit -- closed
-    rooms (every ray that hits the mesh also hit a wall behind it), an emissive mesh, walk stage and sample tokens included."""
+    rooms (every ray that hits the mesh also hit a wall behind it), walk stage and sample tokens included; a scene with a
+    second mesh is left to the flat traversal whole."""
     import pine_amd as pa
     from pine_amd import scenes
     kw = {} if skin == "sss" else dict(skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True)
     sc = scenes.sss((40, 40), level, **kw)
     a, st = _render(sc, 16, 6, specialize=True)
     ref, _ = oracle.render(sc.describe(), (40, 40), 16, 6)
-    if st.block_threads == 1024 and (st.kernel_features & 0x8000):  # (traversal stages chosen: the mesh's BVH fits the LDS cache)
-        assert st.specialized == 2
+    if skin == "sss":  # (ONE mesh; traversal stages chosen: the mesh's BVH fits the LDS cache)
+        assert st.specialized == 2 and (st.kernel_features & 0x8000)
+    else:              # (the emissive-mesh variant of the scene has a second mesh, the lamp: feature set only)
+        assert st.specialized in (0, 1)
     assert_bit_equal(a, ref, f"top level baked, icosphere level {level}, {skin}")
 
 
