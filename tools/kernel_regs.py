@@ -21,9 +21,14 @@ with tempfile.TemporaryDirectory() as tmp:
             break
         n = struct.unpack_from("<Q", data, pos + 24)[0]
         q = pos + 32
+        if n == 0 or n > 64:  # (the magic as a string literal of the host code, not a bundle)
+            pos += 24
+            continue
         for _ in range(n):
             off, size, tl = struct.unpack_from("<QQQ", data, q)
-            triple = data[q + 24:q + 24 + tl].decode()
+            if tl > 256 or off > len(data) or size > len(data):
+                break
+            triple = data[q + 24:q + 24 + tl].decode(errors="replace")
             q += 24 + tl
             if "amdgcn" in triple and size:
                 f = os.path.join(tmp, "co.elf")
