@@ -653,7 +653,7 @@ static int plan_adopt_kernel(pine_gpu_plan* p, bool compile_here) {
 static int plan_check_counters(const Counters& c) {
   if (c.bail_count == 0) return 0;
   static const char* const kWhat[] = {"?", "idle budget exhausted with work outstanding", "ring slot never filled", "item-pool lock never released",
-                                      "work-item hand-out did not converge", "?", "?", "forced by PINE_GPU_FLAG_DEBUG_FORCE_BAIL"};
+                                      "work-item hand-out did not converge", "?", "scene-specialised kernel: a closest-hit ray with an unexpected tmax", "forced by PINE_GPU_FLAG_DEBUG_FORCE_BAIL"};
   char msg[256];
   snprintf(msg, sizeof msg, "path kernel bailed out (%llu wave(s)): code %llu (%s), operands 0x%llx 0x%llx -- the film of this launch is incomplete",
            c.bail_count, c.bail_code, c.bail_code < 8 ? kWhat[c.bail_code] : "?", c.bail_a, c.bail_b);

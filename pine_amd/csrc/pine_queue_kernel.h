@@ -323,6 +323,38 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   };
 #endif
   auto trav_record = [&](int id) -> uint32_t* { return ctxg + (ctx_base + size_t(id)) * kQCtxGlobalDwords + kQCtxTravOffset; };
+#ifdef PINE_BAKED_TOP
+  // Top level baked (pine_specialize.h), closest-hit rays: the first pass over the top-level primitives runs where the ray is
+  // CREATED (stages S / T: every lane of the wave has one).  A ray that does not reach the mesh is resolved here -- true:
+  // hit word and tmax are in the context as finish_hit leaves them -- and never sees the traversal stages.  Otherwise the
+  // context carries what stage XC needs: CF_TMAX = tmax at the mesh's place, CF_PRIM = tmax after ALL top-level primitives,
+  // CF_GEOM = ids of the hit at the mesh's place and of the final hit (4 bits each, 0 = none) | bit 8: a camera ray (its
+  // original tmax is the float maximum; a spawned ray's is spawn_ray's constant -- the replay starts from it).
+  auto top_first_pass = [&](int id, f3 o, f3 d, float tmax) -> bool {
+    DRay r{o, d, 0.0f, tmax};
+    BakedMesh bm{false, 0.0f, -1};
+    int g = -1;
+    const bool hit = scene_traverse_baked_top<false, F, 0>(r, g, bm);
+    if (!bm.reached) {
+      cstf[CF_TMAX * kQCtx + id] = r.tmax;
+      cstu[CF_GEOM * kQCtx + id] = unsigned(hit ? baked_top_word(g) : -1);
+      cstu[CF_PRIM * kQCtx + id] = 0u;
+      return true;
+    }
+    const bool camera = tmax == kFloatMax;
+    if (!camera && tmax != kFloatMax * (1.0f - 1e-3f)) {  // (no other closest-hit ray exists: bail-out code 6, reported by the host)
+      __atomic_store_n(&qctl[QC_ABORT], 1u, __ATOMIC_RELAXED);
+      atomicAdd(&counters->bail_count, 1ull);
+      counters->bail_code = 6;
+      counters->bail_a = __float_as_uint(tmax);
+      counters->bail_b = 0;
+    }
+    cstf[CF_TMAX * kQCtx + id] = bm.t;
+    cstf[CF_PRIM * kQCtx + id] = r.tmax;
+    cstu[CF_GEOM * kQCtx + id] = unsigned(bm.geom + 1) | (unsigned((hit ? g : -1) + 1) << 4) | (camera ? 256u : 0u);
+    return false;
+  };
+#endif
   // trace the context's new ray (closest hit), record the hit, classify (finish_hit).  X variants: the ray waits in
   // the context and the context goes to XC; the traversal stage traces it.
   auto extend = [&](int id, f3 o, f3 d, float tmax, PackedState st, bool& to_shade, bool& to_term, bool& to_xc) {
@@ -336,8 +368,17 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     cstf[CF_DZ * kQCtx + id] = d.z;
     cstu[CF_ST * kQCtx + id] = st.v;
     if constexpr (kX) {
+#if defined(PINE_BAKED_TOP) && !defined(PINE_TOP_CLOSEST_IN_XC)
+      if (top_first_pass(id, o, d, tmax)) {
+        const int geom = int(cstu[CF_GEOM * kQCtx + id]);
+        finish_hit(id, geom >= 0, cstf[CF_TMAX * kQCtx + id], geom, 0, st, to_shade, to_term);
+      } else {
+        to_xc = true;  // the mesh's BVH: stage XC
+      }
+#else
       cstf[CF_TMAX * kQCtx + id] = tmax;
       to_xc = true;  // traced by stage XC
+#endif
     } else if constexpr (kFlat) {
       // the flat traversal, here and now: every lane of the wave to its end
       TravState ts;
@@ -453,18 +494,37 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
           ts.done = 1;
           ts.r_next = 0;
           if (ANY) {
+#ifdef PINE_TOP_SHADOW_IN_XS  /* (measurement: the shadow rays' top-level pass here instead of in stage S) */
             const bool occluded = scene_traverse_baked_top<true, F, 0>(ray, g, bm);
             ts.hit_geom = occluded ? 0 : -1;
             if (occluded) bm.reached = false;
+#else
+            ts.hit_geom = -1;  // (stage S ran the top level for this ray and found it clear up to the mesh)
+            bm.reached = true;
+#endif
           } else {
+#ifdef PINE_TOP_CLOSEST_IN_XC  /* (measurement: the closest-hit rays' first pass here instead of where the ray is created) */
+            const bool ray_is_camera = ray.tmax == kFloatMax;
             const bool hit = scene_traverse_baked_top<false, F, 0>(ray, g, bm);
-            ts.hit_geom = hit ? g : -1;
+            ts.hit_geom = hit ? baked_top_word(g) : -1;
             if (bm.reached) {
               ts.r_pa = __float_as_int(ray.tmax), ts.r_pan = ts.hit_geom;
-              ts.r_pb = (ts.hit_geom != bm.geom) ? 1 : 0;  // (an accepted primitive replaces the hit word: ids are unique)
+              ts.r_pb = (hit ? g : -1) != bm.geom ? 1 : 0;  // (an accepted primitive replaces the hit id: ids are unique)
+              ts.r_pbn = ray_is_camera ? 1 : 0;
               ray.tmax = bm.t;
-              ts.hit_geom = bm.geom;
+              ts.hit_geom = bm.geom >= 0 ? baked_top_word(bm.geom) : -1;
             }
+#else
+            // the first pass ran where the ray was created (top_first_pass): ray.tmax = tmax at the mesh's place already
+            const unsigned packed = cstu[CF_GEOM * kQCtx + id];
+            const int id_a = int(packed & 15u) - 1, id_r = int((packed >> 4) & 15u) - 1;
+            ts.hit_geom = id_a >= 0 ? baked_top_word(id_a) : -1;
+            ts.r_pa = __float_as_int(cstf[CF_PRIM * kQCtx + id]);
+            ts.r_pan = id_r >= 0 ? baked_top_word(id_r) : -1;
+            ts.r_pb = id_r != id_a ? 1 : 0;
+            ts.r_pbn = int((packed >> 8) & 1u);
+            bm.reached = true;
+#endif
           }
           if (bm.reached) {
             const DBvh mb = V.bvhs[1];
@@ -520,7 +580,12 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
                 r[2] = r[3] = r[4] = 0.0f;
               }
             }
-            to_xc = true;  // its new ray waits in the context
+            if (flags & kTravClosestResolved) {  // (top level baked: its new ray never reached the mesh -- hit word and tmax are in the context)
+              const int geom = int(cstu[CF_GEOM * kQCtx + id]);
+              finish_hit(id, geom >= 0, cstf[CF_TMAX * kQCtx + id], geom, 0, st, to_shade, to_term);
+            } else {
+              to_xc = true;  // its new ray waits in the context
+            }
           }
         } else {
 #ifdef PINE_BAKED_TOP
@@ -533,12 +598,12 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
               // a SMALLER t (were the first pass's final tmax not below the triangle's, no such primitive could pass the
               // reference's test `t < tmax` either: whatever the reference accepts, the first pass accepted or bettered):
               // replay the top level with the mesh's result in its place (the reference's own sequence)
-              DRay rr{ray.o, ray.d, 0.0f, cstf[CF_TMAX * kQCtx + id]};
+              DRay rr{ray.o, ray.d, 0.0f, ts.r_pbn ? kFloatMax : kFloatMax * (1.0f - 1e-3f)};  // (camera_gen_ray's / spawn_ray's tmax)
               BakedMesh bm{true, ray.tmax, -1};
               int g = -1;
               const bool hit = scene_traverse_baked_top<false, F, 1>(rr, g, bm);
               ray.tmax = rr.tmax;
-              ts.hit_geom = hit ? g : -1;
+              ts.hit_geom = hit ? baked_top_word(g) : -1;
             }
           }
 #endif
@@ -995,7 +1060,24 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         const float cosine = absdot(wo_world, it.n);
         // ---- X variants: the shadow ray is traced by stage XS; the fold entry / result below hold the direct term as if
         // visible, and XS clears it when the ray turns out occluded ----
+#if defined(PINE_BAKED_TOP) && !defined(PINE_TOP_SHADOW_IN_XS)
+        // Top level baked (pine_specialize.h): the shadow ray meets the top-level primitives HERE, where the wave's lanes all have
+        // one -- an occluded or a clear ray never sees the traversal stages, and stage XS gets the others at the mesh's root.
+        if (have_shadow) {
+          DRay sr = shadow_ray;
+          BakedMesh bm{false, 0.0f, -1};
+          int g = -1;
+          if (scene_traverse_baked_top<true, F, 0>(sr, g, bm)) {
+            nee = mk3(0.0f);  // occluded
+            have_shadow = false;
+          } else if (!bm.reached) {
+            have_shadow = false;  // visible
+          }
+        }
+#endif
         const bool parked_shadow = kX && have_shadow;
+        bool closest_resolved = false;  // (top level baked: the new ray ended in the top-level code)
+        (void)closest_resolved;
         if constexpr (kFlat && !kX) {
           // ... or (F_LDS_TOP variants without traversal stages) here, now that the BSDF has been sampled and little is live
           if (__ballot(have_shadow) != 0) {
@@ -1057,6 +1139,9 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             cstf[CF_DZ * kQCtx + id] = nr.d.z;
             cstf[CF_TMAX * kQCtx + id] = nr.tmax;
             cstu[CF_ST * kQCtx + id] = st.v;
+#if defined(PINE_BAKED_TOP) && !defined(PINE_TOP_CLOSEST_IN_XC)
+            closest_resolved = top_first_pass(id, nr.o, nr.d, nr.tmax);  // (stage XS classifies the context itself then)
+#endif
           } else {
             extend(id, nr.o, nr.d, nr.tmax, st, to_shade, to_term, to_xc);
           }
@@ -1085,7 +1170,8 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
             uint32_t* rec = trav_record(id);
             float4* r4 = reinterpret_cast<float4*>(rec);
             r4[0] = make_float4(shadow_ray.o.x, shadow_ray.o.y, shadow_ray.o.z, shadow_ray.d.x);
-            r4[1] = make_float4(shadow_ray.d.y, shadow_ray.d.z, shadow_ray.tmax, __uint_as_float(continues ? 0u : kTravTerminalAfterShadow));
+            r4[1] = make_float4(shadow_ray.d.y, shadow_ray.d.z, shadow_ray.tmax,
+                                __uint_as_float((continues ? 0u : kTravTerminalAfterShadow) | (closest_resolved ? kTravClosestResolved : 0u)));
             to_xs = true;
           }
         }

@@ -31,7 +31,10 @@ struct TravState {
 };
 constexpr int kTravRecordDwords = 8;  // a context's shadow-ray record in its global record: origin, direction, tmax, flags
 // flags word of a shadow-ray record
-enum : unsigned { kTravTerminalAfterShadow = 1u };  // the vertex has no continuation: after the shadow ray the context goes to stage T
+enum : unsigned {
+  kTravTerminalAfterShadow = 1u,  // the vertex has no continuation: after the shadow ray the context goes to stage T
+  kTravClosestResolved = 2u,      // (top level baked, pine_specialize.h) the vertex's new ray ended in the top-level code: result in the context
+};
 
 __device__ __forceinline__ void trav_begin(const SceneView& S, TravState& ts) {
   ts.next = -1;
