@@ -244,8 +244,9 @@ typedef struct {
                                     set (shape kinds, material lobes, node programs, light kinds, sampler) instead of the
                                     nearest precompiled superset; (2) small scenes without meshes (at most 10 primitives:
                                     cbox-class) get their BVH and every primitive record baked into the kernel as immediates,
-                                    the traversal fully unrolled.  Same arithmetic, same order: bit-identical films; cbox 20 %
-                                    faster.  Costs one `hipcc --genco` run (seconds; cached on disk by content) and needs
+                                    the traversal fully unrolled; a small top level around ONE mesh becomes code run where a ray
+                                    is created, and only rays that reach the mesh enter the traversal stages.  Same tests in
+                                    pine's order: bit-identical films; cbox 24 % faster, the Subsurface icosphere 46 %.  Costs one `hipcc --genco` run (seconds; cached on disk by content) and needs
                                     hipcc and this library's device headers at run time.  A scene with nothing to gain
                                     renders with the precompiled kernel (plan stats: `specialized`); a kernel that cannot be
                                     built fails the plan.  Also $PINE_GPU_SPECIALIZE=1 (every plan) / =0 (never). */
