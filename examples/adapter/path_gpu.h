@@ -108,8 +108,9 @@ struct GpuPathIntegrator {
 
   Sampler sampler;
   int max_path_length;
-  // compile the path kernel for the scene at hand (its exact feature set; small scenes baked in): same film, cbox 24 %
-  // faster, seconds of hipcc the first time a scene's geometry is seen (cached on disk)
+  // the scene's own path kernel (its exact feature set; small scenes baked in): same film, cbox 24 % faster.  By default the
+  // library loads it from its on-disk cache, or compiles it in the background while the precompiled kernel renders this call;
+  // true: wait for the compiler here (seconds of hipcc the first time a geometry is seen) and fail if it cannot be built
   bool specialize = false;
 };
 

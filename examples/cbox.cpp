@@ -33,8 +33,11 @@ int main(int argc, char** argv) {
     scene.set(ThinLenCamera(Film({size, size}, Uncharted2()), {0, 0, 0}, {0, 0, 1}, 0.4f));
 
     auto t0 = std::chrono::steady_clock::now();
-    // (CBOX_SPECIALIZE=1: the kernel compiled for this scene -- same film)
-    PathIntegrator(BlueSampler(spp), depth).specialize(getenv("CBOX_SPECIALIZE") != nullptr).render(scene);
+    // (the library uses the scene's own kernel when its cache has it and compiles it in the background otherwise;
+    //  CBOX_SPECIALIZE=1 waits for the compiler here, =0 keeps to the precompiled kernels -- same film either way)
+    PathIntegrator integrator(BlueSampler(spp), depth);
+    if (const char* e = getenv("CBOX_SPECIALIZE")) integrator.specialize(atoi(e) != 0);
+    integrator.render(scene);
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     auto& film = scene.camera.film();
     FILE* f = fopen(argv[5], "wb");

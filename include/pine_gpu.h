@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PINE_GPU_ABI_VERSION 3
+#define PINE_GPU_ABI_VERSION 4
 
 typedef struct pine_gpu_scene pine_gpu_scene; /* replaces pine::Scene, src/pine/core/scene.h:14-43 */
 typedef struct pine_gpu_plan pine_gpu_plan;   /* a PathIntegrator bound to a scene + device state */
@@ -240,24 +240,30 @@ typedef struct {
                                     accel; also $PINE_GPU_DEVICE_BVH=1.  pine_gpu_plan_stats.accel_built_on_device says what happened. */
 #define PINE_GPU_FLAG_DEBUG_FORCE_BAIL 0x100 /* test hook: the stage-queued path kernel raises its protocol-failure
                                     bail-out at once; every synchronising entry point must then FAIL (never return the film) */
-#define PINE_GPU_FLAG_SPECIALIZE 0x400 /* compile the path kernel FOR THIS SCENE at plan creation: (1) with exactly the scene's feature
-                                    set (shape kinds, material lobes, node programs, light kinds, sampler) instead of the
-                                    nearest precompiled superset; (2) small scenes without meshes (at most 10 primitives:
-                                    cbox-class) get their BVH and every primitive record baked into the kernel as immediates,
-                                    the traversal fully unrolled; a small top level around ONE mesh becomes code run where a ray
-                                    is created, and only rays that reach the mesh enter the traversal stages.  Same tests in
-                                    pine's order: bit-identical films; cbox 24 % faster, the Subsurface icosphere 46 %.  Costs one `hipcc --genco` run (seconds; cached on disk by content) and needs
-                                    hipcc and this library's device headers at run time.  A scene with nothing to gain
-                                    renders with the precompiled kernel (plan stats: `specialized`); a kernel that cannot be
-                                    built fails the plan.  Also $PINE_GPU_SPECIALIZE=1 (every plan) / =0 (never). */
-#define PINE_GPU_FLAG_SPECIALIZE_NO_BAKE 0x800 /* with PINE_GPU_FLAG_SPECIALIZE: the exact feature set only, never the baked scene --
+/* Scene-specialised kernels.  The path kernel can be compiled FOR THE SCENE: (1) with exactly the scene's
+ * feature set (shape kinds, material lobes, node programs, light kinds, sampler) instead of the nearest precompiled superset;
+ * (2) small scenes without meshes (at most 10 primitives: cbox-class) get their BVH and every primitive record baked into the
+ * kernel as immediates, the traversal fully unrolled; a small top level around ONE mesh becomes code run where a ray is
+ * created, and only rays that reach the mesh enter the traversal stages.  Same tests in pine's order: bit-identical films;
+ * cbox 24 % faster, the Subsurface icosphere 46 %.  A build is one `hipcc --genco` run in a child process (seconds), cached
+ * on disk by content ($PINE_GPU_CACHE_DIR, else ~/.cache/pine_gpu); it needs hipcc and this library's device headers.
+ *
+ * DEFAULT (no flag) -- automatic, never in the caller's way: a code object already in the cache is loaded at plan creation
+ * (about a millisecond); otherwise the compiler runs in the BACKGROUND while the precompiled kernel renders, and the first
+ * launch after it has finished -- of this plan or of any later plan or pine_gpu_path_render call on the same geometry -- runs
+ * the scene's own kernel.  Nothing fails because of it: no compiler, no headers, no cache directory or a full compile queue
+ * leave the precompiled kernel in place.  What ran is in pine_gpu_plan_stats (`specialized`, `specialize_source`,
+ * `specialize_pending`).  $PINE_GPU_SPECIALIZE=0 (or PINE_GPU_FLAG_NO_SPECIALIZE): precompiled kernels only. */
+#define PINE_GPU_FLAG_SPECIALIZE 0x400 /* the caller WANTS the scene's kernel from the first launch: plan creation waits for the
+                                    compiler, and a kernel that cannot be built fails the plan.  A scene with nothing to gain
+                                    renders with the precompiled kernel.  Also $PINE_GPU_SPECIALIZE=1 (every plan). */
+#define PINE_GPU_FLAG_SPECIALIZE_NO_BAKE 0x800 /* (either mode) the exact feature set only, never the baked scene --
                                     for geometry that changes from render to render (an animation): a baked kernel is keyed by
                                     the geometry and would be compiled per frame, a feature-set kernel once */
-#define PINE_GPU_FLAG_SPECIALIZE_ASYNC 0x1000 /* with PINE_GPU_FLAG_SPECIALIZE: plan creation does not wait for the compiler -- it runs on a
-                                    background thread while the precompiled kernel renders; the first launch after it has
-                                    finished (and every later one) runs the scene's own kernel.  The films are the same either
-                                    way.  A build that fails leaves the precompiled kernel in place (plan stats: specialized
-                                    == -1); destroying the plan waits for a build in progress. */
+#define PINE_GPU_FLAG_SPECIALIZE_ASYNC 0x1000 /* with PINE_GPU_FLAG_SPECIALIZE: plan creation does not wait for the compiler -- the
+                                    background build of the default mode, but a build that fails is reported (plan stats:
+                                    specialized == -1) instead of passing silently */
+#define PINE_GPU_FLAG_NO_SPECIALIZE 0x2000 /* the precompiled kernel table only: no cache lookup, no background compiler */
 #define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are
@@ -320,11 +326,14 @@ typedef struct {
   int32_t serial_tiles;      /* tile classes (Subsurface scenes): 8x8 tiles of this shard whose pixels are one whole-pixel item each
                               * because a camera ray of theirs can reach a Subsurface shape; the others' samples are independent
                               * items of samples_per_item samples.  0: one class (samples_per_item describes every item) */
-  int32_t specialized;       /* PINE_GPU_FLAG_SPECIALIZE: 0 a precompiled kernel runs (no gain possible, or -- _ASYNC -- the build is still
+  int32_t specialized;       /* 0 a precompiled kernel runs (no gain possible, specialisation off, or a background build is still
                               * running); 1 a kernel compiled for this scene's exact feature set; 2 ... with the scene's BVH and
-                              * primitive records baked in as well; -1 (_ASYNC) the build failed, the precompiled kernel keeps running */
+                              * primitive records baked in as well; -1 a background build failed, the precompiled kernel keeps running */
   float specialize_ms;       /* host: generating + compiling (or fetching from the cache) + loading that kernel at plan creation */
   uint32_t kernel_features;  /* feature bits (pine_device.h F_*) of the path kernel in use */
+  int32_t specialize_source; /* where the scene's kernel came (or will come) from: 0 none; 1 the on-disk cache; 2 compiled at plan
+                              * creation (PINE_GPU_FLAG_SPECIALIZE); 3 compiled in the background by this process           */
+  int32_t specialize_pending;/* 1: a background build is still running (the precompiled kernel renders meanwhile)             */
   int32_t reserved;
 } pine_gpu_plan_stats;
 /* PINE_GPU_FLAG_SPECIALIZE, host half: the text plan creation would compile for this scene (its BVH as straight-line code,

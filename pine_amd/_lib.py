@@ -57,6 +57,8 @@ class PlanStats(C.Structure):
         ("specialized", C.c_int32),
         ("specialize_ms", C.c_float),
         ("kernel_features", C.c_uint32),
+        ("specialize_source", C.c_int32),
+        ("specialize_pending", C.c_int32),
         ("reserved", C.c_int32),
     ]
 
@@ -70,6 +72,7 @@ FLAG_VERTEX_LOG = 0x200
 FLAG_SPECIALIZE = 0x400
 FLAG_SPECIALIZE_NO_BAKE = 0x800
 FLAG_SPECIALIZE_ASYNC = 0x1000
+FLAG_NO_SPECIALIZE = 0x2000
 
 # every symbol include/pine_gpu.h declares, with its signature
 SIGNATURES = {

@@ -551,15 +551,22 @@ class Scene:
 
 
 # ---- PathIntegrator (program_context.cpp:76-81) -------------------------------------------------
+def _specialize_flags(specialize):
+    if specialize is None:
+        return 0
+    return _lib.FLAG_SPECIALIZE if specialize else _lib.FLAG_NO_SPECIALIZE
+
+
 class Plan:
     """A PathIntegrator bound to a scene with all device state resident (bench / multi-GPU)."""
 
     def __init__(self, scene, spp, max_path_length, device=0, shard_rank=0, shard_world=1,
-                 samples_per_item=0, timing=False, sampler="blue", flags=0, specialize=False):
+                 samples_per_item=0, timing=False, sampler="blue", flags=0, specialize=None):
         """spp: an int (BlueSampler(spp), or SobolSampler(spp) with sampler="sobol") or a sampler object.
-        specialize: PINE_GPU_FLAG_SPECIALIZE -- compile the path kernel for this scene when it qualifies (stats().specialized)."""
-        if specialize:
-            flags = int(flags) | _lib.FLAG_SPECIALIZE
+        specialize: None -- the library's default: the scene's own kernel from the cache, else compiled in the background
+        while the precompiled kernel renders; True -- PINE_GPU_FLAG_SPECIALIZE: wait for the compiler at plan creation, fail if
+        the kernel cannot be built; False -- PINE_GPU_FLAG_NO_SPECIALIZE: precompiled kernels only (stats().specialized tells)."""
+        flags = int(flags) | _specialize_flags(specialize)
         if scene.camera is None:
             raise PineError("scene has no camera")
         self.scene = scene
@@ -630,12 +637,11 @@ class PathIntegrator:
     """PathIntegrator(sampler, max_path_length).render(scene) -- the convenience overload a .pine
     script uses (program_context.cpp:79-81); pine-BVH traversal order, UniformLightSampler."""
 
-    def __init__(self, sampler, max_path_length, device=0, flags=0, devices=None, specialize=False):
+    def __init__(self, sampler, max_path_length, device=0, flags=0, devices=None, specialize=None):
         """devices: a list of HIP device ordinals -- the film is rendered by all of them from this one process
         (pine_gpu_path_render_devices); default: the single `device`.
-        specialize: PINE_GPU_FLAG_SPECIALIZE (the path kernel compiled for the scene when it qualifies; same film)."""
-        if specialize:
-            flags = int(flags) | _lib.FLAG_SPECIALIZE
+        specialize: None / True / False as for Plan (the scene's own kernel: automatic / required / never; same film)."""
+        flags = int(flags) | _specialize_flags(specialize)
         if max_path_length <= 0:  # path.cpp:12-13
             raise PineError(f"`PathIntegrator` expect `max_path_length` to be positive, get {max_path_length}")
         self.sampler, self.max_path_length, self.device, self.flags = sampler, int(max_path_length), device, int(flags)

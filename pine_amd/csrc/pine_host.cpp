@@ -1542,10 +1542,9 @@ int pine_gpu_test_specialize_compile(pine_gpu_scene* s, uint32_t features, int c
     text.resize(size_t(n));
     features |= 1u << 17;  // F_BAKED (pine_device.h)
   }
-  const std::string dir = library_dir() + "/..";
   std::string path, err;
   bool hit = false;
-  if (!compile_baked_kernel(text, features, ctx, arch, dir + "/csrc", dir + "/../include", path, err, &hit)) {
+  if (!compile_baked_kernel(text, features, ctx, arch, path, err, &hit)) {
     set_error(err);
     return -1;
   }

@@ -27,6 +27,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -34,6 +37,8 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <signal.h>
+#include <sys/stat.h>
 #include <thread>
 
 #include "../../include/pine_gpu.h"
@@ -553,36 +558,158 @@ struct pine_gpu_plan {
   std::string spec_image;
   unsigned spec_features = 0;  // ... its feature set (the scene's own), and whether the scene's BVH is baked in
   bool spec_baked = false;
-  struct SpecRequest {  // what to compile (filled at plan creation)
-    std::string baked;
-    unsigned features = 0;
-    int ctx = 0;
-    std::string arch;
-    std::chrono::steady_clock::time_point t0;
-  } spec_request;
-  // PINE_GPU_FLAG_SPECIALIZE_ASYNC: the build runs on spec_thread; a launch adopts its result
-  std::atomic<int> spec_state{0};  // kSpecNone / kSpecBuilding / kSpecBuilt (waiting to be adopted) / kSpecAdopted / kSpecFailed
-  std::thread spec_thread;
+  KernelRequest spec_request;  // what to compile (filled at plan creation)
+  std::chrono::steady_clock::time_point spec_t0;
+  bool spec_explicit = false;  // the caller asked for the scene's kernel (PINE_GPU_FLAG_SPECIALIZE): failures are errors
+  int spec_source = 0;         // kSpecSource*: where the scene's kernel came / comes from
+  // background build (the default mode, PINE_GPU_FLAG_SPECIALIZE_ASYNC): a job of the process-wide queue; a launch adopts its result
+  std::atomic<int> spec_state{0};  // kSpecNone / kSpecBuilding / kSpecAdopted / kSpecFailed
+  std::shared_ptr<struct SpecJob> spec_job;
   std::string spec_async_error;
   float specialize_ms = 0.0f;
 };
 
-// PINE_GPU_FLAG_SPECIALIZE / $PINE_GPU_SPECIALIZE (pine_specialize.h): compile the stage-queued kernel FOR THIS SCENE.
+// Scene-specialised kernels (pine_specialize.h): the stage-queued kernel compiled FOR THIS SCENE.
 //  (1) its exact feature set: the precompiled variants are a handful of supersets (pine_variants.h) -- a scene of spheres
 //      under a point light runs the everything-but-Subsurface kernel and pays for every shape kind, node programs and the
 //      Sobol sampler in registers (38 spilled VGPRs).  `need` is what plan_build found in the scene; the LDS layout flags
 //      (and F_SSS, which sizes the per-context records) stay those of the chosen variant, so every buffer size computed
 //      from it stays right.
-//  (2) if the scene has no meshes and its BVH is small enough to unroll: the BVH and primitive records baked in.
-// Nothing to gain (the variant IS the exact set, nothing to bake): the precompiled kernel runs.  A kernel that cannot be
-// built (no hipcc, no headers, no cache directory) fails the plan: the caller asked for it.
+//  (2) if the scene has no meshes and its BVH is small enough to unroll: the BVH and primitive records baked in; one mesh
+//      under a small top level: the top level as code.
+// Nothing to gain (the variant IS the exact set, nothing to bake): the precompiled kernel runs.
+//
+// Modes.  DEFAULT (no flag): automatic and never in the caller's way -- a code object already in the cache is loaded at plan
+// creation (about a millisecond); otherwise the compiler runs in the BACKGROUND (a process-wide queue of at most
+// kSpecWorkers compiler children, keyed by content, shared by every plan that wants the same kernel and outliving the plan
+// that asked first) while the precompiled kernel renders; the first launch after the build has finished -- of this plan or of
+// any later plan of the same geometry -- runs the scene's own kernel.  Nothing can fail because of it: no compiler, no
+// headers, no cache directory, a full queue all leave the precompiled kernel in place (plan stats: specialized 0 or -1).
+// PINE_GPU_FLAG_SPECIALIZE (or $PINE_GPU_SPECIALIZE=1): the caller WANTS the scene's kernel -- plan creation waits for the
+// compiler and a kernel that cannot be built fails the plan; with _ASYNC the build runs in the background as above but a
+// failure is still reported (specialized == -1).  PINE_GPU_FLAG_NO_SPECIALIZE / $PINE_GPU_SPECIALIZE=0: precompiled only.
 enum : int { kSpecNone = 0, kSpecBuilding, kSpecBuilt, kSpecAdopted, kSpecFailed };
+enum : int { kSpecSourceNone = 0, kSpecSourceCache = 1, kSpecSourceCompiledHere = 2, kSpecSourceBackground = 3 };
+
+namespace pine_gpu {
+AbiFingerprint abi_fingerprint() {
+  return AbiFingerprint{sizeof(DeviceScene), sizeof(WorkParams), sizeof(Counters), sizeof(DNode), sizeof(DShape), sizeof(DMaterial), sizeof(DLight),
+                        offsetof(WorkParams, total_items), offsetof(DeviceScene, cam), kQFields, kQWinDwords, int(QC_WORDS), kQTokenDwords,
+                        kTravRecordDwords, kQCtxGlobalDwordsPlain, kQCtxGlobalDwordsSss};
+}
+}  // namespace pine_gpu
+
+// The background compile queue.  A job is one code object (content key); plans hold a shared_ptr and poll `state`.  Workers
+// are started on demand, run jobs in order, skip jobs nobody waits for any more, and exit when the queue is empty.  The
+// singleton is never destroyed (worker threads may outlive static destruction); at process exit an atexit handler raises
+// `closing`, ends running compilers (their own process groups) and joins the workers, so nothing of ours runs while the
+// runtime goes down and no half-written build directory is left behind.
+struct SpecJob {
+  KernelRequest req;
+  std::atomic<int> state{kSpecBuilding};
+  std::atomic<int> waiters{0};
+  std::string error;  // (written before `state` becomes kSpecFailed)
+  float compile_ms = 0.0f;
+};
+struct SpecQueue {
+  static constexpr int kSpecWorkers = 2, kMaxPending = 6;
+  std::mutex mu;
+  std::map<std::string, std::shared_ptr<SpecJob>> jobs;  // by key: every job ever started in this process
+  std::deque<std::shared_ptr<SpecJob>> pending;
+  std::vector<std::thread> workers;
+  int running = 0;
+  std::atomic<int> children[kSpecWorkers];
+  std::atomic<bool> closing{false};
+  static SpecQueue& get() {
+    static SpecQueue* q = [] {
+      SpecQueue* x = new SpecQueue();
+      for (auto& c : x->children) c.store(0);
+      atexit([] { SpecQueue::get().shutdown(); });
+      return x;
+    }();
+    return *q;
+  }
+  // the job for `req` (already keyed): an existing one, or a new one queued for a worker; null when the queue is full
+  // (`retry_failed`: a kernel whose build failed earlier in this process is tried again -- the caller asked for it by flag;
+  //  the automatic mode does not spend a compiler run per plan on a kernel that does not build)
+  std::shared_ptr<SpecJob> submit(const KernelRequest& req, bool retry_failed) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (closing.load()) return nullptr;
+    auto it = jobs.find(req.key);
+    if (it != jobs.end() && (it->second->state.load() != kSpecFailed || !retry_failed)) return it->second;
+    if (int(pending.size()) >= kMaxPending) return nullptr;
+    auto job = std::make_shared<SpecJob>();
+    job->req = req;
+    jobs[req.key] = job;
+    pending.push_back(job);
+    if (running < kSpecWorkers) {
+      const int slot = running++;
+      workers.emplace_back([this, slot] { work(slot); });
+    }
+    return job;
+  }
+  void work(int slot) {
+    for (;;) {
+      std::shared_ptr<SpecJob> job;
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        while (!pending.empty() && !job) {
+          job = pending.front();
+          pending.pop_front();
+          if (job->waiters.load() == 0 || closing.load()) {  // nobody wants it any more
+            job->error = "cancelled";
+            job->state.store(kSpecFailed);
+            jobs.erase(job->req.key);
+            job.reset();
+          }
+        }
+        if (!job) {
+          running--;
+          return;
+        }
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      std::string err;
+      struct stat st;
+      const bool ok = (stat(job->req.path.c_str(), &st) == 0 && st.st_size > 0) || kernel_compile(job->req, err, &children[slot]);
+      job->compile_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      job->error = err;
+      job->req.baked.clear();  // (the text is no longer needed: waiting plans keep their own copy)
+      job->req.baked.shrink_to_fit();
+      job->state.store(ok ? kSpecBuilt : kSpecFailed);
+      if (ok) {  // later plans find the code object on disk; only failures are remembered
+        std::lock_guard<std::mutex> lock(mu);
+        jobs.erase(job->req.key);
+      }
+    }
+  }
+  void shutdown() {
+    closing.store(true);
+    for (auto& c : children) {
+      const int pid = c.load();
+      if (pid > 0) kill(-pid, SIGKILL);  // the compiler's process group
+    }
+    std::vector<std::thread> w;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      w.swap(workers);
+    }
+    for (auto& t : w)
+      if (t.joinable()) t.join();
+  }
+};
+
 static int plan_adopt_kernel(pine_gpu_plan* p, bool compile_here);
 static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vector<DShape>& shapes, const std::vector<int>& packed_prims,
                            const pine_gpu_render_params* prm, unsigned need) {
-  bool want = (prm->flags & PINE_GPU_FLAG_SPECIALIZE) != 0;
-  if (const char* e = getenv("PINE_GPU_SPECIALIZE")) want = atoi(e) != 0;
-  if (!want || p->queue_variant < 0 || (prm->flags & (PINE_GPU_FLAG_FAST | PINE_GPU_FLAG_VERTEX_LOG))) return 0;
+  // explicit: the caller asked for the scene's kernel (failures are errors); automatic: the default (failures are silent)
+  bool explicit_want = (prm->flags & PINE_GPU_FLAG_SPECIALIZE) != 0;
+  bool automatic = !explicit_want && !(prm->flags & PINE_GPU_FLAG_NO_SPECIALIZE);
+  if (const char* e = getenv("PINE_GPU_SPECIALIZE")) {
+    if (atoi(e) != 0) explicit_want = true, automatic = false;
+    else explicit_want = automatic = false;
+  }
+  if ((!explicit_want && !automatic) || p->queue_variant < 0 || (prm->flags & (PINE_GPU_FLAG_FAST | PINE_GPU_FLAG_VERTEX_LOG))) return 0;
   const PineKernelVariant& V = kQueueVariants[p->queue_variant];
   const auto t0 = std::chrono::steady_clock::now();
   const unsigned kLayout = F_LDS_SCENE | F_LDS_TOP | F_LDS_REST | F_XSTAGE | F_SSS;
@@ -600,39 +727,65 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
   HIP_OK(hipGetDeviceProperties(&prop, prm->device));
   std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
   if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
-  p->spec_request = {baked, exact, V.ctx, arch, t0};
-  if (prm->flags & PINE_GPU_FLAG_SPECIALIZE_ASYNC) {
-    // the compiler runs beside the first renders (host work only: files and a child process); a launch adopts the kernel
-    // once it is there.  Until then -- and for good if the build fails -- the precompiled kernel renders the same film.
-    p->spec_state.store(kSpecBuilding);
-    p->spec_thread = std::thread([p]() {
-      std::string path, err;
-      const bool ok = compile_baked_kernel(p->spec_request.baked, p->spec_request.features, p->spec_request.ctx, p->spec_request.arch,
-                                           library_dir() + "/../csrc", library_dir() + "/../../include", path, err);
-      p->spec_async_error = err;
-      p->spec_state.store(ok ? kSpecBuilt : kSpecFailed);
-    });
+  KernelRequest& R = p->spec_request;
+  R.baked = baked, R.features = exact, R.ctx = V.ctx, R.arch = arch;
+  p->spec_t0 = t0;
+  p->spec_explicit = explicit_want;
+  std::string err;
+  const int found = kernel_cache_lookup(R, err);
+  if (found < 0) {
+    if (!explicit_want) {  // (no headers / no cache directory: the precompiled kernel it is)
+      R = KernelRequest();
+      return 0;
+    }
+    set_error(err);
+    return -1;
+  }
+  if (found == 1) {
+    // in the cache already: load it now (a file the runtime refuses is recompiled -- here when the caller waits for the
+    // scene's kernel anyway, in the background otherwise)
+    p->spec_source = kSpecSourceCache;
+    if (plan_adopt_kernel(p, explicit_want && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_ASYNC)) == 0) return 0;
+    if (explicit_want && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_ASYNC)) return -1;
+    (void)unlink(R.path.c_str());
+    if (R.packaged && kernel_cache_lookup(R, err, true) != 0) {  // (a damaged packaged object: the user's cache instead)
+      p->spec_state.store(kSpecFailed);
+      return 0;
+    }
+  } else if (explicit_want && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_ASYNC)) {
+    p->spec_source = kSpecSourceCompiledHere;
+    return plan_adopt_kernel(p, true);
+  }
+  // the compiler runs beside the first renders (host work only: files and a child process); a launch adopts the kernel once
+  // it is there.  Until then -- and for good if the build fails -- the precompiled kernel renders the same film.
+  p->spec_source = kSpecSourceBackground;
+  p->spec_job = SpecQueue::get().submit(R, explicit_want);
+  if (!p->spec_job) {
+    p->spec_state.store(explicit_want ? kSpecFailed : kSpecNone);
+    p->spec_async_error = "the background compile queue is full";
     return 0;
   }
-  return plan_adopt_kernel(p, true);
+  p->spec_job->waiters.fetch_add(1);
+  p->spec_state.store(kSpecBuilding);
+  return 0;
 }
 
-// Load the plan's scene-specialised kernel (compiling it first unless the background thread has) and make it the one that
-// launches.  (Two attempts: a cached code object the runtime refuses -- a file cut short by a full disk, another ROCm's
-// output -- is removed and compiled afresh, once.)
+// Load the plan's scene-specialised kernel (compiling it first when `compile_here`) and make it the one that launches.
+// (Two attempts when compiling here: a cached code object the runtime refuses -- a file cut short by a full disk, another
+// ROCm's output -- is removed and compiled afresh, once; a packaged one that cannot be removed is bypassed.)
 static int plan_adopt_kernel(pine_gpu_plan* p, bool compile_here) {
-  const auto& R = p->spec_request;
-  const std::string dir = library_dir() + "/..";
+  KernelRequest& R = p->spec_request;
+  bool skip_packaged = false;
   for (int attempt = 0;; attempt++) {
-    std::string path, err;
-    bool from_cache = false;
-    // (after a background build this is a cache hit)
-    if (!compile_baked_kernel(R.baked, R.features, R.ctx, R.arch, dir + "/csrc", dir + "/../include", path, err, &from_cache)) {
-      set_error(err);
+    std::string err;
+    const int found = kernel_cache_lookup(R, err, skip_packaged);
+    if (found < 0 || (found == 0 && (!compile_here || !kernel_compile(R, err)))) {
+      set_error(found == 0 && !compile_here ? "scene specialisation: the code object is not in the cache" : err);
       return -1;
     }
+    const bool from_cache = found == 1;
     hipError_t e = hipErrorInvalidImage;
-    if (read_file(path, p->spec_image) && code_object_is_whole(p->spec_image)) {  // (kept for the module's lifetime: the runtime may build the program lazily from it)
+    if (read_file(R.path, p->spec_image) && code_object_is_whole(p->spec_image)) {  // (kept for the module's lifetime: the runtime may build the program lazily from it)
       e = hipModuleLoadData(&p->spec_module, p->spec_image.data());
       if (e == hipSuccess) e = hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(R.features, R.ctx).c_str());
     }
@@ -640,14 +793,32 @@ static int plan_adopt_kernel(pine_gpu_plan* p, bool compile_here) {
     (void)hipGetLastError();
     if (p->spec_module) (void)hipModuleUnload(p->spec_module);
     p->spec_module = nullptr, p->spec_fn = nullptr;
-    if (attempt == 0 && compile_here && from_cache && unlink(path.c_str()) == 0) continue;
-    set_error("scene specialisation: the runtime does not load " + path + " (" + hipGetErrorString(e) + ")");
+    if (attempt == 0 && compile_here && from_cache) {
+      if (unlink(R.path.c_str()) != 0) skip_packaged = true;  // (a read-only install: compile into the user's cache instead)
+      continue;
+    }
+    set_error("scene specialisation: the runtime does not load " + R.path + " (" + hipGetErrorString(e) + ")");
     return -1;
   }
   p->spec_features = R.features;
   p->spec_baked = !R.baked.empty();
-  p->specialize_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - R.t0).count();
+  p->specialize_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - p->spec_t0).count();
   return 0;
+}
+
+// PINE_GPU_FLAG_SPECIALIZE_ASYNC / automatic mode: has the background build finished?  Called by every launch and by stats_get.
+static void plan_poll_background(pine_gpu_plan* p) {
+  if (p->spec_state.load() != kSpecBuilding || !p->spec_job) return;
+  const int js = p->spec_job->state.load();
+  if (js == kSpecBuilding) return;
+  if (js == kSpecBuilt && plan_adopt_kernel(p, false) == 0) {
+    p->spec_state.store(kSpecAdopted);
+  } else {
+    p->spec_async_error = js == kSpecFailed ? p->spec_job->error : std::string(pine_gpu_last_error());
+    p->spec_state.store(kSpecFailed);
+  }
+  p->spec_job->waiters.fetch_sub(1);
+  p->spec_job.reset();
 }
 
 static int plan_check_counters(const Counters& c) {
@@ -702,7 +873,10 @@ int pine_gpu_set_table_path(const char* path) {
 
 void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   if (!p) return;
-  if (p->spec_thread.joinable()) p->spec_thread.join();  // (PINE_GPU_FLAG_SPECIALIZE_ASYNC: a build still running is waited for -- seconds at most)
+  if (p->spec_job) {  // (a background build goes on for the next plan of this geometry; a job nobody waits for is dropped from the queue)
+    p->spec_job->waiters.fetch_sub(1);
+    p->spec_job.reset();
+  }
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_blob);
   (void)hipFree(p->d_tri);
@@ -1401,15 +1575,9 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
   hipStream_t stream = (hipStream_t)stream_;
   HIP_OK(hipSetDevice(p->device));
   (void)hipGetLastError();  // (HIP's last error is sticky: what the check at the end reports must come from THIS launch's calls)
-  if (p->spec_state.load() == kSpecBuilt) {
-    // the background build has finished: this launch and every later one run the scene's own kernel.  (A code object the
-    // runtime refuses leaves the precompiled kernel in place -- same film; plan stats say which one runs.)
-    if (plan_adopt_kernel(p, false) == 0) p->spec_state.store(kSpecAdopted);
-    else {
-      p->spec_async_error = pine_gpu_last_error();
-      p->spec_state.store(kSpecFailed);
-    }
-  }
+  // a background build that has finished: this launch and every later one run the scene's own kernel.  (A code object the
+  // runtime refuses leaves the precompiled kernel in place -- same film; plan stats say which one runs.)
+  plan_poll_background(p);
   g_progress.store(0.0f);
   const size_t film_bytes = size_t(p->film_w) * p->film_h * sizeof(float4);
   if (p->W.shard_world > 1 && !packed) HIP_OK(hipMemsetAsync(film_dev, 0, film_bytes, stream));
@@ -1516,7 +1684,10 @@ int pine_gpu_plan_stats_get(pine_gpu_plan* p, pine_gpu_plan_stats* out) {
   out->spp_effective = p->S.spp;
   out->samples_per_item = p->W.samples_per_item;
   out->serial_tiles = p->W.serial_tiles;
+  plan_poll_background(p);
   out->specialized = p->spec_fn ? (p->spec_baked ? 2 : 1) : p->spec_state.load() == kSpecFailed ? -1 : 0;
+  out->specialize_source = p->spec_fn || p->spec_state.load() == kSpecBuilding ? p->spec_source : 0;
+  out->specialize_pending = p->spec_state.load() == kSpecBuilding ? 1 : 0;
   out->kernel_features = p->spec_fn ? p->spec_features : p->fast ? p->fast->features : p->queue_variant >= 0 ? kQueueVariants[p->queue_variant].features
                                                                                          : p->variant >= 0 ? kVariants[p->variant].features : 0u;
   out->specialize_ms = p->specialize_ms;

@@ -81,10 +81,13 @@ constexpr int q_ctx_global_dwords(unsigned F) { return q_ctx_trav_offset(F) + ((
 // context re-queued between steps, so that a wave's 64 lanes are 64 walks in the same phase whatever their
 // lengths.  Stage S starts a walk (refraction into the shape, channel pick) and is entered a second time when
 // the walk has ended, with the exit point in the context's global record.
+// The kernel's body is a device function so that two kinds of __global__ entry can share it: the precompiled
+// path_queue_kernel<F, CTX> below, and the extern "C" entry a scene-specialised translation unit declares under a plain name
+// (pine_specialize.h).  It reads cold kernel arguments straight from the kernel-argument segment (kS / kW below): every entry
+// point must take exactly these arguments in this order, and the body must be inlined into it.
 template <unsigned F, int CTX = PINE_QCTX>
-__global__ void __launch_bounds__(kQBlock, kQBlock / 256)
-path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
-                  float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
+__device__ __forceinline__ void path_queue_body(const DeviceScene& S, const WorkParams& W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
+                                                float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
   constexpr int kNQ = q_num_queues(F);            // rings in LDS
   constexpr int kNStage = q_num_stage_queues(F);  // ... of which the first kNStage are stage queues
   constexpr bool kFork = (F & F_SSS) != 0;        // sample tokens (below)
@@ -1604,6 +1607,13 @@ path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     for (int off = 32; off > 0; off >>= 1) wc += __shfl_down(wc, off);
     if (lane == 0) atomicAdd(&counters->walk_steps, wc);
   }
+}
+
+template <unsigned F, int CTX = PINE_QCTX>
+__global__ void __launch_bounds__(kQBlock, kQBlock / 256)
+path_queue_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ckpt, float4* __restrict__ samples,
+                  float* __restrict__ fold, uint32_t* __restrict__ ctxg, Counters* __restrict__ counters) {
+  path_queue_body<F, CTX>(S, W, ckpt, samples, fold, ctxg, counters);
 }
 
 }  // namespace pine_gpu

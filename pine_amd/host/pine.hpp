@@ -232,9 +232,12 @@ class PathIntegrator {
     devices_ = std::move(devices);
     return *this;
   }
-  // compile the path kernel for the scene at hand (PINE_GPU_FLAG_SPECIALIZE: exact feature set, small scenes baked in; same film)
+  // The scene's own path kernel (same film; pine_gpu.h): by default the library uses it when it is in its cache and compiles it
+  // in the background otherwise.  specialize(true): wait for the compiler at render() and fail if the kernel cannot be built
+  // (PINE_GPU_FLAG_SPECIALIZE); specialize(false): precompiled kernels only (PINE_GPU_FLAG_NO_SPECIALIZE).
   PathIntegrator& specialize(bool on = true) {
-    flags_ = on ? (flags_ | PINE_GPU_FLAG_SPECIALIZE) : (flags_ & ~PINE_GPU_FLAG_SPECIALIZE);
+    flags_ &= ~(PINE_GPU_FLAG_SPECIALIZE | PINE_GPU_FLAG_NO_SPECIALIZE);
+    flags_ |= on ? PINE_GPU_FLAG_SPECIALIZE : PINE_GPU_FLAG_NO_SPECIALIZE;
     return *this;
   }
   void render(Scene& scene) {

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"libpine_gpu.so does not export {n}"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib.pine_gpu_abi_version() == 3
+    assert _lib.lib.pine_gpu_abi_version() == 4
 
 
 def test_host_math_matches_reference():

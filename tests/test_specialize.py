@@ -102,7 +102,7 @@ def test_specialised_kernel_compiles_for_gfx950_and_is_cached(tmp_path, monkeypa
     r = _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024)  # (pine_variants.h order 0: cbox's variant)
     assert r == 0, _lib.last_error()
     blob = open(out.value.decode(), "rb").read()
-    assert b"_ZN8pine_gpu17path_queue_kernelILj131330ELi1536EEEvNS_11DeviceSceneENS_10WorkParams" in blob
+    assert b"pine_scene_kernel_131330_1536" in blob  # (the extern "C" entry: features | F_BAKED, contexts)
     assert _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024) == 1  # cache hit
     assert os.listdir(tmp_path / "cache") == [os.path.basename(out.value.decode())]  # (the build directory is gone)
     # the key is the GEOMETRY (BVH + records): the same room under another camera and lamp colour is the same kernel ...
@@ -131,29 +131,71 @@ def test_feature_sets_without_a_precompiled_variant_compile(tmp_path, monkeypatc
     monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))
     out = C.create_string_buffer(1024)
     assert _lib.lib.pine_gpu_test_specialize_compile(None, features, ctx, b"gfx950", out, 1024) == 0, _lib.last_error()[-1500:]
-    assert f"path_queue_kernelILj{features}ELi{ctx}E".encode() in open(out.value.decode(), "rb").read()
+    assert f"pine_scene_kernel_{features}_{ctx}".encode() in open(out.value.decode(), "rb").read()  # (the extern "C" entry)
 
 
-def test_prebuilt_kernel_of_the_cornell_box_travels_with_the_package(monkeypatch):
-    """__graft_entry__.build() leaves the Cornell box's kernel in pine_amd/lib/kernel_cache/: found there (same content key)
-    before any compiler is looked for."""
+def test_a_packaged_kernel_is_found_before_any_compiler(monkeypatch, tmp_path):
+    """A deployment may ship code objects in pine_amd/lib/kernel_cache/ (a read-only install, a box without hipcc): an entry
+    with the right content key is found there before a compiler or the user's cache is looked for.  (build() ships none:
+    the benchmark's kernels are compiled on the box that runs it.)"""
     from pine_amd import _lib, scenes
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
     cache = os.path.join(os.path.dirname(_lib.LIB_PATH), "kernel_cache")
-    if not os.path.isdir(cache) or not os.listdir(cache):
-        pytest.skip("pine_amd/lib/kernel_cache is empty (build() has not run)")
-    sc = scenes.cbox((640, 640), "committed")
+    sc = scenes.cbox((64, 64), "readme")
     out = C.create_string_buffer(1024)
-    if os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc"):
-        # (is the entry this tree's?  the key moves with the device headers; a stale entry is never found, which is fine)
-        with tempfile.TemporaryDirectory() as tmp:
-            monkeypatch.setenv("PINE_GPU_CACHE_DIR", tmp)
-            assert _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024) == 0, _lib.last_error()
-            if os.path.basename(out.value.decode()) not in os.listdir(cache):
-                pytest.skip("pine_amd/lib/kernel_cache holds a kernel of other headers (run __graft_entry__.build())")
-    monkeypatch.delenv("PINE_GPU_CACHE_DIR", raising=False)
-    monkeypatch.setenv("PINE_GPU_HIPCC", "/nonexistent/hipcc")  # (not needed: must not be looked for)
-    assert _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024) == 1, _lib.last_error()
-    assert os.path.dirname(os.path.realpath(out.value.decode())) == os.path.realpath(cache)
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))
+    assert _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024) == 0, _lib.last_error()
+    built = out.value.decode()
+    os.makedirs(cache, exist_ok=True)
+    packaged = os.path.join(cache, os.path.basename(built))
+    shutil.copy(built, packaged)
+    try:
+        monkeypatch.delenv("PINE_GPU_CACHE_DIR", raising=False)
+        monkeypatch.setenv("HOME", str(tmp_path / "home"))  # (an empty user cache)
+        monkeypatch.delenv("XDG_CACHE_HOME", raising=False)
+        monkeypatch.setenv("PINE_GPU_HIPCC", "/nonexistent/hipcc")  # (not needed: must not be looked for)
+        assert _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024) == 1, _lib.last_error()
+        assert os.path.realpath(out.value.decode()) == os.path.realpath(packaged)
+    finally:
+        os.unlink(packaged)
+        if not os.listdir(cache):
+            os.rmdir(cache)
+
+
+def test_cache_directory_must_be_private(monkeypatch, tmp_path):
+    """A code object found in the cache is loaded and launched: a directory that others can write to is not used."""
+    from pine_amd import _lib, scenes
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    if os.geteuid() == 0:
+        pass  # (root passes access() everywhere; the ownership / mode test still applies)
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(shared))
+    out = C.create_string_buffer(1024)
+    sc = scenes.cbox((64, 64), "readme")
+    r = _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024)
+    assert r in (0, 1), _lib.last_error()
+    assert os.path.dirname(out.value.decode()) != str(shared) and not os.listdir(shared)
+    st = os.lstat(os.path.dirname(out.value.decode()))
+    assert st.st_uid == os.geteuid() and not (st.st_mode & 0o022)
+
+
+def test_generated_unit_checks_the_headers_it_is_compiled_from(monkeypatch, tmp_path):
+    """The run-time compile static_asserts sizeof / offsetof fingerprints of the kernel-argument and counter structures
+    against the library's own: a kernel built from other headers (here: a flag that grows `Counters`) is refused at compile
+    time instead of running with another argument layout."""
+    from pine_amd import _lib, scenes
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("PINE_GPU_SPECIALIZE_EXTRA", "-DPINE_PROFILE_SECTIONS")
+    out = C.create_string_buffer(1024)
+    sc = scenes.cbox((64, 64), "readme")
+    assert _lib.lib.pine_gpu_test_specialize_compile(sc._h, 258, 1536, b"gfx950", out, 1024) < 0
+    assert "not the ones libpine_gpu.so was built from" in _lib.last_error()
 
 
 # ---- GPU ------------------------------------------------------------------------------------------------------------
@@ -258,7 +300,7 @@ def test_specialised_random_scenes_equal_the_precompiled_kernels():
         if done[level] >= 5:
             continue
         a, st = _render(sc, spp, depth, sampler=sampler, specialize=True)
-        b, st0 = _render(sc, spp, depth, sampler=sampler)
+        b, st0 = _render(sc, spp, depth, sampler=sampler, specialize=False)
         assert st0.specialized == 0
         assert_bit_equal(a, b, f"random scene {seed}: specialised (level {level}) vs precompiled")
         assert st.specialized in (0, level)  # (0: the precompiled variant already is the scene's feature set)
@@ -312,7 +354,7 @@ def test_specialise_under_sharding_and_by_environment(monkeypatch):
     import pine_amd as pa
     from pine_amd import _lib, scenes
     sc = scenes.cbox((72, 40), "readme")
-    whole, _ = _render(sc, 16, 5)
+    whole, _ = _render(sc, 16, 5, specialize=False)
     total = np.zeros_like(whole)
     for rank in range(3):
         part, st = _render(sc, 16, 5, shard_rank=rank, shard_world=3, specialize=True)
@@ -330,7 +372,7 @@ def test_specialise_under_sharding_and_by_environment(monkeypatch):
     # the feature set only (geometry that changes every render): cbox without its boxes is Rects only -> F_OBB dropped
     rects = scenes.cbox((72, 40), "readme", False)
     a, st = _render(rects, 16, 5, flags=_lib.FLAG_SPECIALIZE | _lib.FLAG_SPECIALIZE_NO_BAKE)
-    b, _ = _render(rects, 16, 5)
+    b, _ = _render(rects, 16, 5, specialize=False)
     assert st.specialized == 1 and st.kernel_features & 0xff == 0
     assert_bit_equal(a, b, "feature-set kernel without the baked scene")
     monkeypatch.setenv("PINE_GPU_SPECIALIZE", "0")
@@ -343,7 +385,8 @@ def test_specialise_under_sharding_and_by_environment(monkeypatch):
     # sample tokens and traversal stages included)
     sc = scenes.random_scene(4001, variety=2)[0]
     a, st = _render(sc, 16, 6, specialize=True)
-    b, st0 = _render(sc, 16, 6)
+    b, st0 = _render(sc, 16, 6, specialize=False)
+    assert st0.specialized == 0
     assert_bit_equal(a, b, "exact feature set vs the all-features kernel")
 
 
@@ -357,7 +400,7 @@ def test_asynchronous_specialisation_swaps_the_kernel_in_between_launches(monkey
     from pine_amd import _lib, scenes
     monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))  # (empty: the compiler must run)
     sc = scenes.cbox((48, 48), "readme")
-    want, _ = _render(sc, 8, 4)
+    want, _ = _render(sc, 8, 4, specialize=False)
     t0 = time.perf_counter()
     plan = pa.Plan(sc, 8, 4, flags=_lib.FLAG_SPECIALIZE | _lib.FLAG_SPECIALIZE_ASYNC)
     created = time.perf_counter() - t0
@@ -422,3 +465,64 @@ def test_specialise_fails_loudly_without_a_compiler(monkeypatch, tmp_path):
     monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))
     with pytest.raises(pa.PineError, match="hipcc"):
         pa.Plan(scenes.cbox((32, 32), "readme"), 4, 3, specialize=True)
+
+
+@pytest.mark.gpu
+def test_default_mode_never_waits_never_fails_and_uses_the_cache(monkeypatch, tmp_path):
+    """No flag: the scene's kernel comes from the cache when it is there; otherwise the compiler runs in the background while
+    the precompiled kernel renders, a later launch adopts the result, and the NEXT plan of the same geometry -- another
+    camera, film size, spp -- finds it in the cache at creation.  Without a compiler nothing fails.  Same film throughout."""
+    import time
+    import torch
+    import pine_amd as pa
+    from pine_amd import scenes
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))  # (empty: the compiler must run)
+    monkeypatch.delenv("PINE_GPU_SPECIALIZE", raising=False)
+    sc = scenes.cbox((48, 48), "readme")
+    want, st = _render(sc, 8, 4, specialize=False)
+    assert st.specialized == 0 and st.specialize_source == 0 and st.specialize_pending == 0
+    t0 = time.perf_counter()
+    plan = pa.Plan(sc, 8, 4)
+    created = time.perf_counter() - t0
+    film = torch.zeros((48, 48, 4), device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    seen = []
+    deadline = time.perf_counter() + 120
+    while time.perf_counter() < deadline:
+        film.fill_(-1.0)
+        plan.launch(film.data_ptr(), stream)
+        torch.cuda.synchronize()
+        plan.check()
+        st = plan.stats()
+        seen.append((st.specialized, st.specialize_source, st.specialize_pending))
+        assert_bit_equal(film.cpu().numpy(), want, f"film at {seen[-1]}")
+        if st.specialized != 0 or not st.specialize_pending:
+            break
+        time.sleep(0.02)
+    plan.close()
+    assert seen[0] == (0, 3, 1) and created < 0.5, (seen[:2], created)  # creation did not wait; the precompiled kernel rendered first
+    assert seen[-1] == (2, 3, 0), seen[-1]
+    # the next plan of the same geometry (another camera, size, spp): from the cache, at creation
+    other = scenes.cbox((40, 24), "committed")
+    want2, _ = _render(other, 4, 3, specialize=False)
+    got2, st = _render(other, 4, 3)
+    assert (st.specialized, st.specialize_source, st.specialize_pending) == (2, 1, 0)
+    assert_bit_equal(got2, want2, "kernel from the cache")
+    # no compiler, nothing cached: the default mode renders with the precompiled kernel and says so; nothing raises
+    monkeypatch.setenv("PINE_GPU_HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path / "empty"))
+    plan = pa.Plan(sc, 8, 4)
+    level, deadline = 0, time.perf_counter() + 60
+    while time.perf_counter() < deadline:
+        plan.launch(film.data_ptr(), stream)
+        torch.cuda.synchronize()
+        st = plan.stats()
+        if not st.specialize_pending:
+            break
+        time.sleep(0.02)
+    assert st.specialized == -1 and st.specialize_pending == 0
+    assert_bit_equal(film.cpu().numpy(), want, "film without a compiler")
+    plan.close()
+    # ... and the one-shot entry point (what PathIntegrator.render calls) likewise
+    f = pa.PathIntegrator(pa.BlueSampler(8), 4).render(sc).pixels
+    assert_bit_equal(f, want, "one-shot render without a compiler")

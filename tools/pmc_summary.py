@@ -2,14 +2,18 @@
 import csv, collections, glob, json, sys
 agg = collections.defaultdict(list)
 kname = vg = lds = grid = None
-args = [a for a in sys.argv[1:] if not a.startswith("--traffic-json=")]
-traffic_out = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--traffic-json=")), None)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+def opt(name): return next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--" + name + "=")), None)
+traffic_out = opt("traffic-json")
+# --counters-json=FILE --config=c2 --mode=specialised|precompiled: merge this kernel's mean counters into FILE under "config:mode",
+# stamped with the hash of the kernel sources they were measured on (bench.py reads the file and flags a stale entry)
+counters_out, cfg_name, cfg_mode = opt("counters-json"), opt("config"), opt("mode")
 for d in args:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "path_trace" in r["Kernel_Name"] or "path_queue" in r["Kernel_Name"]:
+            if "path_trace" in r["Kernel_Name"] or "path_queue" in r["Kernel_Name"] or "pine_scene_kernel" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                kname = r["Kernel_Name"].split("<")[0].split("::")[-1].split("(")[0].replace("void ", "")
+                kname = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pine_gpu::", "")
                 vg = r.get("VGPR_Count"); lds = r.get("LDS_Block_Size"); grid = r.get("Grid_Size")
 print(f"kernel {kname} VGPR={vg} static_LDS={lds} grid={grid}   (rocprofv3 reports the kernel's STATIC LDS only; these kernels take all of theirs -- "
       f"130 - 160 KB per workgroup -- as dynamic shared memory: see `lds_bytes` of plan stats / tools/sections.py, and VGPR is the descriptor's granule count)")
@@ -34,3 +38,20 @@ if traffic_out and 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
                "traffic_bytes_per_launch": (2.0 * m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024.0,
                "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 read-request correction of the guide); fabric-side bytes, Infinity-Cache hits included",
                "dispatches_averaged": len(agg['FETCH_SIZE'])}, open(traffic_out, "w"), indent=1)
+
+if counters_out and cfg_name and m:
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    try:
+        allc = json.load(open(counters_out))
+    except Exception:
+        allc = {}
+    entry = {"kernel": kname, "mode": cfg_mode or "precompiled", "counters": m, "dispatches_averaged": {k: len(v) for k, v in agg.items()},
+             "kernel_source_hash": bench.kernel_source_hash(),
+             "what": "mean per dispatch of the path kernel over `python bench.py --headline-only` under rocprofv3 --pmc, one counter group per pass"}
+    if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
+        entry["traffic_bytes_per_launch"] = (2.0 * m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024.0
+        entry["traffic_correction"] = "2 x FETCH_SIZE + WRITE_SIZE KB (gfx950 read-request correction of the guide); fabric side, Infinity-Cache hits included"
+    allc[f"{cfg_name}:{entry['mode']}"] = entry
+    json.dump(allc, open(counters_out, "w"), indent=1, sort_keys=True)

@@ -12,6 +12,12 @@
 #include "../../include/pine_gpu.h"
 #include "../../pine_amd/csrc/pine_host.h"
 
+#include "../../pine_amd/csrc/pine_specialize.h"
+
+// (the structure sizes a run-time compiled kernel is checked against come from the device half of the library: none here --
+//  a kernel compiled through this build's pine_gpu_test_specialize_compile fails its static_assert, as it should)
+pine_gpu::AbiFingerprint pine_gpu::abi_fingerprint() { return pine_gpu::AbiFingerprint{}; }
+
 using pine_gpu::set_error;
 static const char* const kNoDevice =
     "no HIP device available: the PathIntegrator hot path requires an AMD GPU (no CPU fallback) [sanitizer build: host code only]";
