@@ -216,8 +216,9 @@ typedef struct {
 
 #define PINE_GPU_SAMPLER_BLUE  0 /* BlueSampler(spp)  src/pine/core/sampler.h:166-201 (the default)           */
 #define PINE_GPU_SAMPLER_SOBOL 1 /* SobolSampler(spp) src/pine/core/sampler.h:83-164, sampler.cpp:81-113: spp
-                                    as given (no clamp to 256); on the device a power of two up to 4096, and
-                                    not together with Subsurface materials                                  */
+                                    as given (no clamp to 256, any count); on the device up to 4096 (a count that is
+                                    not a power of two renders one work item per pixel), and not together with
+                                    Subsurface materials                                                     */
 #define PINE_GPU_SAMPLER_HALTON 2 /* HaltonSampler(spp) src/pine/core/sampler.h:40-81, sampler.cpp:39-79,
                                     lowdiscrepancy.h:26-51: scrambled radical inverses over the first primes; on the
                                     device under SobolSampler's two restrictions                             */
@@ -264,6 +265,15 @@ typedef struct {
                                     background build of the default mode, but a build that fails is reported (plan stats:
                                     specialized == -1) instead of passing silently */
 #define PINE_GPU_FLAG_NO_SPECIALIZE 0x2000 /* the precompiled kernel table only: no cache lookup, no background compiler */
+#define PINE_GPU_FLAG_ORDER_NEAREST 0x4000 /* closest-hit queries test the scene's primitives NEAREST BOUNDS FIRST instead of in pine-BVH
+                                    order: the order of a nearest-first hierarchy with one primitive per leaf, which is what the reference's
+                                    EmbreeAccel is (src/pine/impl/accel/embree.cpp:101-143,195-257) -- the accel a .pine script gets from
+                                    PathIntegrator(sampler, n) on real pine (program_context.cpp:79-81).  It matters for ONE shape: the scaled
+                                    Box(AABB, mat4), whose intersect clips the object-space interval with the WORLD tmax
+                                    (src/pine/core/bbox.cpp:149-171) and so depends on what was tested before it.  With the flag the films of
+                                    the real reference built with EmbreeAccel are reproduced bit for bit on cbox (tests/golden/film_embree_*);
+                                    without it (the default, and the parity gate) those of Accel(BVH()).  Scenes without a scaled Box render
+                                    the same film either way.  At most 64 top-level primitives (a mesh counts as one); not with _FAST. */
 #define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are

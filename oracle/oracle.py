@@ -45,18 +45,21 @@ def _tp():
     return _tables.ctypes.data_as(C.c_void_p)
 
 
-def render(pscene: str, size, spp, depth, threads=0, rows=None, sampler="blue"):
-    """-> (film[h,w,4] float32, Stats).  sampler: "blue" = BlueSampler(spp), "sobol" = SobolSampler(spp), "halton" = HaltonSampler(spp)."""
+def render(pscene: str, size, spp, depth, threads=0, rows=None, sampler="blue", order="pine"):
+    """-> (film[h,w,4] float32, Stats).  sampler: "blue" = BlueSampler(spp), "sobol" = SobolSampler(spp), "halton" = HaltonSampler(spp).
+    order: "pine" = the reference's BVH order (the parity oracle); "nearest" = nearest bounds first (PINE_GPU_FLAG_ORDER_NEAREST)."""
     w, h = size
     film = np.zeros((h, w, 4), np.float32)
     st = Stats()
     y0, y1 = rows if rows else (0, 0)
     lib().oracle_set_sampler({"sobol": 1, "halton": 2}.get(sampler, 0))
+    lib().oracle_set_order(1 if order == "nearest" else 0)
     try:
         rc = lib().oracle_render(pscene.encode(), _tp(), int(spp), int(depth), int(threads), int(y0), int(y1),
                                  film.ctypes.data_as(C.c_void_p), C.byref(st))
     finally:
         lib().oracle_set_sampler(0)
+        lib().oracle_set_order(0)
     if rc:
         raise RuntimeError(f"oracle_render: {lib().oracle_last_error().decode()}")
     return film, st

@@ -20,6 +20,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -795,6 +796,19 @@ struct AABB {
     tmin = fmax_(tmin0, fmax_(tmin1, fmax_(tmin2, tmin)));
     tmax = fmin_(tmax0, fmin_(tmax1, fmin_(tmax2, tmax)));
     return tmin <= tmax;
+  }
+  // the same slab test, reporting the ENTRY distance (order mode "nearest", below)
+  bool entry(const RayOctant& r, float tmin, float tmax, float& tnear) const {
+    float q[6] = {lower.x, lower.y, lower.z, upper.x, upper.y, upper.z};
+    float tmin0 = q[0 + r.octantx3[0]] * r.dir_inv[0] - r.org_div_dir[0];
+    float tmin1 = q[1 + r.octantx3[1]] * r.dir_inv[1] - r.org_div_dir[1];
+    float tmin2 = q[2 + r.octantx3[2]] * r.dir_inv[2] - r.org_div_dir[2];
+    float tmax0 = q[3 - r.octantx3[0]] * r.dir_inv[0] - r.org_div_dir[0];
+    float tmax1 = q[4 - r.octantx3[1]] * r.dir_inv[1] - r.org_div_dir[1];
+    float tmax2 = q[5 - r.octantx3[2]] * r.dir_inv[2] - r.org_div_dir[2];
+    tnear = fmax_(tmin0, fmax_(tmin1, fmax_(tmin2, tmin)));
+    const float tfar = fmin_(tmax0, fmin_(tmax1, fmin_(tmax2, tmax)));
+    return tnear <= tfar;
   }
   bool hit(const Ray& ray) const {  // bbox.cpp:75-93
     float tmin = ray.tmin, tmax = ray.tmax;
@@ -2211,6 +2225,7 @@ struct BVHImpl {
   }
 };
 
+static int g_order_mode = 0;  // test-infrastructure switch (oracle_set_order): 0 pine's BVH order, 1 nearest bounds first
 struct Scene {
   NodeTable node_table;
   std::vector<Material> materials;
@@ -2232,6 +2247,7 @@ struct Scene {
   std::vector<std::shared_ptr<BVHImpl>> lbvh;
   BVHImpl tbvh;
   std::vector<int> indices;
+  std::vector<AABB> top_aabbs;  // the top-level primitives' boxes, in `indices` order (order mode "nearest")
 
   int find_material(const std::string& n) const {
     for (int i = int(material_names.size()) - 1; i >= 0; i--)  // map semantics: last add wins
@@ -2275,8 +2291,11 @@ struct Scene {
       prims.push_back(p);
       indices.push_back(int(i));
     }
+    top_aabbs.clear();
+    for (auto& p : prims) top_aabbs.push_back(p.aabb);
     tbvh.build(prims);
   }
+  bool intersect_nearest(Ray& ray, SurfaceInteraction& it) const;
   bool hit(Ray ray) const {  // BVH::hit :497-511
     if (geometries.empty()) return false;
     return tbvh.any_hit(ray, [&](const Ray& r, int li) {
@@ -2291,6 +2310,7 @@ struct Scene {
   bool intersect(Ray& ray, SurfaceInteraction& it) const {  // BVH::intersect :513-548
     if (geometries.empty()) return false;
     uint32_t geom_index = 0, prim_index = 0;
+    if (g_order_mode == 1) return intersect_nearest(ray, it);
     bool hit = tbvh.closest(ray, [&](Ray& r, int li) {
       const Geometry& g = geometries[indices[li]];
       if (li < int(lbvh.size())) {
@@ -2318,6 +2338,65 @@ struct Scene {
     return hit;
   }
 };
+
+// Order mode "nearest" (SURVEY.md Appendix A3's second traversal order; PINE_GPU_FLAG_ORDER_NEAREST on the device): the
+// top-level primitives are tested in the order of their bounding boxes' ENTRY distances (ties: stored order), a primitive whose
+// box is entered beyond the closest hit so far is skipped.  That is what a nearest-first traversal of ANY bounding-volume
+// hierarchy with one primitive per leaf converges to -- Embree's BVH4 over the user primitives (embree.cpp:101-143: one user
+// primitive per non-mesh shape, object leaves of size 1, children visited in tNear order) is one such -- so the
+// order-dependent scaled Box(AABB, mat4) (bbox.cpp:149-171) behaves as under EmbreeAccel: it is tested before a farther wall
+// has shortened ray.tmax.  Not the reference's BVH order, hence not bit-exact against O-gcc-bvh by construction; meshes keep
+// their own BVH's order (triangles are not order dependent).  Any-hit queries are order independent and unchanged.
+bool Scene::intersect_nearest(Ray& ray, SurfaceInteraction& it) const {
+  struct Cand {
+    float tnear;
+    int li;
+  };
+  Cand cand[64];
+  std::vector<Cand> big;
+  const int n = int(top_aabbs.size());
+  Cand* c = cand;
+  if (n > 64) {
+    big.resize(size_t(n));
+    c = big.data();
+  }
+  RayOctant oct(ray);
+  int m = 0;
+  for (int li = 0; li < n; li++) {
+    float tn;
+    if (top_aabbs[size_t(li)].entry(oct, ray.tmin, ray.tmax, tn)) c[m++] = Cand{tn, li};
+  }
+  std::stable_sort(c, c + m, [](const Cand& a, const Cand& b) { return a.tnear < b.tnear; });
+  uint32_t geom_index = 0, prim_index = 0;
+  bool hit = false;
+  for (int k = 0; k < m; k++) {
+    if (c[k].tnear > ray.tmax) break;  // (sorted: every later box is entered beyond the hit too)
+    const int li = c[k].li;
+    const Geometry& g = geometries[indices[li]];
+    bool h;
+    if (li < int(lbvh.size())) {
+      const Mesh& mm = g.as<Mesh>();
+      h = lbvh[li]->closest(ray, [&](Ray& rr, int idx) {
+        bool hh = mm.intersect(rr, idx);
+        if (hh) prim_index = idx;
+        return hh;
+      });
+    } else {
+      h = g.intersect(ray);
+    }
+    if (h) {
+      geom_index = indices[li];
+      hit = true;
+    }
+  }
+  if (hit) {
+    const Geometry& g = geometries[geom_index];
+    it.geom = int(geom_index);
+    if (g.kind == S_MESH) g.as<Mesh>().compute_surface_info(ray(), it, prim_index);
+    else g.compute_surface_info(ray(), it);
+  }
+  return hit;
+}
 
 // Mesh::intersect(ray, it) via ShapeBVH (bvh.cpp:568-582) -- used by the BSSRDF walk only
 bool mesh_intersect_full(const Mesh& m, Ray& ray, SurfaceInteraction& it) {
@@ -2979,6 +3058,7 @@ extern "C" {
 
 const char* oracle_last_error(void) { return g_error.c_str(); }
 
+void oracle_set_order(int mode) { g_order_mode = mode == 1 ? 1 : 0; }
 void oracle_set_sampler(int kind) { g_sampler_kind = kind == SAMPLER_SOBOL ? SAMPLER_SOBOL : kind == SAMPLER_HALTON ? SAMPLER_HALTON : SAMPLER_BLUE; }
 
 int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,

@@ -33,6 +33,9 @@ int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth,
 /* Which sampler the render entry points construct: 0 = BlueSobolSampler(spp) (default), 1 = SobolSampler(spp)
  * (sampler.h:83-164), 2 = HaltonSampler(spp) (sampler.h:40-81); for the latter two spp is used as given.  Process-wide, not thread-safe: test use only. */
 void oracle_set_sampler(int kind);
+/* closest-hit primitive order: 0 = pine's BVH order (the parity oracle), 1 = nearest bounds first (SURVEY.md Appendix A3's second
+ * order; what PINE_GPU_FLAG_ORDER_NEAREST does on the device) */
+void oracle_set_order(int mode);
 
 /* Render only the pixels of this shard (8x8 tiles dealt round-robin, the product's multi-GPU
  * partition); film_out must be zero-initialised by the caller, other pixels are left untouched. */

@@ -73,6 +73,7 @@ FLAG_SPECIALIZE = 0x400
 FLAG_SPECIALIZE_NO_BAKE = 0x800
 FLAG_SPECIALIZE_ASYNC = 0x1000
 FLAG_NO_SPECIALIZE = 0x2000
+FLAG_ORDER_NEAREST = 0x4000
 
 # every symbol include/pine_gpu.h declares, with its signature
 SIGNATURES = {

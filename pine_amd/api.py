@@ -406,7 +406,7 @@ class BlueSampler:
 
 class SobolSampler:
     """SobolSampler(spp) (sampler.h:83-164): spp is used as given -- no rounding, no clamp to 256.  On the
-    device a power of two up to 4096, and not with Subsurface materials (the C ABI reports both)."""
+    device any count up to 4096, and not with Subsurface materials (the C ABI reports both)."""
     kind = 1  # PINE_GPU_SAMPLER_SOBOL
 
     def __init__(self, samples_per_pixel):
@@ -557,16 +557,26 @@ def _specialize_flags(specialize):
     return _lib.FLAG_SPECIALIZE if specialize else _lib.FLAG_NO_SPECIALIZE
 
 
+def _order_flags(order):
+    if order in (None, "pine", "bvh"):
+        return 0
+    if order in ("nearest", "embree"):
+        return _lib.FLAG_ORDER_NEAREST
+    raise PineError(f"unknown traversal order {order!r} (pine | nearest)")
+
+
 class Plan:
     """A PathIntegrator bound to a scene with all device state resident (bench / multi-GPU)."""
 
     def __init__(self, scene, spp, max_path_length, device=0, shard_rank=0, shard_world=1,
-                 samples_per_item=0, timing=False, sampler="blue", flags=0, specialize=None):
+                 samples_per_item=0, timing=False, sampler="blue", flags=0, specialize=None, order="pine"):
         """spp: an int (BlueSampler(spp), or SobolSampler(spp) with sampler="sobol") or a sampler object.
         specialize: None -- the library's default: the scene's own kernel from the cache, else compiled in the background
         while the precompiled kernel renders; True -- PINE_GPU_FLAG_SPECIALIZE: wait for the compiler at plan creation, fail if
-        the kernel cannot be built; False -- PINE_GPU_FLAG_NO_SPECIALIZE: precompiled kernels only (stats().specialized tells)."""
-        flags = int(flags) | _specialize_flags(specialize)
+        the kernel cannot be built; False -- PINE_GPU_FLAG_NO_SPECIALIZE: precompiled kernels only (stats().specialized tells).
+        order: "pine" -- closest hits in pine-BVH order, Accel(BVH()) (the default and the parity gate); "nearest" / "embree" --
+        PINE_GPU_FLAG_ORDER_NEAREST: nearest bounds first, the order of the reference's EmbreeAccel (scaled boxes appear as under it)."""
+        flags = int(flags) | _specialize_flags(specialize) | _order_flags(order)
         if scene.camera is None:
             raise PineError("scene has no camera")
         self.scene = scene
@@ -637,11 +647,12 @@ class PathIntegrator:
     """PathIntegrator(sampler, max_path_length).render(scene) -- the convenience overload a .pine
     script uses (program_context.cpp:79-81); pine-BVH traversal order, UniformLightSampler."""
 
-    def __init__(self, sampler, max_path_length, device=0, flags=0, devices=None, specialize=None):
+    def __init__(self, sampler, max_path_length, device=0, flags=0, devices=None, specialize=None, order="pine"):
         """devices: a list of HIP device ordinals -- the film is rendered by all of them from this one process
         (pine_gpu_path_render_devices); default: the single `device`.
-        specialize: None / True / False as for Plan (the scene's own kernel: automatic / required / never; same film)."""
-        flags = int(flags) | _specialize_flags(specialize)
+        specialize: None / True / False as for Plan (the scene's own kernel: automatic / required / never; same film).
+        order: "pine" (Accel(BVH()), the default) or "nearest" / "embree" (PINE_GPU_FLAG_ORDER_NEAREST: what EmbreeAccel does)."""
+        flags = int(flags) | _specialize_flags(specialize) | _order_flags(order)
         if max_path_length <= 0:  # path.cpp:12-13
             raise PineError(f"`PathIntegrator` expect `max_path_length` to be positive, get {max_path_length}")
         self.sampler, self.max_path_length, self.device, self.flags = sampler, int(max_path_length), device, int(flags)

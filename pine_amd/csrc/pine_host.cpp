@@ -609,6 +609,11 @@ void SceneHost::build_accel() {  // BVH::build bvh.cpp:453-495
     top.push_back(make_prim(geometry_aabb(int(gi)), int(gi)));
   }
   accel.top_prim_begin = int(prims.size());
+  for (const BuildPrim& t : top) {
+    float r[8] = {t.lo[0], t.lo[1], t.lo[2], 0.0f, t.hi[0], t.hi[1], t.hi[2], 0.0f};
+    memcpy(&r[3], &t.index, 4);
+    accel.top_boxes.insert(accel.top_boxes.end(), r, r + 8);
+  }
   prims.insert(prims.end(), top.begin(), top.end());
   // the top-level root is numbered first, then the mesh roots, then level by level across all of them
   if (!top.empty()) roots.insert(roots.begin(), root_task(accel.top_prim_begin, int(prims.size()), 0));

@@ -87,6 +87,10 @@ struct FlatAccel {
   // per-vertex attributes of meshes that have them, expanded per triangle like tri_verts: 16 floats per triangle
   // (n0 n1 n2, t0 t1 t2, pad); empty when no mesh of the scene carries normals or texcoords
   std::vector<float> tri_attrs;
+  // the top-level primitives' own boxes in the reference's listing order (bvh.cpp:470-488: one per non-empty mesh, then the
+  // other shapes, each in geometry order), 8 floats each: lower, geometry index (int bits), upper, 0 -- what
+  // PINE_GPU_FLAG_ORDER_NEAREST sorts by
+  std::vector<float> top_boxes;
   bool built = false;
 };
 

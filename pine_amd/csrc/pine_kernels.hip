@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(64) test_traverse_kernel(DeviceScene S, const 
   V.stack_top = S.stack_top, V.num_shapes = S.num_shapes;
   V.leaf = S.leaf, V.nodes = S.nodes, V.shapes = S.shapes, V.materials = S.materials, V.bvhs = S.bvhs, V.prims = nullptr;
   V.lights = S.lights, V.node_ops = S.node_ops;
+  V.top_boxes = nullptr, V.num_top = 0;
   const long long i = blockIdx.x * 64ll + threadIdx.x;
   const bool live = i < nrays;
   const float* q = rays + (live ? i : 0) * 8;
@@ -715,7 +716,8 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
   const unsigned kLayout = F_LDS_SCENE | F_LDS_TOP | F_LDS_REST | F_XSTAGE | F_SSS;
   unsigned exact = (V.features & kLayout) | need;
   std::string baked;
-  if (!(prm->flags & PINE_GPU_FLAG_SPECIALIZE_NO_BAKE) && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr) {
+  // (a baked scene IS pine's visiting order as code: the nearest-bounds-first mode keeps to the feature-set level)
+  if (!(prm->flags & (PINE_GPU_FLAG_SPECIALIZE_NO_BAKE | PINE_GPU_FLAG_ORDER_NEAREST)) && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr) {
     if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0) baked = generate_baked_scene(A, shapes, packed_prims);
     // one mesh under a small top level, traversal stages (C5's class): the top level as code, the mesh left to the flat traversal
     else if ((V.features & F_XSTAGE) && A.bvhs.size() == 2 && getenv("PINE_GPU_SPECIALIZE_NO_TOP") == nullptr)
@@ -1013,11 +1015,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
                      : sobol ? "`SobolSampler` should have positive samples per pixel" : "samples per pixel must be positive");
     return -1;
   }
-  if (sobol && ((spp & (spp - 1)) != 0 || spp > kMaxDeviceSpp)) {
-    set_error(halton ? "HaltonSampler on the device: samples per pixel must be a power of two, at most 4096"
-                     : "SobolSampler on the device: samples per pixel must be a power of two, at most 4096");
+  if (sobol && spp > kMaxDeviceSpp) {  // (the packed path state holds 12 bits of sample index)
+    set_error(halton ? "HaltonSampler on the device: at most 4096 samples per pixel" : "SobolSampler on the device: at most 4096 samples per pixel");
     return -1;
   }
+  const bool spp_pow2 = (spp & (spp - 1)) == 0;  // (BlueSampler's effective spp always is; SobolSampler / HaltonSampler take any count)
   if (prm->shard_world < 1 || prm->shard_rank < 0 || prm->shard_rank >= prm->shard_world) {
     set_error("bad shard rank/world");
     return -1;
@@ -1085,6 +1087,37 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   std::vector<DLight> light_list = H.lights;  // + the environment light last (lightsampler.cpp:6-10)
   if (H.has_env) light_list.push_back(H.env);
   S.off_lights = put(light_list.data(), light_list.size() * sizeof(DLight));
+  // PINE_GPU_FLAG_ORDER_NEAREST: the top-level primitives' boxes in the reference's listing order, each with its place in `leaf`
+  const bool order_nearest = (prm->flags & PINE_GPU_FLAG_ORDER_NEAREST) != 0;
+  S.off_top_boxes = 0;
+  S.num_top = 0;
+  if (order_nearest) {
+    constexpr int kNearestMaxPrims = 64;
+    const int ntop = int(A.top_boxes.size() / 8);
+    if (ntop > kNearestMaxPrims) {
+      set_error("PINE_GPU_FLAG_ORDER_NEAREST: the scene has " + std::to_string(ntop) + " top-level primitives; the nearest-bounds-first order is "
+                "implemented for at most 64 (a mesh counts as one)");
+      return -1;
+    }
+    if (prm->flags & (PINE_GPU_FLAG_FAST | PINE_GPU_FLAG_VERTEX_LOG)) {
+      set_error("PINE_GPU_FLAG_ORDER_NEAREST cannot be combined with PINE_GPU_FLAG_FAST / _VERTEX_LOG");
+      return -1;
+    }
+    std::vector<float> boxes = A.top_boxes;
+    for (int t = 0; t < ntop; t++) {
+      int geom, place = -1;
+      memcpy(&geom, &boxes[size_t(t) * 8 + 3], 4);
+      for (size_t i = size_t(A.top_prim_begin); i < A.prims.size(); i++)
+        if (A.prims[i] == geom) place = int(i);
+      if (place < 0) {
+        set_error("internal: a top-level primitive without a leaf entry");
+        return -1;
+      }
+      memcpy(&boxes[size_t(t) * 8 + 3], &place, 4);
+    }
+    S.off_top_boxes = put(boxes.data(), boxes.size() * sizeof(float));
+    S.num_top = ntop;
+  }
   blob.resize((blob.size() + 15) & ~size_t(15));
   S.blob_bytes = int(blob.size());
   HIP_OK(hipMalloc((void**)&p->d_blob, blob.size()));
@@ -1206,6 +1239,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   if (!node_ops.empty()) need |= F_NODES;
   if (sobol) need |= F_SOBOL;
+  if (order_nearest) need |= F_NEAREST;
   if (sobol && (need & F_SSS)) {
     // a BSSRDF walk draws from the sampler at every step: SobolSampler's dimension counter (no wrap-around,
     // unlike BlueSampler's) is unbounded there and does not fit the packed path state
@@ -1221,6 +1255,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     const unsigned F = kVariants[v].features;
     if ((F & need) != need) continue;
     if (((F & F_LDS_SCENE) != 0) != lds_ok) continue;
+    if (((F & F_NEAREST) != 0) != order_nearest) continue;  // (the order mode's twin variants: never without the flag)
     if (getenv("PINE_GPU_WPS") && atoi(getenv("PINE_GPU_WPS")) != kVariants[v].waves_per_simd) continue;
     p->variant = v;
     break;
@@ -1250,6 +1285,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
         if (((F & F_VLOG) != 0) != ((prm->flags & PINE_GPU_FLAG_VERTEX_LOG) != 0)) continue;  // (the test hook's twin variants)
+        if (((F & F_NEAREST) != 0) != order_nearest) continue;                                   // (the order mode's twin variants)
         if ((F & F_LDS_SCENE) && !lds_ok) continue;  // (a scene-in-global variant later in the table is the fallback when LDS is short)
         if ((F & F_LDS_TOP) && A.nodes.size() > 65535) continue;  // 16-bit stack entries
         const size_t rest_bytes = size_t(S.blob_bytes - S.off_shapes);
@@ -1259,6 +1295,9 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
         const size_t lds = kQueueVariants[v].fixed_lds + stack_bytes + ((F & F_LDS_SCENE) ? size_t(S.blob_bytes) : 0) +
                            ((F & F_LDS_REST) ? rest_bytes : 0);
         if (lds > 160 * 1024) continue;
+        // (measurement aid: PINE_GPU_XSTAGE=1 also passes over the stage-less F_LDS_TOP variants, so that the scene lands on a
+        //  traversal-stage variant whose layout its own kernel -- exact feature set, pine_specialize.h -- then inherits)
+        if ((F & F_LDS_TOP) && !(F & F_XSTAGE) && getenv("PINE_GPU_XSTAGE") && atoi(getenv("PINE_GPU_XSTAGE")) == 1) continue;
         if (F & F_XSTAGE) {
           // traversal stages only where refilling pays: a scene with meshes, (nearly) all nodes in this variant's LDS.
           // PINE_GPU_XSTAGE=0 / 1: never / always (measurement aid, tools/xstage_ab.py).
@@ -1345,7 +1384,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     kspi = (p->queue_variant >= 0 || p->fast) ? ((qf & F_LDS_SCENE) ? std::min(spp, 2) : 1) : std::min(spp, 4);
   }
   if (kspi > spp) kspi = spp;
-  {  // spp is a power of two; k must be a power of two dividing it
+  if (!spp_pow2) {
+    // SobolSampler(12): the work decomposition splits a pixel's samples by shifts and masks, so a count that is not a power
+    // of two is ONE item per pixel -- all its samples in sequence, no checkpoints (sampler.cpp:81-113 takes any count)
+    kspi = spp;
+  } else {  // k must be a power of two dividing spp
     int k2 = 1;
     while (k2 * 2 <= kspi) k2 *= 2;
     kspi = k2;

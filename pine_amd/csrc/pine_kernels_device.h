@@ -94,6 +94,10 @@ struct DeviceScene {
   const uint4* tri_packets;   // entries (tri_packet_entries x 8 bytes, padded to 16), then vertices (x 16 bytes)
   int tri_packet_entries, tri_packet_verts;
   int lds_tris;               // 1: every workgroup copies the packets to LDS and the traversal reads them there
+  // PINE_GPU_FLAG_ORDER_NEAREST (F_NEAREST variants): the top-level primitives' own bounding boxes, in the order the reference
+  // lists them (bvh.cpp:453-495: meshes first, then the other shapes, each in geometry order): two float4 per primitive --
+  // lower | its entry in `leaf`, upper | 0 -- at off_top_boxes of the blob; num_top of them (0: the mode is off)
+  int off_top_boxes, num_top;
 };
 
 // What the traversal and shading code reads.  In the F_LDS_SCENE specialisation every pointer is
@@ -121,6 +125,8 @@ struct SceneView {
   int lds_node_count;
   const uint2* lds_tri_entries;   // DeviceScene::tri_packets in LDS (null: triangles are read from tri_leaf)
   const float4* lds_tri_verts;
+  const float4* top_boxes;        // F_NEAREST variants: DeviceScene::off_top_boxes (null otherwise)
+  int num_top;
 };
 
 // One BVH node into registers.  F_LDS_TOP: from the workgroup's LDS copy when the index is below the cached
@@ -288,6 +294,66 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
   return hit;
 }
 
+// Order mode "nearest" (PINE_GPU_FLAG_ORDER_NEAREST, F_NEAREST variants; SURVEY.md Appendix A3's second traversal order):
+// closest-hit queries test the top-level primitives in the order of their OWN bounding boxes' entry distances (ties: the
+// reference's listing order), and stop at the first box that is entered beyond the closest hit so far.  That is the order a
+// nearest-first traversal of a bounding-volume hierarchy with one primitive per leaf produces whatever the hierarchy's shape --
+// the reference's EmbreeAccel is one (embree.cpp:101-143: one user primitive per shape; Embree's object leaves hold one
+// primitive, children are visited in tNear order) -- so the one order-dependent shape, the scaled Box(AABB, mat4)
+// (bbox.cpp:149-171), is tested before a farther wall has shortened ray.tmax, as under Embree: the golden films of the real
+// reference built with EmbreeAccel are reproduced bit for bit (tests/test_gpu_parity.py).  No hierarchy is walked: every
+// round scans the boxes for the next one in (entry distance, index) order -- O(primitives x tests), which is why the mode is
+// limited to 64 top-level primitives (a mesh counts as one; its own BVH keeps pine's order -- triangles are not order
+// dependent).  Any-hit queries are order independent and stay with the BVH.
+template <unsigned F, int STRIDE, class StackT>
+__device__ __forceinline__ bool scene_traverse_nearest(const SceneView& S, DRay& ray, StackT* stack, int& geom_out, int& prim_out, TravLog* log) {
+  const DRayOct oct = make_oct(ray);
+  float last_t = -1.0f;  // (entry distances are >= tmin >= 0)
+  int last_i = -1;
+  bool hit = false;
+  for (int round = 0; round < S.num_top; round++) {
+    float best_t = 0.0f;
+    int best_i = -1;
+    for (int i = 0; i < S.num_top; i++) {
+      const float4 a = S.top_boxes[2 * i], b = S.top_boxes[2 * i + 1];
+      float tn;
+      if (!box_entry_oct(&a.x, &b.x, oct, ray.tmin, ray.tmax, tn)) continue;
+      const bool after = tn > last_t || (tn == last_t && i > last_i);
+      if (after && (best_i < 0 || tn < best_t)) best_t = tn, best_i = i;  // (strict <: among equal distances the first index)
+    }
+    if (best_i < 0) break;
+    last_t = best_t, last_i = best_i;
+    const DShape* sh = &S.leaf[__float_as_int(S.top_boxes[2 * best_i].w)];
+    DShape rec;
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(sh);
+      uint4* dst = reinterpret_cast<uint4*>(&rec);
+#pragma unroll
+      for (int q = 0; q < 8; q++) dst[q] = src[q];
+      sh = &rec;
+    }
+    const int word = sh->kind;  // (the packed word rides in the copy's kind field)
+    const int kind = word >> kPrimKindShift;
+    bool is_mesh = false;
+    if constexpr (F & F_MESH) is_mesh = kind == SHAPE_MESH;
+    if (log) log->put(unsigned(word & kPrimIndexMask));
+    if (is_mesh) {
+      if constexpr (F & F_MESH) {
+        int prim = 0;
+        if (mesh_traverse<false, STRIDE, F>(S, S.bvhs[as_int(sh->f[2])], ray, oct, stack, S.stack_top, prim, log)) {
+          hit = true;
+          geom_out = word;
+          prim_out = prim;
+        }
+      }
+    } else if (shape_intersect<F>(kind, sh, ray)) {
+      hit = true;
+      geom_out = word;
+    }
+  }
+  return hit;
+}
+
 // ANY: BVH::hit (bvh.cpp:497-511).  !ANY: BVH::intersect (bvh.cpp:513-548) minus the final
 // compute_surface_info, which the caller does once for the winning primitive.
 // geom_out receives the winning primitive's PACKED word (index | emissive bit | kind).
@@ -295,6 +361,7 @@ template <bool ANY, unsigned F, int STRIDE = kBlock, class StackT = int>
 __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, StackT* stack, int& geom_out,
                                                int& prim_out, TravLog* log = nullptr) {
   if (S.num_shapes == 0) return false;
+  if constexpr ((F & F_NEAREST) != 0 && !ANY) return scene_traverse_nearest<F, STRIDE>(S, ray, stack, geom_out, prim_out, log);
   const DRayOct oct = make_oct(ray);
   const DBvh top = S.bvhs[0];
   bool hit = false;
@@ -574,6 +641,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   V.lds_tri_verts = nullptr;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
+  V.num_top = S.num_top;
   if constexpr (F & F_LDS_SCENE) {
     uint4* dst = reinterpret_cast<uint4*>(lds_raw + kOffStack + S.stack_total * kBlock);
     const int n16 = S.blob_bytes >> 4;
@@ -588,8 +656,10 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
+    V.top_boxes = reinterpret_cast<const float4*>(base + S.off_top_boxes);
   } else {
     __syncthreads();  // Sobol rows staged above
+    V.top_boxes = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.blob) + S.off_top_boxes);
     V.leaf = S.leaf;
     V.nodes = S.nodes;
     V.shapes = S.shapes;
@@ -1028,7 +1098,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       const int s_now = st.s_cur();
       samples[size_t(sample_base) + size_t(s_now) * 64u] = make_float4(Li.x, Li.y, Li.z, float(pv_length + 1));
       st.v = unsigned(s_now + 1);
-      if (((s_now + 1) & (kspi - 1)) == 0) have_item = false;  // item = kspi consecutive samples, kspi a power of two
+      // item = kspi consecutive samples: a power of two that divides spp, or (another SobolSampler / HaltonSampler count) the whole pixel
+      if ((kspi & (kspi - 1)) == 0 ? ((s_now + 1) & (kspi - 1)) == 0 : s_now + 1 == kspi) have_item = false;
       alive = false;
     }
     SEC_MARK(9);  // fold + sample store

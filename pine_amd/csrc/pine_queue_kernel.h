@@ -104,6 +104,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
 #endif
   constexpr bool kFlat = kTop && !kBaked;  // rays are traced by the flat traversal (a specialised build: by the scene's own code)
   static_assert(!(F & F_LDS_REST) || kTop, "F_LDS_REST is an option of the F_LDS_TOP variants");
+  static_assert(!(F & F_NEAREST) || (!kTop && !kBaked), "the nearest-bounds-first order lives in scene_traverse: not in the flat traversal, not in baked scenes");
   static_assert(!(F & F_XSTAGE) || kTop, "F_XSTAGE is an option of the F_LDS_TOP variants");
   constexpr int kQCtxGlobalDwords = q_ctx_global_dwords(F);
   constexpr int kQCtxTravOffset = q_ctx_trav_offset(F);
@@ -166,6 +167,8 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
   V.lds_tri_verts = nullptr;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
+  V.num_top = S.num_top;
+  V.top_boxes = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.blob) + S.off_top_boxes);  // (F_NEAREST variants read it)
   char* lds_after_stack = nullptr;
   if constexpr (F & F_LDS_TOP) {
     size_t stack_bytes = size_t(S.stack_total) * kQBlock * sizeof(StackT);
@@ -205,6 +208,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
+    V.top_boxes = reinterpret_cast<const float4*>(base + S.off_top_boxes);
   } else if constexpr (F & F_LDS_REST) {
     // blob = nodes | shapes | materials | node programs | bvhs | leaf records | lights: everything after the nodes
     size_t stack_bytes = size_t(S.stack_total) * kQBlock * sizeof(StackT);
@@ -222,6 +226,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
+    V.top_boxes = reinterpret_cast<const float4*>(base + S.off_top_boxes);
   } else {
     V.leaf = S.leaf;
     V.nodes = S.nodes;
@@ -788,6 +793,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
       bool to_shade = false, to_term = false, to_walk = false, to_xs = false, to_xc = false;
       bool release = false;  // (kFork) this lane's path seals here and its pixel has samples left: a token goes out
       if (valid) {
+        REGION(12);  // (lanes of a stage-S pass that hold a context)
         const f3 ray_o{cstf[CF_OX * kQCtx + id], cstf[CF_OY * kQCtx + id], cstf[CF_OZ * kQCtx + id]};
         const f3 ray_d{cstf[CF_DX * kQCtx + id], cstf[CF_DY * kQCtx + id], cstf[CF_DZ * kQCtx + id]};
         const float ray_tmax = cstf[CF_TMAX * kQCtx + id];
@@ -1292,6 +1298,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
       int s_next = 0;
       uint4 rng_words = make_uint4(0, 0, 0, 0);
       if (valid) {
+        REGION(13);  // (lanes of a stage-T pass that hold a context)
         // the pixel's RNG state is needed only for the next camera sample, but its L2 round trip
         // starts here so that it overlaps the fold loop's
         rng_words = *reinterpret_cast<const uint4*>(ctx_global(id));
@@ -1391,7 +1398,11 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
           s_next = s_now + 1;
           // (sealed: the pixel's next sample went out as a token -- or, with tile classes, the path is a one-sample item
           // of the independent class, which never owned its pixel's chain)
-          if ((kFork && st.sealed()) || (s_next & ((kFork ? chain_spi : W.samples_per_item) - 1)) == 0) need_item = true;
+          // (an item is samples_per_item consecutive samples: a power of two that divides spp, or -- SobolSampler / HaltonSampler
+          //  with another count -- the whole pixel)
+          const int spi = kFork ? chain_spi : W.samples_per_item;
+          const bool item_done = (spi & (spi - 1)) == 0 ? (s_next & (spi - 1)) == 0 : s_next == spi;
+          if ((kFork && st.sealed()) || item_done) need_item = true;
           else have_path = true;
           if constexpr (kFork)
             if (!st.sealed() && (s_next & (chain_spi - 1)) == 0) {

@@ -135,11 +135,11 @@ struct BlueSampler {  // sampler.h:166-201
     if (spp <= 0) throw Error("`BlueSampler` should have positive samples per pixel");
   }
 };
-struct SobolSampler {  // sampler.h:83-164: spp as given (on the device a power of two up to 4096)
+struct SobolSampler {  // sampler.h:83-164: spp as given (on the device any count up to 4096)
   int requested;
   explicit SobolSampler(int spp) : requested(spp) {}
 };
-struct HaltonSampler {  // sampler.h:40-81: spp as given (on the device a power of two up to 4096)
+struct HaltonSampler {  // sampler.h:40-81: spp as given (on the device any count up to 4096)
   int requested;
   explicit HaltonSampler(int spp) : requested(spp) {
     if (spp <= 0) throw Error("`HaltonSampler` should have positive samples per pixel");
@@ -235,6 +235,12 @@ class PathIntegrator {
   // The scene's own path kernel (same film; pine_gpu.h): by default the library uses it when it is in its cache and compiles it
   // in the background otherwise.  specialize(true): wait for the compiler at render() and fail if the kernel cannot be built
   // (PINE_GPU_FLAG_SPECIALIZE); specialize(false): precompiled kernels only (PINE_GPU_FLAG_NO_SPECIALIZE).
+  // closest hits nearest bounds first -- the order of the reference's EmbreeAccel (PINE_GPU_FLAG_ORDER_NEAREST) -- instead of
+  // pine-BVH order (the default: Accel(BVH())); only a scene with a scaled Box(AABB, mat4) shows the difference
+  PathIntegrator& order_nearest(bool on = true) {
+    flags_ = on ? (flags_ | PINE_GPU_FLAG_ORDER_NEAREST) : (flags_ & ~PINE_GPU_FLAG_ORDER_NEAREST);
+    return *this;
+  }
   PathIntegrator& specialize(bool on = true) {
     flags_ &= ~(PINE_GPU_FLAG_SPECIALIZE | PINE_GPU_FLAG_NO_SPECIALIZE);
     flags_ |= on ? PINE_GPU_FLAG_SPECIALIZE : PINE_GPU_FLAG_NO_SPECIALIZE;

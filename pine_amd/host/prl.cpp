@@ -155,6 +155,7 @@ struct LightObj : Object {
 };
 struct IntegratorObj : Object {
   int spp = 0, depth = 0, sampler = 0;
+  int accel = 0;  // 0: the two-argument constructor's default; 1: Accel(BVH()) -- pine-BVH order; 2: Accel(Embree()) -- nearest bounds first
 };
 
 static Value mk_i32(int v) {
@@ -1889,6 +1890,27 @@ Interp::Interp() {
     fail("`UniformSampler` is not provided: its stream depends on the reference's thread scheduling (per-thread RNG clones, "
          "no per-pixel reseed), so there is no result to reproduce -- use BlueSampler, SobolSampler or HaltonSampler");
   });
+  // Accel / LightSampler and the four-argument constructor (program_context.cpp:47-52, 76-78).  The reference registers
+  // `BVH()` and `Embree()` but lets only Embree convert to Accel (ctor_variant<EmbreeAccel>), so a script on real pine can
+  // write PathIntegrator(Embree(), sampler, UniformLightSampler(), n) and nothing else; here BVH() converts as well (an
+  // extension: the explicit way to ask for pine-BVH order).  Embree() selects PINE_GPU_FLAG_ORDER_NEAREST -- closest hits
+  // nearest bounds first, which reproduces the EmbreeAccel films of the real reference bit for bit on cbox
+  // (tests/golden/film_embree_*); BVH() selects pine-BVH order, the parity oracle's.
+  r.def("BVH", {}, "BVH", [](Interp&, std::vector<Cell>&) { return retype(mk_i32(1), "BVH"); });
+  r.def("Embree", {}, "Embree", [](Interp&, std::vector<Cell>&) { return retype(mk_i32(2), "Embree"); });
+  r.convert("Embree", "Accel", [](const Value& v) { return retype(v, "Accel"); });
+  r.convert("BVH", "Accel", [](const Value& v) { return retype(v, "Accel"); });
+  r.def("UniformLightSampler", {}, "UniformLightSampler", [](Interp&, std::vector<Cell>&) { return retype(mk_i32(0), "UniformLightSampler"); });
+  r.convert("UniformLightSampler", "LightSampler", [](const Value& v) { return retype(v, "LightSampler"); });
+  r.def("PathIntegrator", {"Accel", "Sampler", "LightSampler", "i32"}, "PathIntegrator", [](Interp&, std::vector<Cell>& a) {
+    if (a[3]->i[0] <= 0) fail("`PathIntegrator` expect `max_path_length` to be positive, get " + std::to_string(a[3]->i[0]));
+    auto p = std::make_shared<IntegratorObj>();
+    p->accel = a[0]->i[0];
+    p->spp = a[1]->i[0];
+    p->sampler = a[1]->i[1];
+    p->depth = a[3]->i[0];
+    return mk_obj("PathIntegrator", p);
+  });
   r.def("PathIntegrator", {"Sampler", "i32"}, "PathIntegrator", [](Interp&, std::vector<Cell>& a) {
     if (a[1]->i[0] <= 0) fail("`PathIntegrator` expect `max_path_length` to be positive, get " + std::to_string(a[1]->i[0]));
     auto p = std::make_shared<IntegratorObj>();
@@ -1904,7 +1926,7 @@ Interp::Interp() {
     auto f = obj<CameraObj>(s->camera)->film;
     if (in.flags & PINE_PRL_DRY_RUN) {
       in.log(std::string("@render PathIntegrator ") + (p->sampler == PINE_GPU_SAMPLER_SOBOL ? "SobolSampler " : p->sampler == PINE_GPU_SAMPLER_HALTON ? "HaltonSampler " : "BlueSampler ") +
-             std::to_string(p->spp) + " max_path_length " + std::to_string(p->depth) + "\n");
+             std::to_string(p->spp) + " max_path_length " + std::to_string(p->depth) + (p->accel == 2 ? " accel Embree" : p->accel == 1 ? " accel BVH" : "") + "\n");
       in.log(describe_scene(s->h));
       in.log("@end\n");
       return Value();
@@ -1916,6 +1938,23 @@ Interp::Interp() {
     prm.shard_rank = 0;
     prm.shard_world = 1;
     prm.sampler = p->sampler;
+    // The accel decides the ORDER closest hits are found in, which only the transformed Box(AABB, mat4) can see
+    // (bbox.cpp:149-171).  Embree(): nearest bounds first, as EmbreeAccel.  BVH(): pine-BVH order.  The two-argument
+    // constructor: real pine gives it EmbreeAccel (program_context.cpp:79-81); here it renders in pine-BVH order -- the order
+    // of the parity oracle -- unless $PINE_PRL_ACCEL=embree, and a scene that can tell the difference says so once.
+    int accel = p->accel;
+    if (accel == 0) {
+      const char* e = getenv("PINE_PRL_ACCEL");
+      accel = (e && std::string(e) == "embree") ? 2 : 1;
+      static bool said = false;
+      if (accel == 1 && !said && describe_scene(s->h).find("shape obb ") != std::string::npos) {
+        said = true;
+        fprintf(stderr, "[pine-mi355x] note: this scene has a transformed Box(AABB, mat4), whose image depends on the accel's test order; "
+                        "PathIntegrator(sampler, n) renders it in pine-BVH order (Accel(BVH())).  Real pine's default EmbreeAccel tests "
+                        "nearest bounds first: PathIntegrator(Embree(), sampler, UniformLightSampler(), n) or PINE_PRL_ACCEL=embree renders that image.\n");
+      }
+    }
+    if (accel == 2) prm.flags |= PINE_GPU_FLAG_ORDER_NEAREST;
     f->pixels.assign(size_t(f->w) * f->h * 4, 0.0f);
     // $PINE_GPU_DEVICES = "0,1,2,...": render on those devices of the node from this one process (pine-mi355x --devices)
     std::vector<int> devices;

@@ -213,17 +213,14 @@ def _sobol_scene_for(name):
 @pytest.mark.parametrize("name", SOBOL_FILM_NAMES)
 def test_sobol_sampler_film_matches_reference_golden(name):
     """PathIntegrator(SobolSampler(spp), depth): HIP film vs the film the REAL reference rendered with SobolSampler,
-    bit for bit (incl. 512 spp, above BlueSampler's cap).  A non-power-of-two spp is the reference's to take and the
-    device's to refuse, loudly."""
+    bit for bit (incl. 512 spp, above BlueSampler's cap, and 12 spp: a count that is not a power of two is one work item per
+    pixel on the device, sampler.cpp:81-113 takes any)."""
     import pine_amd as pa
     ref, ps, spp, depth = load_film(name)
     sc = _sobol_scene_for(name)
     assert sc.describe() == ps
-    if spp & (spp - 1):
-        with pytest.raises(pa.PineError, match="power of two"):
-            pa.Plan(sc, pa.SobolSampler(spp), depth)
-        return
     film, st = _render(sc, pa.SobolSampler(spp), depth)
+    assert (st.samples_per_item == spp) if spp & (spp - 1) else True
     assert st.spp_effective == spp
     assert_bit_equal(film, ref, name)
 
@@ -232,17 +229,13 @@ def test_sobol_sampler_film_matches_reference_golden(name):
 def test_halton_sampler_film_matches_reference_golden(name):
     """PathIntegrator(HaltonSampler(spp), depth) on the device (sampler.h:40-81: scrambled radical inverses, digit
     permutations derived on the host from a default-seeded RNG, pixel offsets through the 128 x 243 grid) against the film
-    the REAL reference rendered with HaltonSampler; the 12-spp film is the reference's to take and the device's to refuse."""
+    the REAL reference rendered with HaltonSampler, 8 and 12 samples per pixel (any count: sampler.h:44-46)."""
     import pine_amd as pa
     from pine_amd import scenes
     ref, ps, spp, depth = load_film(name)
     sc = {"halton_cbox_readme_40_s8_d4": lambda: scenes.cbox((40, 40), "readme"),
           "halton_mats_zoo_32_s12_d6": lambda: scenes.materials_zoo((32, 32))}[name]()
     assert sc.describe() == ps
-    if spp & (spp - 1):
-        with pytest.raises(pa.PineError, match="power of two"):
-            pa.Plan(sc, pa.HaltonSampler(spp), depth)
-        return
     film, st = _render(sc, pa.HaltonSampler(spp), depth)
     assert st.spp_effective == spp
     assert_bit_equal(film, ref, name)
@@ -271,6 +264,8 @@ def test_sobol_sampler_limits():
         pa.Plan(scenes.sss((16, 16), 1), pa.SobolSampler(4), 4)
     with pytest.raises(pa.PineError, match="positive"):
         pa.Plan(scenes.cbox((16, 16)), pa.SobolSampler(0), 4)
+    with pytest.raises(pa.PineError, match="at most 4096"):
+        pa.Plan(scenes.cbox((16, 16)), pa.SobolSampler(5000), 4)
 
 
 def test_one_shot_host_film_entry_point():
@@ -861,3 +856,60 @@ def test_device_bvh_build_produces_the_host_tree(oracle):
     assert st.accel_built_on_device == 1
     ref, _ = oracle.render(sc.describe(), (96, 48), 16, 6)
     assert_bit_equal(f, ref, "render on the device-built BVH")
+
+
+# ---- PINE_GPU_FLAG_ORDER_NEAREST (SURVEY.md Appendix A3's second traversal order) -----------------------------------------
+@pytest.mark.parametrize("name", ["embree_cbox_readme_64_s16_d4", "embree_cbox_committed_64_s16_d4", "embree_cbox_readme_64_s256_d8",
+                                  "embree_cbox_rect_readme_64_s64_d5"])
+def test_nearest_order_renders_the_embree_reference_films(name, path_kernel):
+    """With PINE_GPU_FLAG_ORDER_NEAREST the device tests a ray's primitives nearest bounds first -- the order of the reference's
+    EmbreeAccel, the accel a .pine script gets on real pine -- and renders the films of the REAL reference built with EmbreeAccel
+    (tests/golden/film_embree_*, tools/make_golden.py --embree) bit for bit, scaled boxes included; both path kernels."""
+    from pine_amd import scenes
+    emb, ps, spp, depth = load_film(name)
+    sc = {"embree_cbox_readme_64_s16_d4": lambda: scenes.cbox((64, 64), "readme"),
+          "embree_cbox_committed_64_s16_d4": lambda: scenes.cbox((64, 64), "committed"),
+          "embree_cbox_readme_64_s256_d8": lambda: scenes.cbox((64, 64), "readme"),
+          "embree_cbox_rect_readme_64_s64_d5": lambda: scenes.cbox((64, 64), "readme", False)}[name]()
+    assert sc.describe() == ps
+    film, st = _render(sc, spp, depth, order="nearest", specialize=False)
+    assert st.kernel_features & (1 << 18), hex(st.kernel_features)  # F_NEAREST: a variant of the order mode ran
+    assert_bit_equal(film, emb, f"PINE_GPU_FLAG_ORDER_NEAREST vs O-gcc-embree, {name}")
+    if "rect" not in name:
+        pine_order, _ = _render(sc, spp, depth, specialize=False)
+        assert (pine_order.view(np.uint32) != film.view(np.uint32)).any(), "the two orders must differ on a scene with scaled boxes"
+
+
+def test_nearest_order_equals_the_oracle_on_other_scenes(oracle, path_kernel):
+    """... and equals the CPU restatement's nearest-bounds-first order on scenes beyond cbox: random rooms of every shape kind
+    (transformed boxes among them), every material and light, meshes (whose own BVH keeps pine's order) -- through the run-time
+    compiled feature-set kernel as well as the precompiled twins."""
+    from pine_amd import scenes
+    done = 0
+    for seed in (3003, 3007, 3011, 3019, 3021, 3030):
+        sc, spp, depth, sampler = scenes.random_scene(seed, variety=True)
+        if sampler != "blue":
+            continue
+        w, h = sc.camera.film().size
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth, order="nearest")
+        film, st = _render(sc, spp, depth, order="nearest", specialize=False)
+        assert_bit_equal(film, ref, f"nearest order, random scene {seed}")
+        if path_kernel == "queue" and done == 0:
+            film2, st2 = _render(sc, spp, depth, order="nearest", specialize=True)
+            assert_bit_equal(film2, ref, f"nearest order, scene-specialised kernel, random scene {seed}")
+            assert st2.specialized in (0, 1)  # (never baked: a baked scene is pine's order as code)
+        done += 1
+    assert done >= 3
+    sc = scenes.sss((40, 40), 1)  # one Subsurface mesh in a room: the mesh is ONE top-level primitive
+    ref, _ = oracle.render(sc.describe(), (40, 40), 16, 6, order="nearest")
+    film, _ = _render(sc, 16, 6, order="nearest")
+    assert_bit_equal(film, ref, "nearest order, mesh scene")
+
+
+def test_nearest_order_has_a_size_limit_and_says_so():
+    import pine_amd as pa
+    from pine_amd import scenes
+    with pytest.raises(pa.PineError, match="at most 64"):
+        pa.Plan(scenes.classic_cones((64, 32), 9), 4, 3, order="nearest")
+    with pytest.raises(pa.PineError, match="unknown traversal order"):
+        pa.Plan(scenes.cbox((32, 32)), 4, 3, order="sideways")

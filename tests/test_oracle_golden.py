@@ -177,3 +177,13 @@ def test_distance_to_the_embree_oracle(oracle, name):
     assert lo <= d["rmse"] <= hi, d
     if "rect" in name:
         assert_bit_equal(film, emb, "Rect-only cbox: both accels, both oracles, one film")
+
+
+@pytest.mark.parametrize("name", EMBREE_FILM_NAMES)
+def test_nearest_order_reproduces_the_embree_oracle(oracle, name):
+    """SURVEY.md Appendix A3's second traversal order: the top-level primitives tested nearest bounds first (what a nearest-first
+    hierarchy with one primitive per leaf -- the reference's EmbreeAccel -- does).  With it the CPU restatement renders the films
+    of the REAL reference built with EmbreeAccel bit for bit, boxes and all; this is the checker of PINE_GPU_FLAG_ORDER_NEAREST."""
+    emb, ps, spp, depth = load_film(name)
+    film, _ = oracle.render(ps, (emb.shape[1], emb.shape[0]), spp, depth, order="nearest")
+    assert_bit_equal(film, emb, f"nearest-bounds-first order vs O-gcc-embree, {name}")

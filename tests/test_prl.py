@@ -372,3 +372,46 @@ def test_example_scripts_render_equal_the_oracle(oracle, script, save, sampler):
     assert film is not None and film.shape == (96, 96, 4)
     ref, _ = oracle.render(ps, (96, 96), spp, depth, sampler=sampler)
     assert_bit_equal(film, ref, script)
+
+
+def test_accel_and_light_sampler_names_of_the_reference():
+    """program_context.cpp:47-52, 76-78: `BVH()`, `Embree()`, `Accel`, `UniformLightSampler()`, `LightSampler` and the
+    four-argument PathIntegrator a script on real pine can write; Embree() selects the nearest-bounds-first order (what
+    EmbreeAccel does), BVH() pine-BVH order; the two-argument form is unchanged."""
+    from pine_amd import prl
+    src = _cornell((64, 64), 8, 4)
+    four = src.replace("PathIntegrator(BlueSampler(spp), depth)", "PathIntegrator(Embree(), BlueSampler(spp), UniformLightSampler(), depth)")
+    assert four != src
+    out = prl.interpret(four, dry_run=True)
+    assert "@render PathIntegrator BlueSampler 8 max_path_length 4 accel Embree" in out
+    assert prl.scene_of_dry_run(out)[0] == prl.scene_of_dry_run(prl.interpret(src, dry_run=True))[0]  # the same scene
+    out = prl.interpret(four.replace("Embree()", "BVH()"), dry_run=True)
+    assert "max_path_length 4 accel BVH" in out
+    assert "accel" not in prl.interpret(src, dry_run=True).split("@render", 1)[1].splitlines()[0]
+    with pytest.raises(prl.PrlError, match="positive"):
+        prl.interpret("PathIntegrator(Embree(), BlueSampler(4), UniformLightSampler(), 0);", dry_run=True)
+    with pytest.raises(prl.PrlError):  # (no such conversion: a sampler is not a light sampler)
+        prl.interpret("PathIntegrator(Embree(), BlueSampler(4), BlueSampler(4), 3);", dry_run=True)
+
+
+@pytest.mark.gpu
+def test_script_with_the_embree_accel_renders_the_nearest_order_film(oracle, monkeypatch):
+    """A script that names its accel: Embree() -> the film of the nearest-bounds-first order (== the real reference's
+    EmbreeAccel film on this scene class, tests/test_gpu_parity.py), BVH() -> pine-BVH order; $PINE_PRL_ACCEL=embree moves the
+    two-argument constructor to the former."""
+    from pine_amd import prl
+    src = _cornell((48, 40), 16, 4).replace('world.camera.film().save("cornell.png");', "")
+    ps, spp, depth = prl.scene_of_dry_run(prl.interpret(src, dry_run=True))
+    near, _ = oracle.render(ps, (48, 40), spp, depth, order="nearest")
+    pine, _ = oracle.render(ps, (48, 40), spp, depth)
+    assert (near.view(np.uint32) != pine.view(np.uint32)).any()
+    four = src.replace("PathIntegrator(BlueSampler(spp), depth)", "PathIntegrator(Embree(), BlueSampler(spp), UniformLightSampler(), depth)")
+    prl.interpret(four)
+    assert_bit_equal(prl.last_film(), near, "PathIntegrator(Embree(), ...) vs the oracle's nearest order")
+    prl.interpret(four.replace("Embree()", "BVH()"))
+    assert_bit_equal(prl.last_film(), pine, "PathIntegrator(BVH(), ...) vs the oracle")
+    prl.interpret(src)
+    assert_bit_equal(prl.last_film(), pine, "PathIntegrator(sampler, n) vs the oracle")
+    monkeypatch.setenv("PINE_PRL_ACCEL", "embree")
+    prl.interpret(src)
+    assert_bit_equal(prl.last_film(), near, "PathIntegrator(sampler, n) with PINE_PRL_ACCEL=embree")

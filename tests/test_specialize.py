@@ -478,7 +478,7 @@ def test_default_mode_never_waits_never_fails_and_uses_the_cache(monkeypatch, tm
     from pine_amd import scenes
     monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path))  # (empty: the compiler must run)
     monkeypatch.delenv("PINE_GPU_SPECIALIZE", raising=False)
-    sc = scenes.cbox((48, 48), "readme")
+    sc = scenes.cbox((48, 48), "readme", False)  # (Rect-only room: a geometry no other test of this process has tried to build)
     want, st = _render(sc, 8, 4, specialize=False)
     assert st.specialized == 0 and st.specialize_source == 0 and st.specialize_pending == 0
     t0 = time.perf_counter()
@@ -503,7 +503,7 @@ def test_default_mode_never_waits_never_fails_and_uses_the_cache(monkeypatch, tm
     assert seen[0] == (0, 3, 1) and created < 0.5, (seen[:2], created)  # creation did not wait; the precompiled kernel rendered first
     assert seen[-1] == (2, 3, 0), seen[-1]
     # the next plan of the same geometry (another camera, size, spp): from the cache, at creation
-    other = scenes.cbox((40, 24), "committed")
+    other = scenes.cbox((40, 24), "committed", False)
     want2, _ = _render(other, 4, 3, specialize=False)
     got2, st = _render(other, 4, 3)
     assert (st.specialized, st.specialize_source, st.specialize_pending) == (2, 1, 0)
