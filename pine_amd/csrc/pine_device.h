@@ -352,6 +352,15 @@ PINE_HD f2 sample_disk_concentric(f2 u) {
   return r * f2{cs, sn};
 }
 PINE_HD f3 cosine_weighted_hemisphere(f2 u) {
+#if defined(PINE_DUP_COSHEMI) && defined(__HIP_DEVICE_COMPILE__)  /* cost measurement only: the map is evaluated PINE_DUP_COSHEMI more times on an opaque copy (same film; the extra time is its cost) */
+  for (int rep_ = 0; rep_ < PINE_DUP_COSHEMI; rep_++) {
+    f2 uu = u;
+    asm volatile("" : "+v"(uu.x), "+v"(uu.y));
+    const f2 dd = sample_disk_concentric(uu);
+    float zz = psqrt(pmax(1.0f - dd.x * dd.x - dd.y * dd.y, 0.0f)) + dd.x + dd.y;
+    asm volatile("" : : "v"(zz));
+  }
+#endif
   const f2 d = sample_disk_concentric(u);
   const float z = psqrt(pmax(1.0f - d.x * d.x - d.y * d.y, 0.0f));
   return f3{d.x, d.y, z};

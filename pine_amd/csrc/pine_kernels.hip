@@ -1264,7 +1264,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   // The stage-queued kernel is the default whenever a variant covers the scene and its LDS fits;
   // PINE_GPU_KERNEL=mega forces the lane-owns-a-path kernel, which covers every scene.
   // LDS left after a variant's fixed parts goes to the BVH node cache first, then -- when ALL nodes are in and there is
-  // still room -- to the triangle packets.  Measured on the icosphere scene: packets in place of the 288
+  // still room -- to the triangle packets.  Measured on the icosphere scene (profiles/HISTORY.md 6.3): packets in place of the 288
   // deepest nodes change nothing (191.7 vs 190.1 ms), so nodes are never evicted for them.
   // PINE_GPU_LDS_TRIS=0 / 1: never / whenever the packets fit, before the nodes (measurement aid).
   auto lds_tris_fit = [&](unsigned F, size_t lds) -> bool {
@@ -1504,7 +1504,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   W.debug_force_bail = (prm->flags & PINE_GPU_FLAG_DEBUG_FORCE_BAIL) ? 1 : 0;
   // Traversal stages of the X variants (pine_queue_kernel.h): a wave goes to retire / refill its lanes when fewer than
   // trav_min_lanes of them are still travelling, at the earliest trav_min_trips trips after the last time.  Measured
-  // (DESIGN.md 6.3): refilling pays when (nearly) the whole BVH sits in LDS (icosphere scene: 212 -> 185 ms); when most node
+  // (profiles/HISTORY.md 6.3): refilling pays when (nearly) the whole BVH sits in LDS (icosphere scene: 212 -> 185 ms); when most node
   // fetches go to L2 it costs -- the rays a wave picks up later are not the neighbours of the ones it has, and the
   // traversal waits on memory (10 000 cones: 9.8 ms without, 10.9 ms with) -- so there a wave runs its rays to the end.
   W.trav_min_lanes = (S.lds_nodes > 0 && size_t(S.lds_nodes) * 10 >= A.nodes.size() * 9) ? 48 : 0;  // (nearly) all nodes in LDS
@@ -1802,6 +1802,19 @@ int pine_gpu_plan_debug_sections(pine_gpu_plan* p, uint64_t out[16]) {
                                                  pine_gpu_kernel_part_regions_6, pine_gpu_kernel_part_regions_7};
     for (RegFn f : regs)
       if (f(rl, rh)) return -1;
+  }
+  if (p->spec_module) {
+    // the scene's own kernel (a module of its own) keeps its own copies of the REGION counters
+    hipDeviceptr_t dl = nullptr, dh = nullptr;
+    size_t bl = 0, bh = 0;
+    if (hipModuleGetGlobal(&dl, &bl, p->spec_module, "_ZN8pine_gpuL14g_region_lanesE") == hipSuccess &&
+        hipModuleGetGlobal(&dh, &bh, p->spec_module, "_ZN8pine_gpuL13g_region_hitsE") == hipSuccess && bl == sizeof rl && bh == sizeof rh) {
+      unsigned long long ml[16], mh[16];
+      if (hipMemcpy(ml, dl, sizeof ml, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(mh, dh, sizeof mh, hipMemcpyDeviceToHost) == hipSuccess)
+        for (int i = 0; i < 16; i++) rl[i] += ml[i], rh[i] += mh[i];
+    } else {
+      (void)hipGetLastError();
+    }
   }
   for (int i = 0; i < 16; i++)
     if (rh[i]) fprintf(stderr, "region %2d: entries %llu avg active lanes %.2f\n", i, rh[i], double(rl[i]) / double(rh[i]));

@@ -477,6 +477,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
     while (true) {
       // ---- the rays of the lanes that just got a context ----
       if (fresh) {
+        REGION(ANY ? 9 : 10);  // (lanes that start a ray in this round of a traversal stage)
         if (ANY) {
           const float4* r4 = reinterpret_cast<const float4*>(trav_record(id));
           const float4 a = r4[0], b = r4[1];
@@ -1230,6 +1231,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
       bool to_walk = false, to_shade = false;
       if constexpr (F & F_SSS) {
         if (valid) {
+          REGION(14);  // (lanes of a stage-W pass that hold a context)
           float4* const cg4 = reinterpret_cast<float4*>(ctx_global(id));
           const float4 a = cg4[2], b = cg4[3];
           PackedState st{cstu[CF_ST * kQCtx + id]};

@@ -135,6 +135,17 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
       const DNode nd = fetch_node<F>(S, ts.next);
       int l = -1, r = -1;
       float t0 = ray.tmax, t1 = ray.tmax;
+#ifdef PINE_DUP_TRAV_NODES  /* cost measurement only: both box tests once more on opaque copies of EVERY operand (same film; the extra time is their cost) */
+      {
+        float q0 = ray.tmax, q1 = ray.tmax, tm = ray.tmin;
+        DRayOct oo = oct;
+        asm volatile("" : "+v"(tm), "+v"(oo.dir_inv.x), "+v"(oo.dir_inv.y), "+v"(oo.dir_inv.z), "+v"(oo.org_div_dir.x), "+v"(oo.org_div_dir.y), "+v"(oo.org_div_dir.z));
+        const bool b0 = box_hit_oct(nd.lo0, nd.hi0, oo, tm, q0);
+        const bool b1 = box_hit_oct(nd.lo1, nd.hi1, oo, tm, q1);
+        float sink = (b0 ? q0 : 0.0f) + (b1 ? q1 : 0.0f);
+        asm volatile("" : : "v"(sink));
+      }
+#endif
       if (box_hit_oct(nd.lo0, nd.hi0, oct, ray.tmin, t0)) {
         if (nd.count[0] == 0) l = nd.child[0];
         else ts.pa = nd.child[0], ts.pan = nd.count[0];
@@ -218,12 +229,28 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
             }
           }
         } else if (ANY) {
+#ifdef PINE_DUP_TRAV_PRIMS  /* cost measurement only: the shape test once more on an opaque copy of the ray */
+          {
+            DRay rr = ray;
+            asm volatile("" : "+v"(rr.tmin), "+v"(rr.o.x), "+v"(rr.d.x));
+            float sink = shape_hit<F>(kind, sh, rr) ? 1.0f : 0.0f;
+            asm volatile("" : : "v"(sink));
+          }
+#endif
           if (shape_hit<F>(kind, sh, ray)) {
             ts.hit_geom = 0;
             ts.done = 1;
           }
-        } else if (shape_intersect<F>(kind, sh, ray)) {
-          ts.hit_geom = word;
+        } else {
+#ifdef PINE_DUP_TRAV_PRIMS
+          {
+            DRay rr = ray;
+            asm volatile("" : "+v"(rr.tmin), "+v"(rr.o.x), "+v"(rr.d.x));
+            float sink = shape_intersect<F>(kind, sh, rr) ? rr.tmax : 0.0f;
+            asm volatile("" : : "v"(sink));
+          }
+#endif
+          if (shape_intersect<F>(kind, sh, ray)) ts.hit_geom = word;
         }
       }
     }

@@ -54,7 +54,7 @@ const PineKernelVariant* pine_gpu_fast_variants(int* count);
 // numbering) is cached in whatever LDS the contexts and the 16-bit traversal stack leave.  The mesh-capable feature
 // sets twice: with traversal stages (F_XSTAGE: XS / XC queues, lanes refilled -- taken for scenes WITH meshes whose BVH
 // (nearly) fits the LDS node cache: the rays of a two-level BVH need very different numbers of trips and refilling
-// pays), and with the flat traversal inside stages S / T (two queue hops per vertex fewer -- taken
+// pays, profiles/HISTORY.md 6.3), and with the flat traversal inside stages S / T (two queue hops per vertex fewer -- taken
 // otherwise).  plan_build decides.  F_LDS_REST: few geometries (big meshes or not): their shape / leaf / material /
 // light records are staged in LDS too.  Subsurface: the BSSRDF random walk is a third stage (W) with its own queue.
 #define PINE_VARIANT_LIST(PINE_Q, PINE_M)                                                                                                   \
