@@ -1,7 +1,10 @@
 """Single-GPU rehearsal of strong scaling (no communication): for world = 1, 2, 4, 8 the time of EVERY rank's shard of a
 BASELINE config (8x8 tiles dealt round-robin), one after the other on this GPU -> the slowest rank's prepass + path kernel
 + resolve is what a step would cost, and base / (world x slowest) the efficiency if communication were free.
-usage: python tools/shard_scaling.py [c2 c3 c4 c5 ...]"""
+usage: python tools/shard_scaling.py [c2 c3 c4 c5 ...]
+Every plan WAITS for its scene's kernel (specialize=True: the steady state of the library's default mode -- with the default
+itself the first plans of a geometry would run the precompiled kernel while the compiler works, and the rows would not be
+comparable); PINE_GPU_SPECIALIZE=0 measures the precompiled kernels."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pine_amd
@@ -18,7 +21,7 @@ for cfg in cfgs:
     for world in (1, 2, 4, 8):
         worst, worst_rank, mean = 0.0, 0, 0.0
         for rank in range(world):
-            plan = pine_amd.Plan(scene, spp, depth, shard_rank=rank, shard_world=world, timing=True)
+            plan = pine_amd.Plan(scene, spp, depth, shard_rank=rank, shard_world=world, timing=True, specialize=True)
             plan.launch(film.data_ptr(), stream)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
