@@ -749,11 +749,17 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
     p->spec_source = kSpecSourceCache;
     if (plan_adopt_kernel(p, explicit_want && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_ASYNC)) == 0) return 0;
     if (explicit_want && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_ASYNC)) return -1;
+    // a code object the runtime refuses (cut short by a full disk, another ROCm's output): out of the way, and built afresh in
+    // the background; a packaged one that cannot be removed is bypassed for the user's cache
+    const bool packaged = R.packaged;
     (void)unlink(R.path.c_str());
-    if (R.packaged && kernel_cache_lookup(R, err, true) != 0) {  // (a damaged packaged object: the user's cache instead)
+    const int again = kernel_cache_lookup(R, err, packaged);
+    if (again < 0 || (again == 1 && plan_adopt_kernel(p, false) != 0)) {
       p->spec_state.store(kSpecFailed);
+      p->spec_async_error = again < 0 ? err : std::string(pine_gpu_last_error());
       return 0;
     }
+    if (again == 1) return 0;
   } else if (explicit_want && !(prm->flags & PINE_GPU_FLAG_SPECIALIZE_ASYNC)) {
     p->spec_source = kSpecSourceCompiledHere;
     return plan_adopt_kernel(p, true);

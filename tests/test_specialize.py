@@ -508,6 +508,26 @@ def test_default_mode_never_waits_never_fails_and_uses_the_cache(monkeypatch, tm
     got2, st = _render(other, 4, 3)
     assert (st.specialized, st.specialize_source, st.specialize_pending) == (2, 1, 0)
     assert_bit_equal(got2, want2, "kernel from the cache")
+    # a damaged cache entry (cut short, as by a full disk): the default mode neither fails nor loads it -- the precompiled kernel
+    # renders, the entry is rebuilt in the background
+    (entry,) = [e for e in os.listdir(tmp_path) if e.endswith(".co")]
+    good = os.path.getsize(tmp_path / entry)
+    with open(tmp_path / entry, "r+b") as f:
+        f.truncate(good // 3)
+    plan = pa.Plan(other, 4, 3)
+    film2 = torch.zeros((24, 40, 4), device="cuda")
+    deadline = time.perf_counter() + 120
+    while time.perf_counter() < deadline:
+        plan.launch(film2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        st = plan.stats()
+        assert_bit_equal(film2.cpu().numpy(), want2, "film while a damaged cache entry is being rebuilt")
+        if st.specialized == 2:
+            break
+        assert st.specialized == 0 and st.specialize_pending == 1, (st.specialized, st.specialize_pending)
+        time.sleep(0.02)
+    plan.close()
+    assert st.specialized == 2 and os.path.getsize(tmp_path / entry) > good // 2
     # no compiler, nothing cached: the default mode renders with the precompiled kernel and says so; nothing raises
     monkeypatch.setenv("PINE_GPU_HIPCC", "/nonexistent/hipcc")
     monkeypatch.setenv("PINE_GPU_CACHE_DIR", str(tmp_path / "empty"))
