@@ -546,3 +546,29 @@ def test_default_mode_never_waits_never_fails_and_uses_the_cache(monkeypatch, tm
     # ... and the one-shot entry point (what PathIntegrator.render calls) likewise
     f = pa.PathIntegrator(pa.BlueSampler(8), 4).render(sc).pixels
     assert_bit_equal(f, want, "one-shot render without a compiler")
+
+
+@pytest.mark.gpu
+def test_a_process_that_exits_while_the_compiler_runs_leaves_nothing_behind(tmp_path):
+    """The default mode's compiler child outlives the plan that asked for it, not the process: at exit the library ends the
+    child (its own process group), joins its workers and removes the half-made build directory -- no hang, no crash, no litter."""
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import pine_amd as pa\nfrom pine_amd import scenes\n"
+            "sc = scenes.cbox((32, 32), 'readme')\n"
+            "plan = pa.Plan(sc, 4, 3)\n"
+            "st = plan.stats()\n"
+            "print('pending', st.specialize_pending, flush=True)\n") % ROOT
+    env = dict(os.environ, PINE_GPU_CACHE_DIR=str(tmp_path))
+    env.pop("PINE_GPU_SPECIALIZE", None)
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    took = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "pending 1" in r.stdout, r.stdout
+    left = os.listdir(tmp_path)
+    assert not [e for e in left if e.startswith("build_")], left  # (a finished kernel may be there if the compiler won the race; a build directory may not)
+    assert took < 60
