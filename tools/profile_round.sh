@@ -11,8 +11,9 @@ counters=$out/${tag}_counters.json
 rm -f $counters
 # warm the kernel cache in plain runs (no profiler attached while a compiler child runs)
 for c in c2 c5; do python3 bench.py --steps 1 --warmup 1 --headline-only --config $c > $out/${tag}_warm_$c.log 2>&1; done
-# kernel-trace stats: the default-mode headline (C2; --no-configs: every path-kernel launch is C2's) ...
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 10 --warmup 2 --no-configs --no-cpu > $out/${tag}_bench_under_rocprof.log 2>&1
+# kernel-trace stats: the default-mode headline (C2; --headline-only: every path-kernel launch of the run is one of the headline
+# loop's -- 3 warm-up + 20 timed -- so the per-kernel AVERAGE is comparable with the HIP-event mean the bench line reports) ...
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 20 --warmup 3 --headline-only > $out/${tag}_bench_under_rocprof.log 2>&1
 cp gpurun_out/prof_$tag/*/*_kernel_stats.csv $out/${tag}_kernel_stats.csv
 echo "progress: c2 trace done"
 tools/pmc.sh $tag c2 specialised $counters > /dev/null 2>&1
@@ -22,7 +23,7 @@ cp gpurun_out/pmc_${tag}_c2pre_summary.txt $out/${tag}_c2_precompiled_pmc_summar
 echo "progress: c2 counters done"
 # ... and the other configs' path kernels
 for c in c4 c5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-configs --config $c > $out/${tag}_${c}_under_rocprof.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$c -- python3 bench.py --steps 6 --warmup 2 --headline-only --config $c > $out/${tag}_${c}_under_rocprof.log 2>&1
   cp gpurun_out/prof_${tag}_$c/*/*_kernel_stats.csv $out/${tag}_${c}_kernel_stats.csv
   mode=specialised; [ $c = c4 ] && mode=precompiled   # (C4 has nothing to specialise: its variant is its feature set)
   tools/pmc.sh ${tag}_$c $c $mode $counters > /dev/null 2>&1
