@@ -57,6 +57,13 @@ const PineKernelVariant* pine_gpu_fast_variants(int* count);
 // pays, profiles/HISTORY.md 6.3), and with the flat traversal inside stages S / T (two queue hops per vertex fewer -- taken
 // otherwise).  plan_build decides.  F_LDS_REST: few geometries (big meshes or not): their shape / leaf / material /
 // light records are staged in LDS too.  Subsurface: the BSSRDF random walk is a third stage (W) with its own queue.
+// (experiment builds, -DPINE_EXPERIMENT_C4X: the cone scene's kinds with traversal stages and 1536 / 1280 contexts)
+#ifdef PINE_EXPERIMENT_C4X
+#define PINE_EXPERIMENT_VARIANTS(PINE_Q)                                                                                       \
+  PINE_Q(1, 19, F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP | F_XSTAGE, PINE_EXPERIMENT_C4X, "experiment: classic.pine's kinds, traversal stages, more contexts")
+#else
+#define PINE_EXPERIMENT_VARIANTS(PINE_Q)
+#endif
 #define PINE_VARIANT_LIST(PINE_Q, PINE_M)                                                                                                   \
   PINE_Q(0, 0, F_OBB | F_LDS_SCENE, PINE_QCTX, "queue: rect+transformed box/diffuse, scene in LDS") /* cbox exactly */                      \
   PINE_Q(0, 1, kFBoxes | F_LDS_SCENE, PINE_QCTX, "queue: rect+box/diffuse, scene in LDS")                                                   \
@@ -83,6 +90,7 @@ const PineKernelVariant* pine_gpu_fast_variants(int* count);
   /* test hook: twins of variants 0 and 6 with the per-vertex log compiled in (PINE_GPU_FLAG_VERTEX_LOG; tests/test_bvh_fixtures.py) */     \
   PINE_Q(7, 16, F_OBB | F_LDS_SCENE | F_VLOG, PINE_QCTX, "queue: rect+transformed box/diffuse, scene in LDS, per-vertex log")                \
   PINE_Q(6, 17, (F_ALL & ~F_SSS) | F_LDS_REST | F_LDS_TOP | F_VLOG, 1024, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS, per-vertex log") \
+  PINE_EXPERIMENT_VARIANTS(PINE_Q)                                                                                                           \
   /* PINE_GPU_FLAG_ORDER_NEAREST: closest hits nearest bounds first (the order of the reference's EmbreeAccel); cbox-class scenes */ \
   PINE_Q(7, 18, kFAnalytic | F_LDS_SCENE | F_NEAREST, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS, nearest-bounds-first order")         \
   PINE_M(0, 0, kFBoxes | F_LDS_SCENE, 4, "rect+box/diffuse, scene in LDS")                                                                  \
