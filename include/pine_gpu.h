@@ -217,11 +217,10 @@ typedef struct {
 #define PINE_GPU_SAMPLER_BLUE  0 /* BlueSampler(spp)  src/pine/core/sampler.h:166-201 (the default)           */
 #define PINE_GPU_SAMPLER_SOBOL 1 /* SobolSampler(spp) src/pine/core/sampler.h:83-164, sampler.cpp:81-113: spp
                                     as given (no clamp to 256, any count); on the device up to 4096 (a count that is
-                                    not a power of two renders one work item per pixel), and not together with
-                                    Subsurface materials                                                     */
+                                    not a power of two renders one work item per pixel)                      */
 #define PINE_GPU_SAMPLER_HALTON 2 /* HaltonSampler(spp) src/pine/core/sampler.h:40-81, sampler.cpp:39-79,
                                     lowdiscrepancy.h:26-51: scrambled radical inverses over the first primes; on the
-                                    device under SobolSampler's two restrictions                             */
+                                    device under SobolSampler's limit (4096 samples per pixel)               */
 
 #define PINE_GPU_FLAG_TIMING 1 /* record per-kernel HIP-event timings for the roofline report */
 #define PINE_GPU_FLAG_PROGRESS 2 /* the kernels post the claimed work-item count to host memory now and then, so that

@@ -406,7 +406,7 @@ class BlueSampler:
 
 class SobolSampler:
     """SobolSampler(spp) (sampler.h:83-164): spp is used as given -- no rounding, no clamp to 256.  On the
-    device any count up to 4096, and not with Subsurface materials (the C ABI reports both)."""
+    device any count up to 4096."""
     kind = 1  # PINE_GPU_SAMPLER_SOBOL
 
     def __init__(self, samples_per_pixel):
@@ -418,7 +418,7 @@ class SobolSampler:
 
 class HaltonSampler:
     """HaltonSampler(spp) (sampler.h:40-81): scrambled radical inverses over the first primes, the pixel's place in the
-    sequence from its coordinates modulo 128; spp as given.  On the device under SobolSampler's restrictions."""
+    sequence from its coordinates modulo 128; spp as given (on the device up to 4096)."""
     kind = 2  # PINE_GPU_SAMPLER_HALTON
 
     def __init__(self, samples_per_pixel):

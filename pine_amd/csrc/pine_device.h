@@ -127,7 +127,7 @@ struct DTables {
   const int* halton_primes;  // [kHaltonDims] primes, then [kHaltonDims] prefix sums
   const uint16_t* halton_perms;
 };
-constexpr int kHaltonDims = 512;  // the packed path state holds 9 bits of sampler dimension (the reference wraps at 1000)
+constexpr int kHaltonDims = 1000;  // PrimeTablesize (primes.h): HaltonSampler::get1d / get2d wrap the dimension to 2 there (sampler.h:52-63)
 // value = sobol[dim + (index ^ rank[(dim + pix*8) % N]) * 256] ^ scramble[dim % 8 + pix*8]
 // (bluenoise_*spp.cpp:14-34); LDS = true reads dims < kLdsSamplerDims from the workgroup cache.
 template <bool LDS = false>
@@ -291,7 +291,10 @@ PINE_HD float sampler_get1d(const DTables& t, DSampler& s) {  // sampler.h:183-1
       const uint64_t u = hash_int(s.dimension);
       return sobol_sample01(si, 0, uint32_t(u));
     }
-    if (t.kind == 2) return halton_sample_dimension(t, s.dimension++, halton_index_of(s.px, s.py, s.index));  // sampler.h:52-56
+    if (t.kind == 2) {  // sampler.h:52-56
+      if (s.dimension >= kHaltonDims) s.dimension = 2;
+      return halton_sample_dimension(t, s.dimension++, halton_index_of(s.px, s.py, s.index));
+    }
   }
   if (s.dimension >= 256) s.dimension = 2;
   return blue_sample_dimension<(MODE & kSmLds) != 0>(t, s.px, s.py, s.index, s.dimension++);
@@ -309,6 +312,7 @@ PINE_HD f2 sampler_get2d(const DTables& t, DSampler& s) {  // sampler.h:188-194 
     }
     if (t.kind == 2) {  // sampler.h:57-63
       const uint32_t hi = halton_index_of(s.px, s.py, s.index);
+      if (s.dimension + 1 >= kHaltonDims) s.dimension = 2;
       const int dim = s.dimension;
       s.dimension += 2;
       const float a = halton_sample_dimension(t, dim, hi);

@@ -1246,13 +1246,8 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (!node_ops.empty()) need |= F_NODES;
   if (sobol) need |= F_SOBOL;
   if (order_nearest) need |= F_NEAREST;
-  if (sobol && (need & F_SSS)) {
-    // a BSSRDF walk draws from the sampler at every step: SobolSampler's dimension counter (no wrap-around,
-    // unlike BlueSampler's) is unbounded there and does not fit the packed path state
-    set_error(halton ? "HaltonSampler with Subsurface materials is not supported on the device"
-                     : "SobolSampler with Subsurface materials is not supported on the device");
-    return -1;
-  }
+  // (SobolSampler / HaltonSampler with Subsurface: a BSSRDF walk draws from the sampler at every step and the sampler's dimension
+  //  counter outgrows the packed path state -- the F_SSS | F_SOBOL variants keep it in a word of its own: kBigDim)
   for (auto& L : light_list)
     if (L.kind != LIGHT_AREA) need |= F_LIGHTS;
   const bool lds_ok = size_t(S.blob_bytes) <= 32 * 1024 && getenv("PINE_GPU_NO_LDS_SCENE") == nullptr;
@@ -1427,7 +1422,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     // materials, the megakernel) keeps one whole-pixel item per pixel.  PINE_GPU_NO_TILE_CLASSES: off (measurement aid).
     const unsigned qf = p->queue_variant >= 0 ? kQueueVariants[p->queue_variant].features : p->fast ? p->fast->features : 0u;
     bool ok = in_path_rng && !uber_rng && (qf & F_SSS) != 0 && H.camera.len_radius == 0.0f && getenv("PINE_GPU_NO_TILE_CLASSES") == nullptr &&
-              getenv("PINE_GPU_NO_FORK") == nullptr && spp > 1;
+              getenv("PINE_GPU_NO_FORK") == nullptr && spp > 1 && spp_pow2;  // (the independent class splits a pixel's samples by shifts and masks)
     for (auto& m : dev_materials)
       if (m.kind != MAT_EMISSIVE && m.kind != MAT_DIFFUSE && m.kind != MAT_SUBSURFACE) ok = false;
     if (ok) {

@@ -721,6 +721,12 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   PackedState st{0};
   unsigned shadow_count = 0;
   unsigned long long beta_flags = 0;  // 2 bits per level (BSSRDF beta channel); dead code without F_SSS
+  // SobolSampler / HaltonSampler in a scene with Subsurface: a BSSRDF walk draws three dimensions per step and has no bound on
+  // its steps, SobolSampler's dimension counter does not wrap (sampler.h:143-155) and HaltonSampler's wraps at 1000 -- more
+  // than the nine bits of the packed state hold.  These variants keep the counter in a register of its own.
+  constexpr bool kBigDim = (F & F_SSS) != 0 && (F & F_SOBOL) != 0;
+  int big_dim = 0;
+  (void)big_dim;
   // wave-uniform private item pool [pool_next, pool_end)
   unsigned long long pool_next = 0, pool_end = 0;
   bool queue_empty = false;
@@ -801,6 +807,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         st.start_sample(st.s_cur());
         if constexpr (F & F_SOBOL)
           if (S.tables.kind == 2) st.set_dim(2);  // HaltonSampler::start_pixel / start_next_sample: dimension = 2
+        if constexpr (kBigDim) big_dim = S.tables.kind == 2 ? 2 : 0;
         const int px = int(pxy & 0xffffu), py = int(pxy >> 16);
         // g++ evaluates gen_ray's arguments right to left (path.cpp:35): lens first, then jitter
         DRng g = rng_load();
@@ -828,6 +835,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     sampler.py = int(pxy >> 16);
     sampler.index = st.s_cur();
     sampler.dimension = st.dim();
+    if constexpr (kBigDim)
+      if (S.tables.kind != 0) sampler.dimension = big_dim;
     const int pv_length = st.length();
     int geom = -1, prim = 0;
     bool hit;
@@ -1053,7 +1062,8 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
         ray_o = nr.o;
         ray_d = nr.d;
         ray_tmax = nr.tmax;
-        st.set_dim(sampler.dimension);
+        st.set_dim(sampler.dimension & 0x1ff);
+        if constexpr (kBigDim) big_dim = sampler.dimension;
         st.next_vertex(bs.is_delta);
       } else {
         // no continuation: this vertex resolves now with lo = nee (path.cpp:121)

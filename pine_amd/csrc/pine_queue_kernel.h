@@ -130,6 +130,10 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
 #define kS(FIELD) ([&] { std::remove_cv_t<decltype(S.FIELD)> v_; kload(offsetof(DeviceScene, FIELD), &v_); return v_; }())
 #define kW(FIELD) ([&] { std::remove_cv_t<decltype(W.FIELD)> v_; kload(kWOffset + offsetof(WorkParams, FIELD), &v_); return v_; }())
   constexpr int kSM = kSmLds | ((F & F_SOBOL) ? kSmSobol : 0);  // sampler front mode (pine_device.h)
+  // SobolSampler / HaltonSampler in a scene with Subsurface: the sampler's dimension counter outgrows the nine bits of the packed
+  // state (a BSSRDF walk draws three dimensions per step, SobolSampler's counter never wraps, HaltonSampler's wraps at 1000);
+  // those variants keep it in a free word of the context's global record (float4 1, third word) while the sampler is not BlueSampler
+  constexpr bool kBigDim = (F & F_SSS) != 0 && (F & F_SOBOL) != 0;
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63;
   unsigned* const qctl = reinterpret_cast<unsigned*>(lds_raw + kQOffCtl);
@@ -298,6 +302,10 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
 
   // samples of a pixel that form one sequential chain (kFork): the whole pixel -- the item itself without tile classes
   const int chain_spi = W.serial_tiles > 0 ? S.spp : W.samples_per_item;
+  // "sample index s closes its chain / item": a chain is a power of two that divides spp, or -- SobolSampler / HaltonSampler with
+  // another count -- the whole pixel (then chain_spi == spp and the chain starts at sample 0)
+  const bool chain_pow2 = (chain_spi & (chain_spi - 1)) == 0;
+  auto chain_ends_at = [&](int s_next) -> bool { return chain_pow2 ? (s_next & (chain_spi - 1)) == 0 : s_next == chain_spi; };
   SEC_DECL;
   // record a finished closest-hit query in the context and classify the vertex it reaches:
   // emissive / miss / path-length limit -> terminal queue, otherwise -> shade queue
@@ -833,6 +841,8 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
         sampler.py = int(pxy >> 16);
         sampler.index = st.s_cur();
         sampler.dimension = st.dim();
+        if constexpr (kBigDim)
+          if (S.tables.kind != 0) sampler.dimension = int(cg[6]);
         const int pv_length = st.length();
 
         const DShape* shape = &V.shapes[geom];
@@ -923,7 +933,8 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
                 const DRay wr = spawn_ray_raw(it.p, it.n, w);  // (later steps start AT the scattering point, with tmax = float max)
                 cg4[2] = make_float4(wr.o.x, wr.o.y, wr.o.z, __int_as_float(channel));
                 cg4[3] = make_float4(wr.d.x, wr.d.y, wr.d.z, wr.tmax);
-                st.set_dim(sampler.dimension);
+                st.set_dim(sampler.dimension & 0x1ff);
+                if constexpr (kBigDim) cg[6] = uint32_t(sampler.dimension);
                 st.set_walk(kWalkRunning);
                 if constexpr (kFork) {
                   // The channel pick was this sample's LAST draw from the pixel's RNG: whatever the walk does (it draws
@@ -933,7 +944,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
                   // W ... -> S).
                   if (kW(fork_sealed) && !st.sealed()) {
                     st.set_sealed();
-                    release = ((st.s_cur() + 1) & (chain_spi - 1)) != 0;
+                    release = !chain_ends_at(st.s_cur() + 1);
                     if (!release) {
                       const unsigned before = atomicSub(&qctl[QC_PIXELS], 1u);
                       (void)before;
@@ -1121,14 +1132,15 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
             cg[4 + word] = (cg[4 + word] & ~(3u << sh)) | (unsigned(beta_channel) << sh);
           }
           const DRay nr = spawn_ray(it.p, it.n, wo_world, kFloatMax);
-          st.set_dim(sampler.dimension);
+          st.set_dim(sampler.dimension & 0x1ff);
+          if constexpr (kBigDim) cg[6] = uint32_t(sampler.dimension);
           st.next_vertex(bs.is_delta);
           if constexpr (kFork) {
             // sealed: after its first non-delta bounce a path makes no RNG draw any more (a Subsurface vertex is then
             // plain diffuse, above), so the pixel's RNG state is final for this sample and the NEXT sample can start
             if (kW(fork_sealed) && !st.sealed() && st.diffuse_length() > 0) {
               st.set_sealed();
-              release = ((st.s_cur() + 1) & (chain_spi - 1)) != 0;
+              release = !chain_ends_at(st.s_cur() + 1);
               if (!release) {  // the pixel's last sample is under way: no longer "in flight" for the intake limit
                 const unsigned before = atomicSub(&qctl[QC_PIXELS], 1u);
                 (void)before;
@@ -1246,6 +1258,8 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
           sampler.py = int(pxy >> 16);
           sampler.index = st.s_cur();
           sampler.dimension = st.dim();
+          if constexpr (kBigDim)
+            if (S.tables.kind != 0) sampler.dimension = int(ctx_global(id)[6]);
           bool hh;
           int wprim = 0;
           bool walk_mesh = false;
@@ -1261,7 +1275,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
             st.set_walk(kWalkFailed);
             to_shade = true;
           } else {
-            const float t = -plog(1 - sampler_get1d<0>(S.tables, sampler)) * (1 / mat->sigma_s[channel]);
+            const float t = -plog(1 - sampler_get1d<kSM & kSmSobol>(S.tables, sampler)) * (1 / mat->sigma_s[channel]);
             if (wr.tmax < t) {
               // leaves the shape here: Shape::intersect filled it.p / it.n for meshes only
               DSurface sit;
@@ -1273,13 +1287,14 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
               to_shade = true;
             } else {
               const f3 p = ray_at(wr, t);
-              const f3 w = uniform_sphere(sampler_get2d<0>(S.tables, sampler));
+              const f3 w = uniform_sphere(sampler_get2d<kSM & kSmSobol>(S.tables, sampler));
               cg4[2] = make_float4(p.x, p.y, p.z, a.w);
               cg4[3] = make_float4(w.x, w.y, w.z, kFloatMax);
               to_walk = true;
             }
           }
-          st.set_dim(sampler.dimension);
+          st.set_dim(sampler.dimension & 0x1ff);
+          if constexpr (kBigDim) ctx_global(id)[6] = uint32_t(sampler.dimension);
           cstu[CF_ST * kQCtx + id] = st.v;
         }
       }
@@ -1402,12 +1417,12 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
           // of the independent class, which never owned its pixel's chain)
           // (an item is samples_per_item consecutive samples: a power of two that divides spp, or -- SobolSampler / HaltonSampler
           //  with another count -- the whole pixel)
-          const int spi = kFork ? chain_spi : W.samples_per_item;
-          const bool item_done = (spi & (spi - 1)) == 0 ? (s_next & (spi - 1)) == 0 : s_next == spi;
+          const int spi = W.samples_per_item;
+          const bool item_done = kFork ? chain_ends_at(s_next) : (spi & (spi - 1)) == 0 ? (s_next & (spi - 1)) == 0 : s_next == spi;
           if ((kFork && st.sealed()) || item_done) need_item = true;
           else have_path = true;
           if constexpr (kFork)
-            if (!st.sealed() && (s_next & (chain_spi - 1)) == 0) {
+            if (!st.sealed() && chain_ends_at(s_next)) {
               const unsigned before = atomicSub(&qctl[QC_PIXELS], 1u);
               (void)before;
 #ifdef PINE_PROFILE_SECTIONS
@@ -1579,6 +1594,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
         const float jx = rng_nextf(g);
         const float jy = rng_nextf(g);
         cg4[0] = make_uint4(uint32_t(g.s0), uint32_t(g.s0 >> 32), uint32_t(g.s1), uint32_t(g.s1 >> 32));
+        if constexpr (kBigDim) ctx_global(id)[6] = S.tables.kind == 2 ? 2u : 0u;  // start_next_sample: dimension = 0 (HaltonSampler: 2)
         const int px = int(pxy & 0xffffu), py = int(pxy >> 16);
         const DCamera cam = kS(cam);
         const f2 pf{(float(px) + jx) / float(cam.W), (float(py) + jy) / float(cam.H)};

@@ -83,10 +83,10 @@ FILM_NAMES = [
 
 
 SOBOL_FILM_NAMES = ["sobol_cbox_readme_48_s8_d4", "sobol_cbox_ragged_45x37_s12_d3", "sobol_mats_zoo_32_s16_d6",
-                    "sobol_cbox_readme_24_s512_d5"]   # rendered by the reference with SobolSampler(spp)
+                    "sobol_cbox_readme_24_s512_d5", "sobol_sss_32_s8_d6"]   # rendered by the reference with SobolSampler(spp)
 
 
-HALTON_FILM_NAMES = ["halton_cbox_readme_40_s8_d4", "halton_mats_zoo_32_s12_d6"]  # rendered by the reference with HaltonSampler(spp)
+HALTON_FILM_NAMES = ["halton_cbox_readme_40_s8_d4", "halton_mats_zoo_32_s12_d6", "halton_sss_24x20_s12_d5"]  # rendered by the reference with HaltonSampler(spp)
 
 
 @pytest.fixture(scope="session")

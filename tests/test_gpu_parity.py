@@ -207,6 +207,7 @@ def _sobol_scene_for(name):
         "sobol_cbox_ragged_45x37_s12_d3": lambda: scenes.cbox((45, 37), "committed"),
         "sobol_mats_zoo_32_s16_d6": lambda: scenes.materials_zoo((32, 32)),
         "sobol_cbox_readme_24_s512_d5": lambda: scenes.cbox((24, 24), "readme"),
+        "sobol_sss_32_s8_d6": lambda: scenes.sss((32, 32), 2),
     }[name]()
 
 
@@ -234,7 +235,8 @@ def test_halton_sampler_film_matches_reference_golden(name):
     from pine_amd import scenes
     ref, ps, spp, depth = load_film(name)
     sc = {"halton_cbox_readme_40_s8_d4": lambda: scenes.cbox((40, 40), "readme"),
-          "halton_mats_zoo_32_s12_d6": lambda: scenes.materials_zoo((32, 32))}[name]()
+          "halton_mats_zoo_32_s12_d6": lambda: scenes.materials_zoo((32, 32)),
+          "halton_sss_24x20_s12_d5": lambda: scenes.sss((24, 20), 1, camera="committed")}[name]()
     assert sc.describe() == ps
     film, st = _render(sc, pa.HaltonSampler(spp), depth)
     assert st.spp_effective == spp
@@ -253,15 +255,27 @@ def test_halton_sampler_matches_the_oracle(oracle, path_kernel):
         f, st = _render(sc, pa.HaltonSampler(spp), depth)
         ref, _ = oracle.render(sc.describe(), (w, h), spp, depth, sampler="halton")
         assert_bit_equal(f, ref, f"HaltonSampler case {i} ({path_kernel})")
-    with pytest.raises(pa.PineError, match="Subsurface"):
-        pa.Plan(scenes.sss((16, 16), 1), pa.HaltonSampler(4), 4)
+
+
+@pytest.mark.parametrize("sampler", ["sobol", "halton"])
+def test_sobol_and_halton_samplers_with_subsurface(oracle, path_kernel, sampler):
+    """A BSSRDF walk draws three sampler dimensions per step and has no bound on its steps: SobolSampler's dimension counter never
+    wraps (sampler.h:143-155) and HaltonSampler's wraps to 2 at the 1000-prime table's end (:52-63) -- both beyond the nine bits the
+    packed path state keeps for BlueSampler (which wraps at 256).  The Subsurface + Sobol variants keep the counter in a word
+    of its own; films equal the CPU restatement's, walks of hundreds of steps included (sigma_s 40 in a sphere of radius 0.4)."""
+    import pine_amd as pa
+    from pine_amd import scenes
+    make = pa.SobolSampler if sampler == "sobol" else pa.HaltonSampler
+    for sc, size, spp, depth in ((scenes.sss((32, 32), 2), (32, 32), 8, 6), (scenes.sss((24, 20), 1, camera="committed"), (24, 20), 12, 5)):
+        film, st = _render(sc, make(spp), depth)
+        ref, ost = oracle.render(sc.describe(), size, spp, depth, sampler=sampler)
+        assert st.walk_steps > 0 or path_kernel == "mega"
+        assert_bit_equal(film, ref, f"{sampler} sampler with Subsurface ({path_kernel})")
 
 
 def test_sobol_sampler_limits():
     import pine_amd as pa
     from pine_amd import scenes
-    with pytest.raises(pa.PineError, match="Subsurface"):
-        pa.Plan(scenes.sss((16, 16), 1), pa.SobolSampler(4), 4)
     with pytest.raises(pa.PineError, match="positive"):
         pa.Plan(scenes.cbox((16, 16)), pa.SobolSampler(0), 4)
     with pytest.raises(pa.PineError, match="at most 4096"):

@@ -70,6 +70,8 @@ SOBOL_FILMS = {
     "sobol_cbox_ragged_45x37_s12_d3": (lambda: scenes.cbox((45, 37), "committed"), 12, 3),
     "sobol_mats_zoo_32_s16_d6": (lambda: scenes.materials_zoo((32, 32)), 16, 6),
     "sobol_cbox_readme_24_s512_d5": (lambda: scenes.cbox((24, 24), "readme"), 512, 5),
+    # with Subsurface: a BSSRDF walk's draws push the dimension counter far beyond what any other path reaches
+    "sobol_sss_32_s8_d6": (lambda: scenes.sss((32, 32), 2), 8, 6),
 }
 
 
@@ -77,6 +79,8 @@ HALTON_FILMS = {
     # HaltonSampler(spp) (sampler.h:40-81): restated in the oracle only (the device refuses it)
     "halton_cbox_readme_40_s8_d4": (lambda: scenes.cbox((40, 40), "readme"), 8, 4),
     "halton_mats_zoo_32_s12_d6": (lambda: scenes.materials_zoo((32, 32)), 12, 6),
+    # with Subsurface (the dimension wraps to 2 at the 1000-prime table's end), a count that is not a power of two, a ragged film
+    "halton_sss_24x20_s12_d5": (lambda: scenes.sss((24, 20), 1, camera="committed"), 12, 5),
 }
 
 
