@@ -932,13 +932,16 @@ def test_nearest_order_has_a_size_limit_and_says_so():
 def test_meshes_beyond_the_16_bit_node_limit_render_on_the_32_bit_variant(oracle, path_kernel):
     """The F_LDS_TOP variants keep 16-bit node ids on their traversal stacks: a BVH of 65 536 nodes and more must land on the
     all-features variant with a 32-bit stack (stage-queued kernel) or on the megakernel -- and render the oracle's film.  An
-    icosphere of 81 920 triangles (about 10^5 nodes) with a glossy skin, and the same with Subsurface."""
+    icosphere of 327 680 triangles (more than 10^5 nodes) with a glossy skin, and the same with Subsurface."""
     import pine_amd as pa
     from pine_amd import scenes
+    from pine_amd import _lib
     for skin, spp, depth in ((pa.Glossy([0.9, 0.5, 0.3], 0.2), 4, 4), (None, 2, 4)):
-        sc = scenes.sss((24, 24), 6, skin=skin)
+        sc = scenes.sss((24, 24), 7, skin=skin)  # 327 680 triangles
+        assert _lib.lib.pine_gpu_scene_build_accel(sc._h) >= 65536
         film, st = _render(sc, spp, depth)
         ref, _ = oracle.render(sc.describe(), (24, 24), spp, depth)
-        assert_bit_equal(film, ref, f"81 920-triangle mesh, skin {'glossy' if skin else 'subsurface'} ({path_kernel})")
-        if path_kernel == "queue":
-            assert st.block_threads == 1024 and not (st.kernel_features & (1 << 13)), hex(st.kernel_features)  # no F_LDS_TOP: the 32-bit-stack variant
+        assert_bit_equal(film, ref, f"327 680-triangle mesh, skin {'glossy' if skin else 'subsurface'} ({path_kernel})")
+        # (never a 16-bit-stack variant: the stage-queued kernel's 32-bit one when its stack fits LDS beside the contexts, else --
+        #  this tree is 20-odd levels deep, 4 KB of LDS per level -- the megakernel)
+        assert not (st.kernel_features & (1 << 13)), hex(st.kernel_features)
