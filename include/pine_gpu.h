@@ -301,6 +301,11 @@ int pine_gpu_path_render_devices(pine_gpu_scene*, const pine_gpu_render_params*,
  * `film_dev` is a DEVICE pointer to W*H float4; `stream` is a hipStream_t (0 = default stream).
  * Pixels outside this rank's shard are written as zeros, so a sum-reduce over ranks is exact. */
 pine_gpu_plan* pine_gpu_plan_create(pine_gpu_scene*, const pine_gpu_render_params*);
+/* Device memory of destroyed plans (the per-sample radiance buffer of a 640 x 640 x 256 render is 1.7 GB) is kept for the next
+ * plan instead of being returned to the driver: a one-shot pine_gpu_path_render spends most of its time outside the kernels in
+ * hipMalloc / hipFree otherwise.  At most $PINE_GPU_POOL_MB (default 16 384; 0 = keep nothing) per process; this call
+ * returns all of it.  The reference has no counterpart (its film and per-thread state live in host memory). */
+void pine_gpu_release_cached_memory(void);
 int pine_gpu_plan_launch(pine_gpu_plan*, void* film_dev, void* stream);
 void pine_gpu_plan_destroy(pine_gpu_plan*);
 

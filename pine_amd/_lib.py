@@ -79,6 +79,7 @@ FLAG_ORDER_NEAREST = 0x4000
 SIGNATURES = {
     "pine_gpu_last_error": (C.c_char_p, []),
     "pine_gpu_progress": (C.c_float, []),
+    "pine_gpu_release_cached_memory": (None, []),
     "pine_gpu_abi_version": (C.c_int, []),
     "pine_gpu_plan_test_traverse_baked": (C.c_int, [C.c_void_p, c_f_p, C.c_int64, C.POINTER(C.c_uint32)]),
     "pine_gpu_test_specialize_compile": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_char_p, C.c_char_p, C.c_int64]),

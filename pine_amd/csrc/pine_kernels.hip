@@ -434,11 +434,106 @@ static int effective_spp(int spp) {  // BlueSobolSampler ctor sampler.cpp:115-12
   return x + 1;
 }
 
+// Device memory of plans comes from a process-wide pool: hipMalloc / hipFree of the big per-plan buffers (the per-sample
+// radiance buffer is 1.7 GB for a 640 x 640 x 256 render, 6.8 GB for 1920 x 1080) cost 30 - 90 ms per plan, which is most of
+// what a ONE-SHOT render (pine_gpu_path_render: create, launch, destroy -- what PathIntegrator::render does) spends outside
+// its kernels.  A destroyed plan's blocks of 256 KB and more go to a per-device free list instead and the next plan takes
+// the smallest one that fits within 25 %; at most $PINE_GPU_POOL_MB (default 16 384; 0: no pool) are kept,
+// pine_gpu_release_cached_memory() frees them.  No kernel reads a buffer before writing it (hipMalloc does not clear either).
+struct DevicePool {
+  struct Block {
+    void* p;
+    size_t bytes;
+    int device;
+  };
+  std::mutex mu;
+  std::vector<Block> free_blocks;
+  std::map<void*, Block> live;  // pooled-size allocations handed out
+  size_t pooled = 0, cap = size_t(16384) << 20;
+  DevicePool() {
+    if (const char* e = getenv("PINE_GPU_POOL_MB")) cap = size_t(atoll(e) > 0 ? atoll(e) : 0) << 20;
+  }
+  static DevicePool& get() {
+    static DevicePool* q = new DevicePool();  // (never destroyed: plans may be destroyed during static destruction)
+    return *q;
+  }
+  static constexpr size_t kMinPooled = size_t(256) << 10;
+  hipError_t alloc(void** out, size_t bytes) {
+    *out = nullptr;
+    if (bytes < kMinPooled || cap == 0) return hipMalloc(out, bytes);
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const size_t want = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      int best = -1;
+      for (size_t i = 0; i < free_blocks.size(); i++) {
+        const Block& b = free_blocks[i];
+        if (b.device != device || b.bytes < want || b.bytes > want + want / 4) continue;
+        if (best < 0 || b.bytes < free_blocks[size_t(best)].bytes) best = int(i);
+      }
+      if (best >= 0) {
+        const Block b = free_blocks[size_t(best)];
+        free_blocks.erase(free_blocks.begin() + best);
+        pooled -= b.bytes;
+        live[b.p] = b;
+        *out = b.p;
+        return hipSuccess;
+      }
+    }
+    hipError_t e = hipMalloc(out, want);
+    if (e != hipSuccess) {  // memory is short: give the pool back and try once more
+      release_all();
+      (void)hipGetLastError();
+      e = hipMalloc(out, want);
+    }
+    if (e == hipSuccess) {
+      std::lock_guard<std::mutex> lock(mu);
+      live[*out] = Block{*out, want, device};
+    }
+    return e;
+  }
+  void free(void* p) {
+    if (!p) return;
+    Block b{nullptr, 0, 0};
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = live.find(p);
+      if (it != live.end()) {
+        b = it->second;
+        live.erase(it);
+        if (pooled + b.bytes <= cap) {
+          free_blocks.push_back(b);
+          pooled += b.bytes;
+          return;
+        }
+      }
+    }
+    (void)hipFree(p);  // (a small allocation, or the pool is full)
+  }
+  void release_all() {
+    std::vector<Block> blocks;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      blocks.swap(free_blocks);
+      pooled = 0;
+    }
+    int keep = 0;
+    (void)hipGetDevice(&keep);
+    for (const Block& b : blocks) {
+      (void)hipSetDevice(b.device);
+      (void)hipFree(b.p);
+    }
+    (void)hipSetDevice(keep);
+  }
+};
+#define POOL_ALLOC(ptr, bytes) DevicePool::get().alloc((void**)&(ptr), (bytes))
+
 template <class T>
 static int upload(T*& dptr, const std::vector<T>& v) {
   dptr = nullptr;
   size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-  HIP_OK(hipMalloc((void**)&dptr, bytes));
+  HIP_OK(POOL_ALLOC(dptr, bytes));
   if (!v.empty()) HIP_OK(hipMemcpy(dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return 0;
 }
@@ -886,20 +981,23 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
     p->spec_job.reset();
   }
   (void)hipSetDevice(p->device);
-  (void)hipFree(p->d_blob);
-  (void)hipFree(p->d_tri);
-  (void)hipFree(p->d_tri_leaf);
-  (void)hipFree(p->d_tri_packets);
-  (void)hipFree(p->d_halton);
-  (void)hipFree(p->d_tri_attrs);
-  (void)hipFree(p->d_tables);
-  (void)hipFree(p->d_ctxg);
-  (void)hipFree(p->d_ckpt);
-  (void)hipFree(p->d_tile_order);
-  (void)hipFree(p->d_vertex_log);
-  (void)hipFree(p->d_samples);
-  (void)hipFree(p->d_fold);
-  (void)hipFree(p->d_counters);
+  // the plan's buffers go back to the pool, which hands them to the next plan without the device-wide synchronisation hipFree
+  // implies: the plan's last launch must have finished first
+  if (p->launched) (void)hipStreamSynchronize(p->last_stream);
+  DevicePool::get().free(p->d_blob);
+  DevicePool::get().free(p->d_tri);
+  DevicePool::get().free(p->d_tri_leaf);
+  DevicePool::get().free(p->d_tri_packets);
+  DevicePool::get().free(p->d_halton);
+  DevicePool::get().free(p->d_tri_attrs);
+  DevicePool::get().free(p->d_tables);
+  DevicePool::get().free(p->d_ctxg);
+  DevicePool::get().free(p->d_ckpt);
+  DevicePool::get().free(p->d_tile_order);
+  DevicePool::get().free(p->d_vertex_log);
+  DevicePool::get().free(p->d_samples);
+  DevicePool::get().free(p->d_fold);
+  DevicePool::get().free(p->d_counters);
   if (p->spec_module) (void)hipModuleUnload(p->spec_module);
   if (p->h_progress) (void)hipHostFree(p->h_progress);
   for (auto& slot : p->ev)
@@ -1126,7 +1224,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   blob.resize((blob.size() + 15) & ~size_t(15));
   S.blob_bytes = int(blob.size());
-  HIP_OK(hipMalloc((void**)&p->d_blob, blob.size()));
+  HIP_OK(POOL_ALLOC(p->d_blob, blob.size()));
   HIP_OK(hipMemcpy(p->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (upload(p->d_tri, A.tri_verts)) return -1;
   if (upload(p->d_tri_leaf, A.tri_leaf)) return -1;
@@ -1134,7 +1232,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   int tri_packet_entries = 0, tri_packet_verts = 0;
   const bool have_tri_packets = build_tri_packets(A, tri_packets, tri_packet_entries, tri_packet_verts);
   if (have_tri_packets) {
-    HIP_OK(hipMalloc((void**)&p->d_tri_packets, tri_packets.size() * 4));
+    HIP_OK(POOL_ALLOC(p->d_tri_packets, tri_packets.size() * 4));
     HIP_OK(hipMemcpy(p->d_tri_packets, tri_packets.data(), tri_packets.size() * 4, hipMemcpyHostToDevice));
   }
   const size_t tri_packet_bytes = tri_packets.size() * 4;
@@ -1145,7 +1243,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (sobol) k = 0;  // (SobolSampler reads no table; any variant keeps the BlueSampler window loads in bounds)
   // device layout: sobolT 64 KiB | scramble 128 KiB | rank 128 KiB | 64 bytes = rank[0..63] again, so
   // a pixel's 40 consecutive ranking bytes never need the reference's modulo wrap
-  HIP_OK(hipMalloc((void**)&p->d_tables, 65536 + 262144 + 64));
+  HIP_OK(POOL_ALLOC(p->d_tables, 65536 + 262144 + 64));
   {
     const std::vector<uint8_t> st = transposed_sobol(g_tables);
     HIP_OK(hipMemcpy(p->d_tables, st.data(), 65536, hipMemcpyHostToDevice));
@@ -1190,7 +1288,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   if (halton) {
     const HaltonHostTables& ht = halton_host_tables();
     const size_t head = size_t(2 * kHaltonDims) * sizeof(int), bytes = head + ht.perms.size() * sizeof(uint16_t);
-    HIP_OK(hipMalloc((void**)&p->d_halton, bytes));
+    HIP_OK(POOL_ALLOC(p->d_halton, bytes));
     HIP_OK(hipMemcpy(p->d_halton, ht.primes_and_sums.data(), head, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(p->d_halton + head, ht.perms.data(), ht.perms.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     S.tables.halton_primes = reinterpret_cast<const int*>(p->d_halton);
@@ -1572,21 +1670,21 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
 
   if (W.items_per_pixel > 1)
-    HIP_OK(hipMalloc((void**)&p->d_ckpt, (size_t)(W.num_local_tiles - W.serial_tiles) * W.items_per_pixel * 64 * sizeof(ulonglong2)));
+    HIP_OK(POOL_ALLOC(p->d_ckpt, (size_t)(W.num_local_tiles - W.serial_tiles) * W.items_per_pixel * 64 * sizeof(ulonglong2)));
   if (!p->tile_order.empty()) {
-    HIP_OK(hipMalloc((void**)&p->d_tile_order, p->tile_order.size() * sizeof(int)));
+    HIP_OK(POOL_ALLOC(p->d_tile_order, p->tile_order.size() * sizeof(int)));
     HIP_OK(hipMemcpy(p->d_tile_order, p->tile_order.data(), p->tile_order.size() * sizeof(int), hipMemcpyHostToDevice));
     W.tile_order = p->d_tile_order;
   }
-  HIP_OK(hipMalloc((void**)&p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
+  HIP_OK(POOL_ALLOC(p->d_samples, (size_t)W.num_local_tiles * spp * 64 * sizeof(float4)));
   const size_t fold_slots = queued ? size_t(p->grid) * qctx : size_t(p->grid) * kBlock;
-  HIP_OK(hipMalloc((void**)&p->d_fold, size_t(prm->max_path_length) * 8 * fold_slots * sizeof(float)));
+  HIP_OK(POOL_ALLOC(p->d_fold, size_t(prm->max_path_length) * 8 * fold_slots * sizeof(float)));
   if (queued) {
     // per-context records, then (Subsurface variants) every workgroup's ring of sample-token slots
     const size_t token_dwords = (queue_features & F_SSS) ? size_t(p->grid) * (qctx <= 1024 ? 1024 : 2048) * kQTokenDwords : 0;
-    HIP_OK(hipMalloc((void**)&p->d_ctxg, (size_t(p->grid) * qctx * q_ctx_global_dwords(queue_features) + token_dwords) * sizeof(uint32_t)));
+    HIP_OK(POOL_ALLOC(p->d_ctxg, (size_t(p->grid) * qctx * q_ctx_global_dwords(queue_features) + token_dwords) * sizeof(uint32_t)));
   }
-  HIP_OK(hipMalloc((void**)&p->d_counters, sizeof(Counters)));
+  HIP_OK(POOL_ALLOC(p->d_counters, sizeof(Counters)));
   p->timed = (prm->flags & PINE_GPU_FLAG_TIMING) != 0;
   if (p->timed)
     for (auto& slot : p->ev)
@@ -1668,6 +1766,8 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
   p->last_stream = stream;
   return 0;
 }
+
+void pine_gpu_release_cached_memory(void) { DevicePool::get().release_all(); }
 
 int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream) { return plan_launch(p, film_dev, stream, false); }
 int pine_gpu_plan_launch_packed(pine_gpu_plan* p, void* slab_dev, void* stream) { return plan_launch(p, slab_dev, stream, true); }
@@ -1869,7 +1969,7 @@ int64_t pine_gpu_plan_vertex_log(pine_gpu_plan* p, float* out, int64_t capacity)
   }
   HIP_OK(hipSetDevice(p->device));
   if (!out) {  // switch the log on: the NEXT launches fill it
-    if (!p->d_vertex_log) HIP_OK(hipMalloc((void**)&p->d_vertex_log, size_t(n) * 4));
+    if (!p->d_vertex_log) HIP_OK(POOL_ALLOC(p->d_vertex_log, size_t(n) * 4));
     HIP_OK(hipMemset(p->d_vertex_log, 0, size_t(n) * 4));
     p->W.vertex_log = p->d_vertex_log;
     return n;
@@ -1926,7 +2026,7 @@ int pine_gpu_path_render(pine_gpu_scene* scene, const pine_gpu_render_params* pr
   void* d_film = nullptr;
   const size_t bytes = size_t(p->film_w) * p->film_h * 16;
   do {
-    if (hipMalloc(&d_film, bytes) != hipSuccess) {
+    if (DevicePool::get().alloc(&d_film, bytes) != hipSuccess) {
       set_error("hipMalloc(film) failed");
       break;
     }
@@ -1943,7 +2043,8 @@ int pine_gpu_path_render(pine_gpu_scene* scene, const pine_gpu_render_params* pr
   g_progress_src.store(nullptr);
   g_progress.store(rc ? 0.0f : 1.0f);
   std::string keep = rc ? pine_gpu_last_error() : "";
-  hipFree(d_film);
+  if (rc) (void)hipDeviceSynchronize();  // (a failed launch may still be running: nothing of it may touch a block the pool hands out again)
+  DevicePool::get().free(d_film);
   pine_gpu_plan_destroy(p);
   if (rc) set_error(keep);
   return rc;

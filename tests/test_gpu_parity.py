@@ -945,3 +945,21 @@ def test_meshes_beyond_the_16_bit_node_limit_render_on_the_32_bit_variant(oracle
         # (never a 16-bit-stack variant: the stage-queued kernel's 32-bit one when its stack fits LDS beside the contexts, else --
         #  this tree is 20-odd levels deep, 4 KB of LDS per level -- the megakernel)
         assert not (st.kernel_features & (1 << 13)), hex(st.kernel_features)
+
+
+def test_device_memory_pool_changes_nothing_and_can_be_released(oracle):
+    """Plans take their device buffers from a process-wide pool of the blocks destroyed plans gave back (a one-shot render spends
+    most of its time outside the kernels in hipMalloc / hipFree otherwise): films of back-to-back one-shot renders -- the second
+    in the first's recycled memory, a smaller one in a block that is too large, one after the pool has been emptied -- equal the
+    oracle's."""
+    import pine_amd as pa
+    from pine_amd import _lib, scenes
+    a, b = scenes.cbox((96, 80), "readme"), scenes.classic_cones((64, 32), 6)
+    ra, _ = oracle.render(a.describe(), (96, 80), 16, 5)
+    rb, _ = oracle.render(b.describe(), (64, 32), 8, 4)
+    integ_a, integ_b = pa.PathIntegrator(pa.BlueSampler(16), 5), pa.PathIntegrator(pa.BlueSampler(8), 4)
+    for round_ in range(3):
+        assert_bit_equal(integ_a.render(a).pixels, ra, f"one-shot cbox, round {round_}")
+        assert_bit_equal(integ_b.render(b).pixels, rb, f"one-shot cones in recycled memory, round {round_}")
+        if round_ == 1:
+            _lib.lib.pine_gpu_release_cached_memory()

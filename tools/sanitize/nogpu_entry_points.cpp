@@ -28,6 +28,7 @@ static int fail() {
 
 extern "C" {
 float pine_gpu_progress(void) { return 0.0f; }
+void pine_gpu_release_cached_memory(void) {}
 int pine_gpu_set_table_path(const char* path) { return path ? 0 : fail(); }
 int pine_gpu_path_render(pine_gpu_scene*, const pine_gpu_render_params*, float*) { return fail(); }
 int pine_gpu_path_render_multi(pine_gpu_scene*, const pine_gpu_render_params*, uint64_t, float*) { return fail(); }
