@@ -304,7 +304,8 @@ pine_gpu_plan* pine_gpu_plan_create(pine_gpu_scene*, const pine_gpu_render_param
 /* Device memory of destroyed plans (the per-sample radiance buffer of a 640 x 640 x 256 render is 1.7 GB) is kept for the next
  * plan instead of being returned to the driver: a one-shot pine_gpu_path_render spends most of its time outside the kernels in
  * hipMalloc / hipFree otherwise.  At most $PINE_GPU_POOL_MB (default 16 384; 0 = keep nothing) per process; this call
- * returns all of it.  The reference has no counterpart (its film and per-thread state live in host memory). */
+ * returns all of it, and drops the process's table of loaded scene kernels (the last 16 code objects stay loaded per device so
+ * that the next plan of the same geometry does not load its kernel again).  The reference has no counterpart (its film and per-thread state live in host memory). */
 void pine_gpu_release_cached_memory(void);
 int pine_gpu_plan_launch(pine_gpu_plan*, void* film_dev, void* stream);
 void pine_gpu_plan_destroy(pine_gpu_plan*);

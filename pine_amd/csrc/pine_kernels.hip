@@ -649,9 +649,9 @@ struct pine_gpu_plan {
   float accel_build_ms = 0.0f, upload_ms = 0.0f;  // host-side cost of plan creation (reported by stats_get)
   bool accel_on_device = false;
   // PINE_GPU_FLAG_SPECIALIZE: the queue kernel compiled for this scene (pine_specialize.h); null: the precompiled variant
+  std::shared_ptr<struct LoadedKernel> spec_loaded;  // (shared with every plan of this geometry on this device: LoadedKernels)
   hipModule_t spec_module = nullptr;
   hipFunction_t spec_fn = nullptr;
-  std::string spec_image;
   unsigned spec_features = 0;  // ... its feature set (the scene's own), and whether the scene's BVH is baked in
   bool spec_baked = false;
   KernelRequest spec_request;  // what to compile (filled at plan creation)
@@ -795,6 +795,51 @@ struct SpecQueue {
   }
 };
 
+// A code object loaded into a device's context, shared by the plans that run it: hipModuleLoadData of a scene's kernel is a
+// millisecond or two, which a one-shot render (create, launch, destroy) of the same geometry would pay on every call.  The
+// process keeps the last kMaxLoaded of them per (device, content key); a module is unloaded when the table has dropped it and
+// the last plan that launches it is gone.
+struct LoadedKernel {
+  int device = 0;
+  std::string key, image;  // (the image is kept for the module's lifetime: the runtime may build the program lazily from it)
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+  ~LoadedKernel() {
+    if (module) {
+      int keep = 0;
+      (void)hipGetDevice(&keep);
+      (void)hipSetDevice(device);
+      (void)hipModuleUnload(module);
+      (void)hipSetDevice(keep);
+    }
+  }
+};
+struct LoadedKernels {
+  static constexpr size_t kMaxLoaded = 16;
+  std::mutex mu;
+  std::deque<std::shared_ptr<LoadedKernel>> recent;
+  static LoadedKernels& get() {
+    static LoadedKernels* q = new LoadedKernels();  // (never destroyed: unloading modules while the runtime goes down is not safe)
+    return *q;
+  }
+  std::shared_ptr<LoadedKernel> find(int device, const std::string& key) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& k : recent)
+      if (k->device == device && k->key == key) return k;
+    return nullptr;
+  }
+  void remember(const std::shared_ptr<LoadedKernel>& k) {
+    std::lock_guard<std::mutex> lock(mu);
+    recent.push_front(k);
+    if (recent.size() > kMaxLoaded) recent.pop_back();
+  }
+  void forget(const std::string& key) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto it = recent.begin(); it != recent.end();)
+      it = (*it)->key == key ? recent.erase(it) : it + 1;
+  }
+};
+
 static int plan_adopt_kernel(pine_gpu_plan* p, bool compile_here);
 static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vector<DShape>& shapes, const std::vector<int>& packed_prims,
                            const pine_gpu_render_params* prm, unsigned need) {
@@ -887,14 +932,26 @@ static int plan_adopt_kernel(pine_gpu_plan* p, bool compile_here) {
       return -1;
     }
     const bool from_cache = found == 1;
-    hipError_t e = hipErrorInvalidImage;
-    if (read_file(R.path, p->spec_image) && code_object_is_whole(p->spec_image)) {  // (kept for the module's lifetime: the runtime may build the program lazily from it)
-      e = hipModuleLoadData(&p->spec_module, p->spec_image.data());
-      if (e == hipSuccess) e = hipModuleGetFunction(&p->spec_fn, p->spec_module, kernel_symbol(R.features, R.ctx).c_str());
+    if (auto loaded = LoadedKernels::get().find(p->device, R.key)) {  // this geometry's kernel is in this device's context already
+      p->spec_loaded = loaded;
+      p->spec_module = loaded->module, p->spec_fn = loaded->fn;
+      break;
     }
-    if (e == hipSuccess) break;
+    hipError_t e = hipErrorInvalidImage;
+    auto k = std::make_shared<LoadedKernel>();
+    k->device = p->device, k->key = R.key;
+    if (read_file(R.path, k->image) && code_object_is_whole(k->image)) {
+      e = hipModuleLoadData(&k->module, k->image.data());
+      if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, kernel_symbol(R.features, R.ctx).c_str());
+    }
+    if (e == hipSuccess) {
+      LoadedKernels::get().remember(k);
+      p->spec_loaded = k;
+      p->spec_module = k->module, p->spec_fn = k->fn;
+      break;
+    }
     (void)hipGetLastError();
-    if (p->spec_module) (void)hipModuleUnload(p->spec_module);
+    k.reset();  // (unloads what was loaded)
     p->spec_module = nullptr, p->spec_fn = nullptr;
     if (attempt == 0 && compile_here && from_cache) {
       if (unlink(R.path.c_str()) != 0) skip_packaged = true;  // (a read-only install: compile into the user's cache instead)
@@ -998,7 +1055,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   DevicePool::get().free(p->d_samples);
   DevicePool::get().free(p->d_fold);
   DevicePool::get().free(p->d_counters);
-  if (p->spec_module) (void)hipModuleUnload(p->spec_module);
+  p->spec_loaded.reset();  // (the module stays loaded while the process-wide table or another plan holds it)
   if (p->h_progress) (void)hipHostFree(p->h_progress);
   for (auto& slot : p->ev)
     for (auto& e : slot)
@@ -1767,7 +1824,11 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
   return 0;
 }
 
-void pine_gpu_release_cached_memory(void) { DevicePool::get().release_all(); }
+void pine_gpu_release_cached_memory(void) {
+  DevicePool::get().release_all();
+  std::lock_guard<std::mutex> lock(LoadedKernels::get().mu);
+  LoadedKernels::get().recent.clear();  // (a module is unloaded when the last plan that launches it is gone)
+}
 
 int pine_gpu_plan_launch(pine_gpu_plan* p, void* film_dev, void* stream) { return plan_launch(p, film_dev, stream, false); }
 int pine_gpu_plan_launch_packed(pine_gpu_plan* p, void* slab_dev, void* stream) { return plan_launch(p, slab_dev, stream, true); }

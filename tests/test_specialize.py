@@ -451,6 +451,8 @@ def test_a_damaged_cache_entry_is_replaced(monkeypatch, tmp_path):
     good = os.path.getsize(tmp_path / entry)
     with open(tmp_path / entry, "r+b") as f:  # cut short, as by a full disk
         f.truncate(good // 3)
+    from pine_amd import _lib
+    _lib.lib.pine_gpu_release_cached_memory()  # (as a new process would find it: this one still has the kernel loaded)
     b, st = _render(sc, 4, 3, specialize=True)
     assert st.specialized == 2, "the plan did not get its kernel back"
     assert os.listdir(tmp_path) == [entry] and os.path.getsize(tmp_path / entry) > good // 2, (os.listdir(tmp_path), os.path.getsize(tmp_path / entry), good)
@@ -514,6 +516,8 @@ def test_default_mode_never_waits_never_fails_and_uses_the_cache(monkeypatch, tm
     good = os.path.getsize(tmp_path / entry)
     with open(tmp_path / entry, "r+b") as f:
         f.truncate(good // 3)
+    from pine_amd import _lib
+    _lib.lib.pine_gpu_release_cached_memory()  # (as a new process would find it: this one still has the kernel loaded)
     plan = pa.Plan(other, 4, 3)
     film2 = torch.zeros((24, 40, 4), device="cuda")
     deadline = time.perf_counter() + 120
