@@ -15,12 +15,23 @@
 #include <pine/core/scene.h>
 #include <pine/core/sampler.h>
 #include <pine/core/material.h>
+#include <pine/core/accel.h>
+#include <pine/core/lightsampler.h>
 
 #include <pine_gpu.h>
 
 namespace pine {
 
 struct GpuPathIntegrator {
+  // PathIntegrator(Accel, Sampler, LightSampler, int) (program_context.cpp:76-78).  The accel decides the ORDER closest hits are
+  // found in, which one shape can see (the transformed Box, bbox.cpp:149-171): an Accel that holds an EmbreeAccel -- the only
+  // one a .pine script can construct, and what the two-argument constructor of program_context.cpp:79-81 passes -- renders
+  // nearest bounds first (PINE_GPU_FLAG_ORDER_NEAREST: the films of the reference's EmbreeAccel, bit for bit); a BVH, in
+  // pine-BVH order.  The light sampler has one alternative, UniformLightSampler: nothing to choose.
+  GpuPathIntegrator(const Accel& accel, Sampler sampler_, LightSampler, int max_path_length)
+      : GpuPathIntegrator(MOVE(sampler_), max_path_length) {
+    order_nearest = accel.is<EmbreeAccel>();
+  }
   GpuPathIntegrator(Sampler sampler_, int max_path_length) : sampler(MOVE(sampler_)), max_path_length(max_path_length) {
     if (max_path_length <= 0)
       SEVERE("`PathIntegrator` expect `max_path_length` to be positive, get", max_path_length);  // path.cpp:12-13
@@ -97,7 +108,8 @@ struct GpuPathIntegrator {
   void render(Scene& scene) {
     auto* s = mirror(scene);
     auto& film = scene.camera.film();
-    pine_gpu_render_params prm{sampler.spp(), max_path_length, /*device*/ 0, /*rank*/ 0, /*world*/ 1, 0, specialize ? PINE_GPU_FLAG_SPECIALIZE : 0,
+    pine_gpu_render_params prm{sampler.spp(), max_path_length, /*device*/ 0, /*rank*/ 0, /*world*/ 1, 0,
+                               (specialize ? PINE_GPU_FLAG_SPECIALIZE : 0) | (order_nearest ? PINE_GPU_FLAG_ORDER_NEAREST : 0),
                                sampler.is<SobolSampler>() ? PINE_GPU_SAMPLER_SOBOL : sampler.is<HaltonSampler>() ? PINE_GPU_SAMPLER_HALTON : PINE_GPU_SAMPLER_BLUE};
     // film.data() is Array2d<vec4>: W*H float4, row 0 first -- exactly the layout the ABI writes (array.h:51-55)
     const int rc = pine_gpu_path_render(s, &prm, &film.data()[0][0]);
@@ -112,6 +124,8 @@ struct GpuPathIntegrator {
   // library loads it from its on-disk cache, or compiles it in the background while the precompiled kernel renders this call;
   // true: wait for the compiler here (seconds of hipcc the first time a geometry is seen) and fail if it cannot be built
   bool specialize = false;
+  // closest hits nearest bounds first, as EmbreeAccel (set by the four-argument constructor from the Accel it is handed)
+  bool order_nearest = false;
 };
 
 }  // namespace pine

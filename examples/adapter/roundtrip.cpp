@@ -75,7 +75,12 @@ int main(int argc, char** argv) {
     const vec2i size(atoi(argv[3]), atoi(argv[4]));
     Scene scene = which == "zoo" ? zoo(size) : cbox(size);
     scene.camera.film().clear();
-    GpuPathIntegrator integ(Sampler(BlueSobolSampler(atoi(argv[5]))), atoi(argv[6]));
+    // ROUNDTRIP_ACCEL=embree | bvh: the four-argument constructor with that Accel (never built: the GPU path needs none)
+    const char* accel_name = getenv("ROUNDTRIP_ACCEL");
+    GpuPathIntegrator integ = accel_name
+        ? GpuPathIntegrator(std::string(accel_name) == "embree" ? Accel(EmbreeAccel()) : Accel(BVH()), Sampler(BlueSobolSampler(atoi(argv[5]))),
+                            LightSampler(UniformLightSampler()), atoi(argv[6]))
+        : GpuPathIntegrator(Sampler(BlueSobolSampler(atoi(argv[5]))), atoi(argv[6]));
     integ.specialize = getenv("ROUNDTRIP_SPECIALIZE") != nullptr;  // (the test renders both ways)
     integ.render(scene);  // (aborts through SEVERE on any error, as the reference's integrators do)
     auto& film = scene.camera.film();

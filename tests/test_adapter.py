@@ -136,6 +136,24 @@ def test_adapter_render_end_to_end_equals_the_reference_film(tmp_path, which, na
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("accel, name", [("embree", "embree_cbox_readme_64_s16_d4"), ("bvh", "cbox_readme_64_s16_d4")])
+def test_adapter_four_argument_constructor_follows_the_accel(tmp_path, accel, name):
+    """GpuPathIntegrator(Accel, Sampler, LightSampler, int) -- the registration of program_context.cpp:76-78: handed an
+    Accel(EmbreeAccel()) it renders the film the real reference rendered WITH EmbreeAccel, handed Accel(BVH()) the one it
+    rendered with its own BVH; both bit for bit."""
+    exe = os.path.join(ROOT, "build", "adapter_roundtrip")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("build/adapter_roundtrip not built (needs the reference sources: __graft_entry__.build() in the build container)")
+    out = tmp_path / "a.film"
+    r = subprocess.run([exe, "cbox", "render", "64", "64", "16", "4", str(out)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ROUNDTRIP_ACCEL=accel))
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    film = np.fromfile(out, dtype=np.float32).reshape(64, 64, 4)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", f"film_{name}.npz"))["film"]
+    assert_bit_equal(film, ref, f"adapter, Accel({accel}) vs the reference's film {name}")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("specialize", [False, True])
 def test_cpp_facade_example_renders_the_reference_film(tmp_path, specialize):
     """examples/cbox.cpp (scenes/cbox.pine written against pine_amd/host/pine.hpp, built by __graft_entry__.build()): its film
