@@ -1940,18 +1940,32 @@ Interp::Interp() {
     prm.sampler = p->sampler;
     // The accel decides the ORDER closest hits are found in, which only the transformed Box(AABB, mat4) can see
     // (bbox.cpp:149-171).  Embree(): nearest bounds first, as EmbreeAccel.  BVH(): pine-BVH order.  The two-argument
-    // constructor: real pine gives it EmbreeAccel (program_context.cpp:79-81); here it renders in pine-BVH order -- the order
-    // of the parity oracle -- unless $PINE_PRL_ACCEL=embree, and a scene that can tell the difference says so once.
+    // constructor is `PathIntegrator(EmbreeAccel(), sampler, UniformLightSampler(), n)` in the reference
+    // (program_context.cpp:79-81), so a script that uses it -- scenes/cbox.pine does -- gets what it gets from real pine:
+    // nearest bounds first, wherever that order is implemented and reproduces it (at most 64 top-level primitives, no meshes);
+    // other scenes render in pine-BVH order and, if they have a transformed Box, say so once.  $PINE_PRL_ACCEL=bvh | embree (pine-mi355x --accel) decides
+    // for the two-argument form explicitly.
     int accel = p->accel;
     if (accel == 0) {
       const char* e = getenv("PINE_PRL_ACCEL");
-      accel = (e && std::string(e) == "embree") ? 2 : 1;
-      static bool said = false;
-      if (accel == 1 && !said && describe_scene(s->h).find("shape obb ") != std::string::npos) {
-        said = true;
-        fprintf(stderr, "[pine-mi355x] note: this scene has a transformed Box(AABB, mat4), whose image depends on the accel's test order; "
-                        "PathIntegrator(sampler, n) renders it in pine-BVH order (Accel(BVH())).  Real pine's default EmbreeAccel tests "
-                        "nearest bounds first: PathIntegrator(Embree(), sampler, UniformLightSampler(), n) or PINE_PRL_ACCEL=embree renders that image.\n");
+      if (e && std::string(e) == "embree") accel = 2;
+      else if (e && std::string(e) == "bvh") accel = 1;
+      else {
+        const std::string text = describe_scene(s->h);
+        size_t shapes = 0;
+        for (size_t at = text.find("shape "); at != std::string::npos; at = text.find("\nshape ", at + 1)) shapes++;
+        // (a scene with meshes keeps pine-BVH order: under real Embree a mesh's triangles go through Embree's own intersector,
+        //  which nothing here restates, so there is no EmbreeAccel image to reproduce -- and the fixtures of the glTF import are
+        //  the reference's BVH renders)
+        const bool meshes = text.find("shape mesh") != std::string::npos;
+        accel = shapes <= 64 && !meshes ? 2 : 1;
+        static bool said = false;
+        if (accel == 1 && !said && text.find("shape obb ") != std::string::npos) {
+          said = true;
+          fprintf(stderr, "[pine-mi355x] note: this scene has a transformed Box(AABB, mat4), whose image depends on the accel's test order, and "
+                          "%s: PathIntegrator(sampler, n) renders it in pine-BVH order (Accel(BVH())), not in the nearest-bounds-first order "
+                          "of real pine's default EmbreeAccel.\n", meshes ? "meshes" : "more than 64 top-level primitives");
+        }
       }
     }
     if (accel == 2) prm.flags |= PINE_GPU_FLAG_ORDER_NEAREST;
