@@ -125,10 +125,23 @@ __device__ __forceinline__ void trav_trips(const SceneView& S, DRay& ray, const 
 #define PINE_NODE_REPS_X 1
 #endif
 #endif
+#ifdef PINE_NODE_ADAPT  /* experiment: up to PINE_NODE_ADAPT_MAX node steps per trip, ended as soon as PINE_NODE_ADAPT lanes wait with a primitive or no lane has a node to visit */
+    constexpr int kNodeReps = PINE_NODE_ADAPT_MAX;
+#else
     constexpr int kNodeReps = (F & F_XSTAGE) != 0 ? PINE_NODE_REPS_X : 2;
+#endif
 #pragma unroll
     for (int rep = 0; rep < kNodeReps; rep++) {
-    if (rep > 0) next_step();
+    if (rep > 0) {
+      next_step();
+#ifdef PINE_NODE_ADAPT
+      if (rep >= PINE_NODE_ADAPT_MIN) {
+        const unsigned long long waiting = __ballot(ts.pan > 0 && !ts.done);
+        const unsigned long long at_node = __ballot(ts.pan == 0 && ts.next >= 0 && !ts.done);
+        if (at_node == 0 || __popcll(waiting) >= PINE_NODE_ADAPT) break;
+      }
+#endif
+    }
     if (ts.pan == 0 && ts.next >= 0 && !ts.done) {
       // ---- one node: both child boxes against the tmax of this moment (bvh.cpp:405-446) ----
       REGION(ANY ? 6 : 2);
