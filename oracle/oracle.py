@@ -53,7 +53,7 @@ def render(pscene: str, size, spp, depth, threads=0, rows=None, sampler="blue", 
     st = Stats()
     y0, y1 = rows if rows else (0, 0)
     lib().oracle_set_sampler({"sobol": 1, "halton": 2}.get(sampler, 0))
-    lib().oracle_set_order(1 if order == "nearest" else 0)
+    lib().oracle_set_order({"nearest": 1, "embree": 2}.get(order, 0))
     try:
         rc = lib().oracle_render(pscene.encode(), _tp(), int(spp), int(depth), int(threads), int(y0), int(y1),
                                  film.ctypes.data_as(C.c_void_p), C.byref(st))

@@ -26,7 +26,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
+#include <stdexcept>
+#include <utility>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -2225,7 +2228,303 @@ struct BVHImpl {
   }
 };
 
-static int g_order_mode = 0;  // test-infrastructure switch (oracle_set_order): 0 pine's BVH order, 1 nearest bounds first
+static int g_order_mode = 0;  // test-infrastructure switch (oracle_set_order): 0 pine's BVH order, 1 nearest bounds first, 2 EmbreeAccel's order
+
+// ------------------------------------------------------------------------------------------------
+// Order mode "embree": the order in which the reference's DEFAULT accel, EmbreeAccel, tests the non-mesh shapes.
+// pine registers every non-mesh shape as one Embree user primitive with pine's own bounds / intersect callbacks
+// (src/pine/impl/accel/embree.cpp:12-40, :88-99), so the only thing Embree decides is WHICH primitives a closest-hit query
+// tests, in WHICH order, with which tfar.  That is restated here from the vendored Embree 4.3.1 (src/contrib/embree), the
+// code path an AVX2 x86 host takes: a BVH8 of `Object` leaves (one primitive each: kernels/common/state.cpp:76-77,
+// kernels/common/scene.cpp:453-467) built by the binned-SAH builder (kernels/builders/bvh_builder_sah.h:220-330,
+// heuristic_binning.h, heuristic_binning_array_aligned.h) and walked by the single-ray traverser
+// (kernels/bvh/bvh_intersector1.cpp:30-107, bvh_traverser1.h:310-385, node_intersector1.h:26-60, :484-530).
+// ------------------------------------------------------------------------------------------------
+#include "../pine_amd/data/rcpps_table.h"  // the RCPPS estimates of the CPU that rendered tests/golden/film_embree_* (tools/extract_rcpps_table.c)
+namespace embree_order {
+constexpr float kInf = std::numeric_limits<float>::infinity();
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+// common/math/vec3fa.h:122-144 (AVX2 branch): r = RCPPS(a); r + r * (1 - a * r), both steps fused
+inline float rcp_nr(float a) {
+  const uint32_t u = f2u(a);
+  const int e = int((u >> 23) & 0xffu);                                            // (zero_fix keeps |a| >= 1e-18: normal numbers only)
+  const uint32_t t = kRcppsTable[(u >> 12) & 0x7ffu];                              // estimate for the mantissa in [1, 2): in (0.5, 1]
+  const float r = u2f((u & 0x80000000u) | ((((t >> 23) & 0xffu) + 127u - uint32_t(e)) << 23) | (t & 0x7fffffu));
+  const float h = std::fmaf(-a, r, 1.0f);
+  return std::fmaf(r, h, r);
+}
+inline float rcp_safe(float a) {  // vec3fa.h:167-172: min_rcp_input = 1e-18f (common/math/constants.h)
+  return rcp_nr(std::fabs(a) < 1e-18f ? 1e-18f : a);
+}
+struct Box {
+  float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+  void extend(const float* l, const float* h) {
+    for (int d = 0; d < 3; d++) lo[d] = std::min(lo[d], l[d]), hi[d] = std::max(hi[d], h[d]);
+  }
+  void extend(const float* p) { extend(p, p); }
+  void extend(const Box& b) { extend(b.lo, b.hi); }
+};
+// common/math/vec3fa.h:349, bbox.h:129-139: madd(d.x, d.y + d.z, d.y * d.z).  The BUILDER is the AVX one ("building BVH8<object> using
+// avx::BVH8BuilderSAH" under verbose=2; builders are not compiled for AVX2): its madd is a * b + c with two roundings (emath.h:328)
+inline float half_area(const Box& b) {
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return dx * (dy + dz) + dy * dz;
+}
+struct PrimRef {
+  float lo[3], hi[3];
+  int id;  // geomID (primID is 0: rtcSetGeometryUserPrimitiveCount(geom, 1))
+  void center2(float* c) const { for (int d = 0; d < 3; d++) c[d] = lo[d] + hi[d]; }
+};
+struct Set {  // PrimInfoRange: [begin, end) of the PrimRef array with the bounds of the boxes and of the doubled centres
+  size_t begin = 0, end = 0;
+  Box geom, cent;
+  size_t size() const { return end - begin; }
+  void add(const PrimRef& p) {
+    geom.extend(p.lo, p.hi);
+    float c[3];
+    p.center2(c);
+    cent.extend(c);
+  }
+};
+struct Split {  // BinSplit + its BinMapping
+  float sah = kInf;
+  int dim = -1, pos = 0;
+  size_t num = 0;
+  float ofs[3] = {0, 0, 0}, scale[3] = {0, 0, 0};
+  int bin(const PrimRef& p, int d) const {  // BinMapping::bin_unsafe: floori((center2 - ofs) * scale)
+    float c[3];
+    p.center2(c);
+    return int(std::floor((c[d] - ofs[d]) * scale[d]));
+  }
+};
+struct Tree {
+  struct Node {
+    float lo[3][8], hi[3][8];
+    int child[8];  // >= 0: node; < 0: ~geometry index (an Object leaf); kEmpty: no child
+    int n = 0;
+  };
+  static constexpr int kEmpty = INT32_MIN;
+  std::vector<Node> nodes;
+  int root = kEmpty;
+  std::vector<PrimRef> prims;
+
+  // HeuristicArrayBinningSAH::find (heuristic_binning_array_aligned.h:100-114) = BinMapping (heuristic_binning.h:43-52), BinInfoT::bin (:210-255), ::best (:331-385)
+  Split find(const Set& set) const {
+    Split sp;
+    constexpr size_t BINS = 32;  // NUM_OBJECT_BINS
+    sp.num = std::min(BINS, size_t(4.0f + 0.05f * float(set.size())));
+    for (int d = 0; d < 3; d++) {
+      const float eps = 1E-34f, size = set.cent.hi[d] - set.cent.lo[d];
+      const float diag = eps > size ? eps : size;  // _mm_max_ps(eps, size)
+      sp.scale[d] = diag > eps ? (0.99f * float(sp.num)) / diag : 0.0f;
+      sp.ofs[d] = set.cent.lo[d];
+    }
+    Box bounds[BINS][3];
+    unsigned counts[BINS][3] = {};
+    for (size_t i = set.begin; i < set.end; i++)
+      for (int d = 0; d < 3; d++) {
+        const int b = std::clamp(sp.bin(prims[i], d), 0, int(sp.num) - 1);  // BinMapping::bin clamps
+        bounds[b][d].extend(prims[i].lo, prims[i].hi);
+        counts[b][d]++;
+      }
+    float rAreas[BINS][3];
+    unsigned rCounts[BINS][3];
+    {
+      unsigned count[3] = {0, 0, 0};
+      Box bx[3];
+      for (size_t i = sp.num - 1; i > 0; i--)
+        for (int d = 0; d < 3; d++) {
+          count[d] += counts[i][d];
+          rCounts[i][d] = count[d];
+          bx[d].extend(bounds[i][d]);
+          rAreas[i][d] = half_area(bx[d]);
+        }
+    }
+    float best_sah[3] = {kInf, kInf, kInf};
+    int best_pos[3] = {0, 0, 0};
+    {
+      unsigned count[3] = {0, 0, 0};
+      Box bx[3];
+      for (size_t i = 1; i < sp.num; i++)
+        for (int d = 0; d < 3; d++) {
+          count[d] += counts[i - 1][d];
+          bx[d].extend(bounds[i - 1][d]);
+          const float lArea = half_area(bx[d]);
+          // counts in blocks of 8: BVH8VirtualSceneBuilderSAH passes sahBlockSize = 8 (bvh_builder_sah.cpp:509-513)
+          const float sah = lArea * float((count[d] + 7u) >> 3) + rAreas[i][d] * float((rCounts[i][d] + 7u) >> 3);
+          if (sah < best_sah[d]) best_pos[d] = int(i), best_sah[d] = sah;
+        }
+    }
+    for (int d = 0; d < 3; d++) {
+      if (sp.scale[d] == 0.0f) continue;  // mapping.invalid(dim)
+      if (best_sah[d] < sp.sah && best_pos[d] != 0) sp.dim = d, sp.pos = best_pos[d], sp.sah = best_sah[d];
+    }
+    return sp;
+  }
+  // HeuristicArrayBinningSAH::split (heuristic_binning_array_aligned.h:134-171): the array order inside the halves never
+  // reaches the tree (sets are re-binned; the fallback sorts first), so a stable partition stands for serial_partitioning
+  void split(const Split& sp, const Set& set, Set& l, Set& r) {
+    if (sp.dim < 0) {  // deterministic_order + performFallbackSplit (:49-64, :173-181): by ID, then the median
+      std::sort(prims.begin() + long(set.begin), prims.begin() + long(set.end), [](const PrimRef& a, const PrimRef& b) { return a.id < b.id; });
+      const size_t center = (set.begin + set.end) / 2;
+      l.begin = set.begin, l.end = center, r.begin = center, r.end = set.end;
+    } else {
+      auto mid = std::stable_partition(prims.begin() + long(set.begin), prims.begin() + long(set.end), [&](const PrimRef& p) { return sp.bin(p, sp.dim) < sp.pos; });
+      l.begin = set.begin, l.end = size_t(mid - prims.begin()), r.begin = l.end, r.end = set.end;
+    }
+    for (size_t i = l.begin; i < l.end; i++) l.add(prims[i]);
+    for (size_t i = r.begin; i < r.end; i++) r.add(prims[i]);
+  }
+  // GeneralBVHBuilder::BuilderT::recurse (bvh_builder_sah.h:220-330) with branchingFactor 8, minLeafSize = maxLeafSize = 1
+  int recurse(const Set& current, int depth) {
+    if (current.size() <= 1 || depth + 8 >= 40) {
+      if (current.size() != 1) throw std::runtime_error("embree order: large leaves are not restated");
+      return ~prims[current.begin].id;
+    }
+    Set children[8];
+    int n = 2;
+    split(find(current), current, children[0], children[1]);
+    while (n < 8) {
+      float best_area = -kInf;
+      int best = -1;
+      for (int i = 0; i < n; i++) {
+        if (children[i].size() <= 1) continue;
+        if (half_area(children[i].geom) > best_area) best = i, best_area = half_area(children[i].geom);
+      }
+      if (best < 0) break;
+      Set l, r;
+      split(find(children[best]), children[best], l, r);
+      children[best] = l;
+      children[n++] = r;
+    }
+    std::stable_sort(children, children + n, [](const Set& a, const Set& b) { return a.size() > b.size(); });  // std::sort of <= 8 records: an insertion sort
+    const int me = int(nodes.size());
+    nodes.emplace_back();
+    {
+      Node& nd = nodes[size_t(me)];
+      nd.n = n;
+      for (int i = 0; i < 8; i++) {
+        nd.child[i] = kEmpty;
+        for (int d = 0; d < 3; d++) nd.lo[d][i] = kInf, nd.hi[d][i] = -kInf;  // AABBNode::clear
+      }
+      for (int i = 0; i < n; i++)
+        for (int d = 0; d < 3; d++) nd.lo[d][i] = children[i].geom.lo[d], nd.hi[d][i] = children[i].geom.hi[d];
+    }
+    for (int i = 0; i < n; i++) {
+      const int c = recurse(children[i], depth + 1);
+      nodes[size_t(me)].child[i] = c;
+    }
+    return me;
+  }
+  // createPrimRefArray (kernels/common/scene_user_geometry.h:35-47, accelset.h:105-110): boxes that are not finite
+  // (|x| < FLT_LARGE = 1.844e18) or empty are left out of the hierarchy altogether
+  void build(const std::vector<std::pair<AABB, int>>& boxes) {
+    nodes.clear();
+    prims.clear();
+    root = kEmpty;
+    Set all;
+    for (auto& [b, id] : boxes) {
+      PrimRef p{{b.lower.x, b.lower.y, b.lower.z}, {b.upper.x, b.upper.y, b.upper.z}, id};
+      bool ok = true;
+      for (int d = 0; d < 3; d++) ok = ok && p.lo[d] > -1.844E18f && p.hi[d] < 1.844E18f && p.lo[d] <= p.hi[d];
+      if (!ok) continue;
+      prims.push_back(p);
+      all.add(p);
+    }
+    all.begin = 0, all.end = prims.size();
+    if (prims.empty()) return;
+    root = recurse(all, 1);
+  }
+};
+// BVHNIntersector1<8, BVH_AN1, false, ...>::intersect (kernels/bvh/bvh_intersector1.cpp:30-107): `leaf(geometry index)` is
+// the user callback; it reads and may shorten ray.tmax.
+template <class Leaf>
+inline void traverse(const Tree& tree, Ray& ray, Leaf&& leaf) {
+  if (tree.root == Tree::kEmpty) return;
+  // TravRay<8, false> (node_intersector1.h:26-60): rdir = rcp_safe(dir), org_rdir = org * rdir, near / far planes by the sign of rdir
+  const float org[3] = {ray.o.x, ray.o.y, ray.o.z}, dir[3] = {ray.d.x, ray.d.y, ray.d.z};
+  float rdir[3], org_rdir[3];
+  bool near_hi[3];
+  for (int d = 0; d < 3; d++) {
+    rdir[d] = rcp_safe(dir[d]);
+    org_rdir[d] = org[d] * rdir[d];
+    near_hi[d] = !(rdir[d] >= 0.0f);
+  }
+  const float tnear = std::max(ray.tmin, 0.0f);
+  float tfar = std::max(ray.tmax, 0.0f);
+  struct Item {
+    int ref;
+    uint32_t dist;
+  };
+  Item stack[1 + 7 * 40];
+  int sp = 1;
+  stack[0] = Item{tree.root, f2u(-kInf)};
+  auto as_int = [](float f) { return int32_t(f2u(f)); };
+  while (sp > 0) {
+    sp--;
+    int cur = stack[sp].ref;
+    if (u2f(stack[sp].dist) > ray.tmax) continue;  // (ray.tfar: the RayHit's own, updated by the callback)
+    bool popped = false;
+    while (cur >= 0) {
+      const Tree::Node& nd = tree.nodes[size_t(cur)];
+      // intersectNode<8> (node_intersector1.h:484-530, AVX2 without AVX-512): fused a * rdir - org_rdir, integer max / min
+      uint32_t dist[8];
+      unsigned mask = 0;
+      for (int i = 0; i < 8; i++) {
+        int32_t tn = as_int(tnear), tf = as_int(tfar);
+        for (int d = 0; d < 3; d++) {
+          const float lo = nd.lo[d][i], hi = nd.hi[d][i];
+          tn = std::max(tn, as_int(std::fmaf(near_hi[d] ? hi : lo, rdir[d], -org_rdir[d])));
+          tf = std::min(tf, as_int(std::fmaf(near_hi[d] ? lo : hi, rdir[d], -org_rdir[d])));
+        }
+        dist[i] = uint32_t(tn);
+        if (!(tn > tf)) mask |= 1u << i;
+      }
+      if (mask == 0) {
+        popped = true;
+        break;
+      }
+      // BVHNNodeTraverser1Hit<8>::traverseClosestHit (bvh_traverser1.h:310-385), children in ascending slot order
+      Item hits[8];
+      int nh = 0;
+      for (int i = 0; i < 8; i++)
+        if (mask & (1u << i)) hits[nh++] = Item{nd.child[i], dist[i]};
+      auto cmp_xchg = [](Item& a, Item& b) {  // stack_item.h:54-66: a <= b afterwards (signed compare of the distance words)
+        if (int32_t(b.dist) < int32_t(a.dist)) std::swap(a, b);
+      };
+      if (nh == 1) {
+        cur = hits[0].ref;
+      } else if (nh == 2) {
+        if (hits[0].dist < hits[1].dist) stack[sp++] = hits[1], cur = hits[0].ref;
+        else stack[sp++] = hits[0], cur = hits[1].ref;
+      } else if (nh == 3) {
+        Item &s0 = hits[0], &s1 = hits[1], &s2 = hits[2];
+        cmp_xchg(s1, s0), cmp_xchg(s2, s1), cmp_xchg(s1, s0);  // sort3
+        stack[sp++] = s0, stack[sp++] = s1, cur = s2.ref;
+      } else if (nh == 4) {
+        Item &s0 = hits[0], &s1 = hits[1], &s2 = hits[2], &s3 = hits[3];
+        cmp_xchg(s1, s0), cmp_xchg(s3, s2), cmp_xchg(s2, s0), cmp_xchg(s3, s1), cmp_xchg(s2, s1);  // sort4
+        stack[sp++] = s0, stack[sp++] = s1, stack[sp++] = s2, cur = s3.ref;
+      } else {
+        Item* first = stack + sp;
+        for (int i = 0; i < nh; i++) stack[sp++] = hits[i];
+        for (Item* i = first + 1; i != stack + sp; ++i) {  // sort(begin, end), stack_item.h:88-104: descending, stable
+          const Item item = *i;
+          Item* j = i;
+          while (j != first && (j - 1)->dist < item.dist) *j = *(j - 1), --j;
+          *j = item;
+        }
+        cur = stack[--sp].ref;
+      }
+    }
+    if (popped || cur == Tree::kEmpty) continue;
+    leaf(~cur);       // an Object leaf: the user callback, which may shorten ray.tmax (embree.cpp:24-40)
+    tfar = ray.tmax;  // tray.tfar = ray.tfar
+  }
+}
+}  // namespace embree_order
+
 struct Scene {
   NodeTable node_table;
   std::vector<Material> materials;
@@ -2248,6 +2547,7 @@ struct Scene {
   BVHImpl tbvh;
   std::vector<int> indices;
   std::vector<AABB> top_aabbs;  // the top-level primitives' boxes, in `indices` order (order mode "nearest")
+  embree_order::Tree etree;     // order mode "embree": Embree's BVH8 over the non-mesh shapes
 
   int find_material(const std::string& n) const {
     for (int i = int(material_names.size()) - 1; i >= 0; i--)  // map semantics: last add wins
@@ -2294,8 +2594,15 @@ struct Scene {
     top_aabbs.clear();
     for (auto& p : prims) top_aabbs.push_back(p.aabb);
     tbvh.build(prims);
+    {
+      std::vector<std::pair<AABB, int>> boxes;  // user primitives in geomID order (embree.cpp:113-117)
+      for (size_t i = 0; i < geometries.size(); i++)
+        if (geometries[i].kind != S_MESH) boxes.emplace_back(geometries[i].get_aabb(), int(i));
+      etree.build(boxes);
+    }
   }
   bool intersect_nearest(Ray& ray, SurfaceInteraction& it) const;
+  bool intersect_embree(Ray& ray, SurfaceInteraction& it) const;
   bool hit(Ray ray) const {  // BVH::hit :497-511
     if (geometries.empty()) return false;
     return tbvh.any_hit(ray, [&](const Ray& r, int li) {
@@ -2311,6 +2618,7 @@ struct Scene {
     if (geometries.empty()) return false;
     uint32_t geom_index = 0, prim_index = 0;
     if (g_order_mode == 1) return intersect_nearest(ray, it);
+    if (g_order_mode == 2) return intersect_embree(ray, it);
     bool hit = tbvh.closest(ray, [&](Ray& r, int li) {
       const Geometry& g = geometries[indices[li]];
       if (li < int(lbvh.size())) {
@@ -2389,6 +2697,39 @@ bool Scene::intersect_nearest(Ray& ray, SurfaceInteraction& it) const {
       hit = true;
     }
   }
+  if (hit) {
+    const Geometry& g = geometries[geom_index];
+    it.geom = int(geom_index);
+    if (g.kind == S_MESH) g.as<Mesh>().compute_surface_info(ray(), it, prim_index);
+    else g.compute_surface_info(ray(), it);
+  }
+  return hit;
+}
+
+// Order mode "embree": BVHNIntersector1<8, BVH_AN1, false, ...>::intersect (kernels/bvh/bvh_intersector1.cpp:30-107) over the
+// tree above.  Meshes are Embree triangle geometry with Embree's own intersector, which is NOT restated: they are tested first
+// (the triangle accel precedes the user-geometry accel, kernels/common/scene.cpp:741-755) through pine's triangle tests.
+bool Scene::intersect_embree(Ray& ray, SurfaceInteraction& it) const {
+  using namespace embree_order;
+  uint32_t geom_index = 0, prim_index = 0;
+  bool hit = false;
+  for (size_t li = 0; li < lbvh.size(); li++) {
+    const Mesh& mm = geometries[indices[li]].as<Mesh>();
+    if (lbvh[li]->closest(ray, [&](Ray& rr, int idx) {
+          bool hh = mm.intersect(rr, idx);
+          if (hh) prim_index = idx;
+          return hh;
+        }))
+      geom_index = indices[li], hit = true;
+  }
+  embree_order::traverse(etree, ray, [&](int gi) {
+    Ray r(ray.o, ray.d, ray.tmin, ray.tmax);  // (the callback builds its own Ray from Embree's, embree.cpp:31-33)
+    if (geometries[size_t(gi)].intersect(r)) {
+      ray.tmax = r.tmax;
+      geom_index = uint32_t(gi);
+      hit = true;
+    }
+  });
   if (hit) {
     const Geometry& g = geometries[geom_index];
     it.geom = int(geom_index);
@@ -3058,7 +3399,34 @@ extern "C" {
 
 const char* oracle_last_error(void) { return g_error.c_str(); }
 
-void oracle_set_order(int mode) { g_order_mode = mode == 1 ? 1 : 0; }
+// test hook (tests/test_embree_order.py, tools/embree_order_check.py): the order in which order mode "embree" calls the user callback for
+// one ray over n boxes (lower xyz, upper xyz each); hit_t[i] >= 0: primitive i reports a hit at that distance when it lies inside
+// (tnear, tfar).  -> number of calls (ids[0 .. cap) filled), *hit_id = closest primitive or -1, *tfar = final ray.tfar
+int oracle_embree_order(const float* boxes, int n, const float* ray8, const float* hit_t, int* ids, int cap, int* hit_id, float* tfar) {
+  std::vector<std::pair<AABB, int>> bx;
+  for (int i = 0; i < n; i++) bx.emplace_back(AABB(vec3(boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]), vec3(boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5])), i);
+  embree_order::Tree tree;
+  tree.build(bx);
+  if (getenv("PINE_ORACLE_EMBREE_DUMP")) {
+    for (size_t k = 0; k < tree.nodes.size(); k++) {
+      fprintf(stderr, "node %zu:", k);
+      for (int i = 0; i < tree.nodes[k].n; i++) fprintf(stderr, " %s%d", tree.nodes[k].child[i] < 0 ? "L" : "N", tree.nodes[k].child[i] < 0 ? ~tree.nodes[k].child[i] : tree.nodes[k].child[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+  Ray ray(vec3(ray8[0], ray8[1], ray8[2]), vec3(ray8[3], ray8[4], ray8[5]), ray8[6], ray8[7]);
+  int calls = 0;
+  *hit_id = -1;
+  embree_order::traverse(tree, ray, [&](int gi) {
+    if (calls < cap) ids[calls] = gi;
+    calls++;
+    const float t = hit_t[gi];
+    if (t >= 0.0f && t > ray.tmin && t < ray.tmax) ray.tmax = t, *hit_id = gi;
+  });
+  *tfar = ray.tmax;
+  return calls;
+}
+void oracle_set_order(int mode) { g_order_mode = mode == 1 || mode == 2 ? mode : 0; }
 void oracle_set_sampler(int kind) { g_sampler_kind = kind == SAMPLER_SOBOL ? SAMPLER_SOBOL : kind == SAMPLER_HALTON ? SAMPLER_HALTON : SAMPLER_BLUE; }
 
 int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth, int threads,

@@ -34,8 +34,11 @@ int oracle_render(const char* pscene, const uint8_t* tables, int spp, int depth,
  * (sampler.h:83-164), 2 = HaltonSampler(spp) (sampler.h:40-81); for the latter two spp is used as given.  Process-wide, not thread-safe: test use only. */
 void oracle_set_sampler(int kind);
 /* closest-hit primitive order: 0 = pine's BVH order (the parity oracle), 1 = nearest bounds first (SURVEY.md Appendix A3's second
- * order; what PINE_GPU_FLAG_ORDER_NEAREST does on the device) */
+ * order), 2 = the order of the reference's default accel, EmbreeAccel (restated from the vendored Embree's BVH8 builder and
+ * single-ray traverser) */
 void oracle_set_order(int mode);
+/* test hook: the order in which mode 2 calls the user callback for one ray over n boxes (see pine_oracle.cpp) */
+int oracle_embree_order(const float* boxes, int n, const float* ray8, const float* hit_t, int* ids, int cap, int* hit_id, float* tfar);
 
 /* Render only the pixels of this shard (8x8 tiles dealt round-robin, the product's multi-GPU
  * partition); film_out must be zero-initialised by the caller, other pixels are left untouched. */

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""usage (this container: needs oracle/_ref/embree_probe, see oracle/embree_probe.cpp): tools/embree_order_check.py [scenes] [rays]
+The order in which REAL Embree (the vendored 4.3.1, built here) calls the user callback against the order the restatement
+(oracle order mode "embree": builder + traverser) produces, ray by ray: random box sets of 1 .. 400 primitives, rays with and
+without reported hits.  Prints the number of rays whose call sequence, hit primitive or final tfar differ."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle  # noqa: E402
+
+PROBE = os.path.join(ROOT, "oracle", "_ref", "embree_probe")
+
+
+def hexf(a):
+    return " ".join(float(x).hex() for x in a)
+
+
+def case(rng, n, m):
+    kind = rng.integers(0, 3)
+    if kind == 0:    # scattered small boxes
+        c = rng.uniform(-1, 1, (n, 3)); e = rng.uniform(0.01, 0.3, (n, 3))
+    elif kind == 1:  # a grid (C4-like), flat boxes among them
+        g = int(np.ceil(np.sqrt(n)))
+        c = np.array([[-1 + 2 * (i % g) / g, 0, -1 + 2 * (i // g) / g] for i in range(n)]) + rng.uniform(-0.01, 0.01, (n, 3))
+        e = np.full((n, 3), 0.4 / g); e[::5, 1] = 0.0
+    else:            # cbox-like: big flat walls plus boxes
+        c = rng.uniform(-1, 1, (n, 3)); e = rng.uniform(0.0, 1.0, (n, 3)) * (rng.uniform(size=(n, 3)) < 0.7)
+    boxes = np.concatenate([c - e, c + e], axis=1).astype(np.float32)
+    o = rng.uniform(-2, 2, (m, 3)); t = rng.uniform(-1, 1, (m, 3)); d = t - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    if m > 4:
+        d[:m // 8, rng.integers(0, 3)] = 0.0  # axis-parallel rays (rcp_safe's clamp)
+        d[:m // 8] /= np.maximum(np.linalg.norm(d[:m // 8], axis=1, keepdims=True), 1e-9)
+    rays = np.concatenate([o, d, np.zeros((m, 1)), np.full((m, 1), 3.4028235e38)], axis=1).astype(np.float32)
+    rays[::3, 7] = rng.uniform(0.5, 4.0, len(rays[::3]))
+    hits = np.where(rng.uniform(size=(m, n)) < 0.5, rng.uniform(0.2, 4.0, (m, n)), -1.0).astype(np.float32)
+    hits[::4] = -1.0
+    return boxes, rays, hits
+
+
+def main():
+    scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    m = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    rng = np.random.default_rng(5)
+    lib = oracle.lib()
+    lib.oracle_embree_order.restype = C.c_int
+    bad = total = 0
+    for s in range(scenes):
+        n = int(rng.choice([1, 2, 3, 5, 8, 9, 10, 12, 16, 20, 33, 64, 100, 400]))
+        boxes, rays, hits = case(rng, n, m)
+        text = f"{n}\n" + "\n".join(hexf(b) for b in boxes) + f"\n{m}\n" + "\n".join(hexf(r) + " " + hexf(h) for r, h in zip(rays, hits)) + "\n"
+        out = subprocess.run([PROBE], input=text, capture_output=True, text=True, check=True).stdout.splitlines()
+        sbad = 0
+        for k in range(m):
+            seq, tail = out[k].split("|")
+            want = [int(x) for x in seq.split()]
+            wh, wt = tail.split()
+            ids = (C.c_int * (n + 8))()
+            hid = C.c_int(0)
+            tf = C.c_float(0)
+            cnt = lib.oracle_embree_order(boxes.ctypes.data_as(C.c_void_p), n, rays[k].ctypes.data_as(C.c_void_p), hits[k].ctypes.data_as(C.c_void_p), ids, n + 8, C.byref(hid), C.byref(tf))
+            got = list(ids[:min(cnt, n + 8)])
+            if got != want or hid.value != int(wh) or float(tf.value).hex() != float.fromhex(wt).hex():
+                if sbad == 0 and bad < 5:
+                    print(f"scene {s} n={n} ray {k}: embree {want} | {wh} {wt}   restated {got} | {hid.value} {float(tf.value).hex()}")
+                sbad += 1
+        bad += sbad
+        total += m
+        print(f"scene {s}: {n} primitives, {sbad} of {m} rays differ", flush=True)
+    print(f"{bad} of {total} rays differ")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

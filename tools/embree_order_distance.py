@@ -40,6 +40,6 @@ print("top-level primitives | order | identical-pixel share vs real EmbreeAccel 
 with tempfile.TemporaryDirectory() as tmp:
     for extra in (0, 1, 2, 4, 8, 12, 24, 40, 55):
         ps, film, _ = mg.ref_film(scene_with(extra, 7 + extra), 16, 5, tmp)
-        for order in ("nearest", "pine"):
+        for order in ("embree", "nearest", "pine"):
             o, _ = oracle.render(ps, (48, 48), 16, 5, order=order)
             print(f"{extra + 8:3d} | {order:7s} | {np.all(o == film, axis=-1).mean():.4f} | {np.sqrt(((o - film) ** 2).mean()):.4g}", flush=True)
