@@ -26,7 +26,7 @@ struct GpuPathIntegrator {
   // PathIntegrator(Accel, Sampler, LightSampler, int) (program_context.cpp:76-78).  The accel decides the ORDER closest hits are
   // found in, which one shape can see (the transformed Box, bbox.cpp:149-171): an Accel that holds an EmbreeAccel -- the only
   // one a .pine script can construct, and what the two-argument constructor of program_context.cpp:79-81 passes -- renders
-  // nearest bounds first (PINE_GPU_FLAG_ORDER_NEAREST: the films of the reference's EmbreeAccel, bit for bit); a BVH, in
+  // nearest bounds first (PINE_GPU_FLAG_ORDER_EMBREE: the films of the reference's EmbreeAccel, bit for bit); a BVH, in
   // pine-BVH order.  The light sampler has one alternative, UniformLightSampler: nothing to choose.
   GpuPathIntegrator(const Accel& accel, Sampler sampler_, LightSampler, int max_path_length)
       : GpuPathIntegrator(MOVE(sampler_), max_path_length) {
@@ -109,7 +109,7 @@ struct GpuPathIntegrator {
     auto* s = mirror(scene);
     auto& film = scene.camera.film();
     pine_gpu_render_params prm{sampler.spp(), max_path_length, /*device*/ 0, /*rank*/ 0, /*world*/ 1, 0,
-                               (specialize ? PINE_GPU_FLAG_SPECIALIZE : 0) | (order_nearest ? PINE_GPU_FLAG_ORDER_NEAREST : 0),
+                               (specialize ? PINE_GPU_FLAG_SPECIALIZE : 0) | (order_nearest ? PINE_GPU_FLAG_ORDER_EMBREE : 0),
                                sampler.is<SobolSampler>() ? PINE_GPU_SAMPLER_SOBOL : sampler.is<HaltonSampler>() ? PINE_GPU_SAMPLER_HALTON : PINE_GPU_SAMPLER_BLUE};
     // film.data() is Array2d<vec4>: W*H float4, row 0 first -- exactly the layout the ABI writes (array.h:51-55)
     const int rc = pine_gpu_path_render(s, &prm, &film.data()[0][0]);

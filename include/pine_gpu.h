@@ -264,15 +264,19 @@ typedef struct {
                                     background build of the default mode, but a build that fails is reported (plan stats:
                                     specialized == -1) instead of passing silently */
 #define PINE_GPU_FLAG_NO_SPECIALIZE 0x2000 /* the precompiled kernel table only: no cache lookup, no background compiler */
-#define PINE_GPU_FLAG_ORDER_NEAREST 0x4000 /* closest-hit queries test the scene's primitives NEAREST BOUNDS FIRST instead of in pine-BVH
-                                    order: the order of a nearest-first hierarchy with one primitive per leaf, which is what the reference's
-                                    EmbreeAccel is (src/pine/impl/accel/embree.cpp:101-143,195-257) -- the accel a .pine script gets from
-                                    PathIntegrator(sampler, n) on real pine (program_context.cpp:79-81).  It matters for ONE shape: the scaled
-                                    Box(AABB, mat4), whose intersect clips the object-space interval with the WORLD tmax
-                                    (src/pine/core/bbox.cpp:149-171) and so depends on what was tested before it.  With the flag the films of
-                                    the real reference built with EmbreeAccel are reproduced bit for bit on cbox (tests/golden/film_embree_*);
-                                    without it (the default, and the parity gate) those of Accel(BVH()).  Scenes without a scaled Box render
-                                    the same film either way.  At most 64 top-level primitives (a mesh counts as one); not with _FAST. */
+#define PINE_GPU_FLAG_ORDER_EMBREE 0x4000 /* closest-hit queries hand the scene's non-mesh shapes to their tests in the order of the reference's
+                                    DEFAULT accel, EmbreeAccel (src/pine/impl/accel/embree.cpp:101-143,195-257; what a .pine script's
+                                    PathIntegrator(sampler, n) gets on real pine, program_context.cpp:79-81), instead of pine-BVH order.  pine
+                                    registers every such shape as one Embree user primitive with pine's own bounds and intersect callbacks, so
+                                    Embree decides only the ORDER -- and pine has shapes whose answer depends on it: the scaled
+                                    Box(AABB, mat4) (src/pine/core/bbox.cpp:149-171), Plane's finite bounds, Line, Cylinder.  The order is
+                                    restated from the vendored Embree 4.3.1's BVH8 builder and single-ray traverser as an AVX2 x86 host runs
+                                    them (pine_amd/csrc/pine_embree_order.h, scene_traverse_embree); the films of the real reference built
+                                    with EmbreeAccel are reproduced bit for bit (tests/golden/film_embree_*, any number of shapes), without
+                                    the flag (the default, and the parity gate) those of Accel(BVH()).  Meshes are Embree's own triangle
+                                    geometry there, whose intersector is NOT restated: they are tested first, with pine's triangle tests.
+                                    Not with _FAST. */
+#define PINE_GPU_FLAG_ORDER_NEAREST PINE_GPU_FLAG_ORDER_EMBREE /* (the name of this flag before the order was Embree's own for any shape count) */
 #define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 
 /* Multi-GPU partition: rank that owns pixel (x, y) of a film_w-wide film when 8x8-pixel tiles are
@@ -406,6 +410,10 @@ int pine_gpu_test_atan(int device, const float* y_host, const float* x_host, int
  * then [count, words ...] (cap words) and hit of the any-hit query.  A test word is a top-level primitive's geometry index
  * or 0x40000000 | triangle index within the mesh entered last: the layout of `pine_ref bvh` (tests/golden/bvh_*.npz). */
 int pine_gpu_test_traverse(pine_gpu_scene*, int device, const float* rays_host, int64_t nrays, int flat, int cap, uint32_t* out_host);
+/* (flat = 2: the closest-hit query in EmbreeAccel's order, PINE_GPU_FLAG_ORDER_EMBREE: the geometry indices handed to their tests)
+ * ... and the hierarchy of that order over n boxes (6 floats each), HOST code only: the root's child word, then 8 child words per
+ * node in creation order (>= 0 a node, < 0 the complement of a box index, INT32_MIN unused).  -> words written, < 0 on failure. */
+int pine_gpu_test_embree_tree(const float* boxes, int n, int* words, int cap);
 /* ... and the BAKED traversal of a plan created with PINE_GPU_FLAG_SPECIALIZE (plan stats: specialized == 2) on the same kind of
  * rays: per ray 4 words -- hit, geometry, tmax bits of the closest-hit query, result of the any-hit query.  Must equal the
  * corresponding words of pine_gpu_test_traverse for every finite ray (tests/test_specialize.py: axis-parallel and grazing rays,

@@ -3407,13 +3407,6 @@ int oracle_embree_order(const float* boxes, int n, const float* ray8, const floa
   for (int i = 0; i < n; i++) bx.emplace_back(AABB(vec3(boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]), vec3(boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5])), i);
   embree_order::Tree tree;
   tree.build(bx);
-  if (getenv("PINE_ORACLE_EMBREE_DUMP")) {
-    for (size_t k = 0; k < tree.nodes.size(); k++) {
-      fprintf(stderr, "node %zu:", k);
-      for (int i = 0; i < tree.nodes[k].n; i++) fprintf(stderr, " %s%d", tree.nodes[k].child[i] < 0 ? "L" : "N", tree.nodes[k].child[i] < 0 ? ~tree.nodes[k].child[i] : tree.nodes[k].child[i]);
-      fprintf(stderr, "\n");
-    }
-  }
   Ray ray(vec3(ray8[0], ray8[1], ray8[2]), vec3(ray8[3], ray8[4], ray8[5]), ray8[6], ray8[7]);
   int calls = 0;
   *hit_id = -1;
@@ -3425,6 +3418,50 @@ int oracle_embree_order(const float* boxes, int n, const float* ray8, const floa
   });
   *tfar = ray.tmax;
   return calls;
+}
+// test hook: the hierarchy of order mode "embree" over n boxes, one line of 8 child words per node in creation order (>= 0 a node,
+// < 0 the complement of a box index, INT32_MIN unused), preceded by the root's child word -> words written, -1 when cap is too small
+int oracle_embree_tree(const float* boxes, int n, int* words, int cap) {
+  std::vector<std::pair<AABB, int>> bx;
+  for (int i = 0; i < n; i++) bx.emplace_back(AABB(vec3(boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]), vec3(boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5])), i);
+  embree_order::Tree tree;
+  tree.build(bx);
+  if (1 + 8 * int(tree.nodes.size()) > cap) return -1;
+  int k = 0;
+  words[k++] = tree.root;
+  for (auto& nd : tree.nodes)
+    for (int i = 0; i < 8; i++) words[k++] = nd.child[i];
+  return k;
+}
+// test hook: the closest-hit query of order mode "embree" on a scene, ray by ray: per ray cap + 3 words -- [count, the geometry
+// indices handed to their tests in order ...] (cap words), hit, geometry, tmax bits (meshes: their word only)
+int oracle_embree_traverse(const char* pscene, const float* rays, int64_t nrays, int cap, uint32_t* out) {
+  Scene scene;
+  if (!parse_pscene(pscene, scene)) return 2;
+  scene.build_accel();
+  for (int64_t i = 0; i < nrays; i++) {
+    const float* q = rays + i * 8;
+    uint32_t* o = out + i * (cap + 3);
+    Ray ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
+    int n = 0, hit_geom = -1;
+    for (size_t li = 0; li < scene.lbvh.size(); li++) {
+      if (1 + n < cap) o[1 + n] = uint32_t(scene.indices[li]);
+      n++;
+      const Mesh& mm = scene.geometries[size_t(scene.indices[li])].as<Mesh>();
+      if (scene.lbvh[li]->closest(ray, [&](Ray& rr, int idx) { return mm.intersect(rr, idx); })) hit_geom = scene.indices[li];
+    }
+    embree_order::traverse(scene.etree, ray, [&](int gi) {
+      if (1 + n < cap) o[1 + n] = uint32_t(gi);
+      n++;
+      Ray r(ray.o, ray.d, ray.tmin, ray.tmax);
+      if (scene.geometries[size_t(gi)].intersect(r)) ray.tmax = r.tmax, hit_geom = gi;
+    });
+    o[0] = uint32_t(n);
+    o[cap] = hit_geom >= 0 ? 1u : 0u;
+    o[cap + 1] = hit_geom >= 0 ? uint32_t(hit_geom) : 0u;
+    o[cap + 2] = embree_order::f2u(ray.tmax);
+  }
+  return 0;
 }
 void oracle_set_order(int mode) { g_order_mode = mode == 1 || mode == 2 ? mode : 0; }
 void oracle_set_sampler(int kind) { g_sampler_kind = kind == SAMPLER_SOBOL ? SAMPLER_SOBOL : kind == SAMPLER_HALTON ? SAMPLER_HALTON : SAMPLER_BLUE; }

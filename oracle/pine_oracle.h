@@ -39,6 +39,9 @@ void oracle_set_sampler(int kind);
 void oracle_set_order(int mode);
 /* test hook: the order in which mode 2 calls the user callback for one ray over n boxes (see pine_oracle.cpp) */
 int oracle_embree_order(const float* boxes, int n, const float* ray8, const float* hit_t, int* ids, int cap, int* hit_id, float* tfar);
+/* ... that hierarchy itself (root word, then 8 child words per node), and the closest-hit query of mode 2 on a scene's rays */
+int oracle_embree_tree(const float* boxes, int n, int* words, int cap);
+int oracle_embree_traverse(const char* pscene, const float* rays, int64_t nrays, int cap, uint32_t* out);
 
 /* Render only the pixels of this shard (8x8 tiles dealt round-robin, the product's multi-GPU
  * partition); film_out must be zero-initialised by the caller, other pixels are left untouched. */

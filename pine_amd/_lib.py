@@ -73,7 +73,8 @@ FLAG_SPECIALIZE = 0x400
 FLAG_SPECIALIZE_NO_BAKE = 0x800
 FLAG_SPECIALIZE_ASYNC = 0x1000
 FLAG_NO_SPECIALIZE = 0x2000
-FLAG_ORDER_NEAREST = 0x4000
+FLAG_ORDER_EMBREE = 0x4000
+FLAG_ORDER_NEAREST = FLAG_ORDER_EMBREE  # (former name)
 
 # every symbol include/pine_gpu.h declares, with its signature
 SIGNATURES = {
@@ -171,6 +172,7 @@ SIGNATURES = {
     "pine_gpu_test_sincos": (C.c_int, [C.c_int, c_f_p, C.c_int64, c_f_p, c_f_p]),
     "pine_gpu_test_powlog": (C.c_int, [C.c_int, c_f_p, c_f_p, C.c_int64, c_f_p, c_f_p]),
     "pine_gpu_test_atan": (C.c_int, [C.c_int, c_f_p, c_f_p, C.c_int64, c_f_p, c_f_p]),
+    "pine_gpu_test_embree_tree": (C.c_int, [c_f_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "pine_gpu_test_traverse": (C.c_int, [C.c_void_p, C.c_int, c_f_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "pine_gpu_scene_accel_bvhs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64]),
     "pine_gpu_test_shapes": (C.c_int, [C.c_void_p, C.c_int, c_f_p, C.c_int64, c_f_p, C.c_int64]),

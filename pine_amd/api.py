@@ -560,9 +560,9 @@ def _specialize_flags(specialize):
 def _order_flags(order):
     if order in (None, "pine", "bvh"):
         return 0
-    if order in ("nearest", "embree"):
-        return _lib.FLAG_ORDER_NEAREST
-    raise PineError(f"unknown traversal order {order!r} (pine | nearest)")
+    if order in ("embree", "nearest"):  # ("nearest": this order's former name)
+        return _lib.FLAG_ORDER_EMBREE
+    raise PineError(f"unknown traversal order {order!r} (pine | embree)")
 
 
 class Plan:
@@ -574,8 +574,8 @@ class Plan:
         specialize: None -- the library's default: the scene's own kernel from the cache, else compiled in the background
         while the precompiled kernel renders; True -- PINE_GPU_FLAG_SPECIALIZE: wait for the compiler at plan creation, fail if
         the kernel cannot be built; False -- PINE_GPU_FLAG_NO_SPECIALIZE: precompiled kernels only (stats().specialized tells).
-        order: "pine" -- closest hits in pine-BVH order, Accel(BVH()) (the default and the parity gate); "nearest" / "embree" --
-        PINE_GPU_FLAG_ORDER_NEAREST: nearest bounds first, the order of the reference's EmbreeAccel (scaled boxes appear as under it)."""
+        order: "pine" -- closest hits in pine-BVH order, Accel(BVH()) (the default and the parity gate); "embree" --
+        PINE_GPU_FLAG_ORDER_EMBREE: the order of the reference's default accel, EmbreeAccel (order-dependent shapes appear as under it)."""
         flags = int(flags) | _specialize_flags(specialize) | _order_flags(order)
         if scene.camera is None:
             raise PineError("scene has no camera")
@@ -651,7 +651,7 @@ class PathIntegrator:
         """devices: a list of HIP device ordinals -- the film is rendered by all of them from this one process
         (pine_gpu_path_render_devices); default: the single `device`.
         specialize: None / True / False as for Plan (the scene's own kernel: automatic / required / never; same film).
-        order: "pine" (Accel(BVH()), the default) or "nearest" / "embree" (PINE_GPU_FLAG_ORDER_NEAREST: what EmbreeAccel does)."""
+        order: "pine" (Accel(BVH()), the default) or "embree" (PINE_GPU_FLAG_ORDER_EMBREE: what the reference's EmbreeAccel does)."""
         flags = int(flags) | _specialize_flags(specialize) | _order_flags(order)
         if max_path_length <= 0:  # path.cpp:12-13
             raise PineError(f"`PathIntegrator` expect `max_path_length` to be positive, get {max_path_length}")

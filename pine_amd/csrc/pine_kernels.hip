@@ -53,6 +53,8 @@ SceneHost& scene_host(pine_gpu_scene* s);
 }  // namespace pine_gpu
 #include "pine_kernels_device.h"
 #include "pine_bvh_build_device.h"
+#include "pine_embree_order.h"
+#include "../data/rcpps_table.h"
 namespace pine_gpu {
 
 // ---- the BVH build on the device: host orchestration (one decide / scan / split triple per level) ----
@@ -282,9 +284,11 @@ __global__ void test_rng_kernel(unsigned long long* out) {
 // (FLAT = false: scene_traverse / mesh_traverse) or the flat state machine of the F_LDS_TOP variants (pine_trav.h).
 // One thread per ray, 64 per block; out: per ray `cap` words closest (count, words...), 4 result words (hit, geometry,
 // triangle, tmax bits), `cap` words any-hit, 1 result word.
-template <bool FLAT>
+// (MODE 2: the closest-hit query in EmbreeAccel's order, PINE_GPU_FLAG_ORDER_EMBREE; the any-hit query is the nested loops')
+template <int MODE>
 __global__ void __launch_bounds__(64) test_traverse_kernel(DeviceScene S, const float* rays, long long nrays, int cap, unsigned* out) {
-  constexpr unsigned F = FLAT ? (F_ALL | F_LDS_TOP) : F_ALL;
+  constexpr bool FLAT = MODE == 1;
+  constexpr unsigned F = FLAT ? (F_ALL | F_LDS_TOP) : MODE == 2 ? (F_ALL | F_NEAREST) : F_ALL;
   using StackT = typename std::conditional<FLAT, unsigned short, int>::type;
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   StackT* const stack = reinterpret_cast<StackT*>(lds_raw) + threadIdx.x;
@@ -294,7 +298,9 @@ __global__ void __launch_bounds__(64) test_traverse_kernel(DeviceScene S, const 
   V.stack_top = S.stack_top, V.num_shapes = S.num_shapes;
   V.leaf = S.leaf, V.nodes = S.nodes, V.shapes = S.shapes, V.materials = S.materials, V.bvhs = S.bvhs, V.prims = nullptr;
   V.lights = S.lights, V.node_ops = S.node_ops;
-  V.top_boxes = nullptr, V.num_top = 0;
+  V.etree = reinterpret_cast<const EmbreeNode*>(reinterpret_cast<const char*>(S.blob) + S.off_etree), V.etree_root = S.etree_root;
+  V.emesh = reinterpret_cast<const int*>(reinterpret_cast<const char*>(S.blob) + S.off_emesh), V.num_emesh = S.num_emesh;
+  V.rcpps = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(S.blob) + S.off_rcpps);
   const long long i = blockIdx.x * 64ll + threadIdx.x;
   const bool live = i < nrays;
   const float* q = rays + (live ? i : 0) * 8;
@@ -1248,39 +1254,51 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   std::vector<DLight> light_list = H.lights;  // + the environment light last (lightsampler.cpp:6-10)
   if (H.has_env) light_list.push_back(H.env);
   S.off_lights = put(light_list.data(), light_list.size() * sizeof(DLight));
-  // PINE_GPU_FLAG_ORDER_NEAREST: the top-level primitives' boxes in the reference's listing order, each with its place in `leaf`
-  const bool order_nearest = (prm->flags & PINE_GPU_FLAG_ORDER_NEAREST) != 0;
-  S.off_top_boxes = 0;
-  S.num_top = 0;
+  // PINE_GPU_FLAG_ORDER_EMBREE: the hierarchy EmbreeAccel walks over the non-mesh shapes (pine_embree_order.h), the meshes' places
+  // in `leaf` (tested first), and -- behind the part of the blob that scene-in-LDS variants copy -- the RCPPS estimates
+  const bool order_nearest = (prm->flags & PINE_GPU_FLAG_ORDER_EMBREE) != 0;
+  S.off_etree = S.off_emesh = S.off_rcpps = 0;
+  S.etree_root = kEmbreeNoChild;
+  S.num_emesh = 0;
   if (order_nearest) {
-    constexpr int kNearestMaxPrims = 64;
-    const int ntop = int(A.top_boxes.size() / 8);
-    if (ntop > kNearestMaxPrims) {
-      set_error("PINE_GPU_FLAG_ORDER_NEAREST: the scene has " + std::to_string(ntop) + " top-level primitives; the nearest-bounds-first order is "
-                "implemented for at most 64 (a mesh counts as one)");
-      return -1;
-    }
     if (prm->flags & (PINE_GPU_FLAG_FAST | PINE_GPU_FLAG_VERTEX_LOG)) {
-      set_error("PINE_GPU_FLAG_ORDER_NEAREST cannot be combined with PINE_GPU_FLAG_FAST / _VERTEX_LOG");
+      set_error("PINE_GPU_FLAG_ORDER_EMBREE cannot be combined with PINE_GPU_FLAG_FAST / _VERTEX_LOG");
       return -1;
     }
-    std::vector<float> boxes = A.top_boxes;
-    for (int t = 0; t < ntop; t++) {
+    const int ntop = int(A.top_boxes.size() / 8);
+    std::vector<float> boxes;
+    std::vector<int> places, mesh_places;
+    for (int t = 0; t < ntop; t++) {  // (FlatAccel::top_boxes: the meshes first, then the other shapes, each in geometry order)
+      const float* r = &A.top_boxes[size_t(t) * 8];
       int geom, place = -1;
-      memcpy(&geom, &boxes[size_t(t) * 8 + 3], 4);
+      memcpy(&geom, &r[3], 4);
       for (size_t i = size_t(A.top_prim_begin); i < A.prims.size(); i++)
         if (A.prims[i] == geom) place = int(i);
       if (place < 0) {
         set_error("internal: a top-level primitive without a leaf entry");
         return -1;
       }
-      memcpy(&boxes[size_t(t) * 8 + 3], &place, 4);
+      if (shapes[size_t(geom)].kind == SHAPE_MESH) {
+        mesh_places.push_back(place);
+      } else {
+        boxes.insert(boxes.end(), {r[0], r[1], r[2], r[4], r[5], r[6]});
+        places.push_back(place);
+      }
     }
-    S.off_top_boxes = put(boxes.data(), boxes.size() * sizeof(float));
-    S.num_top = ntop;
+    EmbreeOrderTree tree;
+    std::string why;
+    if (!tree.build(boxes, places, why)) {
+      set_error("PINE_GPU_FLAG_ORDER_EMBREE: " + why);
+      return -1;
+    }
+    S.etree_root = tree.root;
+    S.off_etree = put(tree.nodes.data(), tree.nodes.size() * sizeof(EmbreeNode));
+    S.num_emesh = int(mesh_places.size());
+    S.off_emesh = put(mesh_places.data(), mesh_places.size() * sizeof(int));
   }
   blob.resize((blob.size() + 15) & ~size_t(15));
   S.blob_bytes = int(blob.size());
+  if (order_nearest) S.off_rcpps = put(kRcppsTable, sizeof(kRcppsTable));  // (global memory only: blob_bytes is what LDS variants stage)
   HIP_OK(POOL_ALLOC(p->d_blob, blob.size()));
   HIP_OK(hipMemcpy(p->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (upload(p->d_tri, A.tri_verts)) return -1;
@@ -2354,6 +2372,30 @@ int pine_gpu_test_rng(int device, uint64_t* out, int64_t capacity) {
   hipFree(d);
   return 0;
 }
+int pine_gpu_test_embree_tree(const float* boxes, int n, int* words, int cap) {
+  if (!boxes || !words || n < 0) {
+    set_error("bad argument");
+    return -1;
+  }
+  std::vector<float> bx(boxes, boxes + 6 * size_t(n));
+  std::vector<int> places(size_t(n), 0);
+  for (int i = 0; i < n; i++) places[size_t(i)] = i;
+  EmbreeOrderTree tree;
+  std::string why;
+  if (!tree.build(bx, places, why)) {
+    set_error(why);
+    return -1;
+  }
+  if (1 + 8 * int(tree.nodes.size()) > cap) {
+    set_error("capacity");
+    return -1;
+  }
+  int k = 0;
+  words[k++] = tree.root;
+  for (const EmbreeNode& nd : tree.nodes)
+    for (int i = 0; i < 8; i++) words[k++] = nd.child[i];
+  return k;
+}
 int pine_gpu_test_traverse(pine_gpu_scene* scene, int device, const float* rays, int64_t nrays, int flat, int cap, uint32_t* out) {
   if (!scene || !rays || !out || cap < 2 || nrays < 0) {
     set_error("bad argument");
@@ -2363,6 +2405,7 @@ int pine_gpu_test_traverse(pine_gpu_scene* scene, int device, const float* rays,
   // the scene as the kernels see it: a plan's device records (nothing is rendered)
   pine_gpu_render_params prm{};
   prm.spp = 1, prm.max_path_length = 2, prm.device = device, prm.shard_rank = 0, prm.shard_world = 1;
+  prm.flags = PINE_GPU_FLAG_NO_SPECIALIZE | (flat == 2 ? PINE_GPU_FLAG_ORDER_EMBREE : 0);
   pine_gpu_plan* p = pine_gpu_plan_create(scene, &prm);
   if (!p) return -1;
   int rc = -1;
@@ -2370,16 +2413,17 @@ int pine_gpu_test_traverse(pine_gpu_scene* scene, int device, const float* rays,
   unsigned* dout = nullptr;
   const size_t words = size_t(nrays) * (2 * size_t(cap) + 5);
   do {
-    if (flat && p->S.stack_total > 0 && scene_host(scene).accel.nodes.size() > 65535) {
+    if (flat == 1 && p->S.stack_total > 0 && scene_host(scene).accel.nodes.size() > 65535) {
       set_error("the flat traversal keeps 16-bit node ids");
       break;
     }
     if (hipMalloc((void**)&dr, std::max<int64_t>(nrays, 1) * 32) != hipSuccess || hipMalloc((void**)&dout, std::max<size_t>(words, 1) * 4) != hipSuccess) break;
     if (hipMemcpy(dr, rays, nrays * 32, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dout, 0, std::max<size_t>(words, 1) * 4) != hipSuccess) break;
-    const size_t lds = size_t(std::max(1, p->S.stack_total)) * 64 * (flat ? sizeof(unsigned short) : sizeof(int));
+    const size_t lds = size_t(std::max(1, p->S.stack_total)) * 64 * (flat == 1 ? sizeof(unsigned short) : sizeof(int));
     if (nrays > 0) {
-      if (flat) hipLaunchKernelGGL(test_traverse_kernel<true>, dim3(unsigned((nrays + 63) / 64)), dim3(64), lds, 0, p->S, dr, (long long)nrays, cap, dout);
-      else hipLaunchKernelGGL(test_traverse_kernel<false>, dim3(unsigned((nrays + 63) / 64)), dim3(64), lds, 0, p->S, dr, (long long)nrays, cap, dout);
+      if (flat == 1) hipLaunchKernelGGL(test_traverse_kernel<1>, dim3(unsigned((nrays + 63) / 64)), dim3(64), lds, 0, p->S, dr, (long long)nrays, cap, dout);
+      else if (flat == 2) hipLaunchKernelGGL(test_traverse_kernel<2>, dim3(unsigned((nrays + 63) / 64)), dim3(64), lds, 0, p->S, dr, (long long)nrays, cap, dout);
+      else hipLaunchKernelGGL(test_traverse_kernel<0>, dim3(unsigned((nrays + 63) / 64)), dim3(64), lds, 0, p->S, dr, (long long)nrays, cap, dout);
     }
     if (hipMemcpy(out, dout, words * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
     rc = 0;

@@ -94,11 +94,25 @@ struct DeviceScene {
   const uint4* tri_packets;   // entries (tri_packet_entries x 8 bytes, padded to 16), then vertices (x 16 bytes)
   int tri_packet_entries, tri_packet_verts;
   int lds_tris;               // 1: every workgroup copies the packets to LDS and the traversal reads them there
-  // PINE_GPU_FLAG_ORDER_NEAREST (F_NEAREST variants): the top-level primitives' own bounding boxes, in the order the reference
-  // lists them (bvh.cpp:453-495: meshes first, then the other shapes, each in geometry order): two float4 per primitive --
-  // lower | its entry in `leaf`, upper | 0 -- at off_top_boxes of the blob; num_top of them (0: the mode is off)
-  int off_top_boxes, num_top;
+  // PINE_GPU_FLAG_ORDER_EMBREE (F_NEAREST variants): the BVH8 the reference's EmbreeAccel walks over the non-mesh shapes
+  // (pine_embree_order.h) -- EmbreeNode records at off_etree of the blob, the root's child word (kEmbreeNoChild: no such
+  // shape) -- the places in `leaf` of the meshes (num_emesh ints at off_emesh; tested first) and the 2048 RCPPS estimates
+  // (off_rcpps: BEHIND blob_bytes, global memory only)
+  int off_etree, etree_root, off_emesh, num_emesh, off_rcpps;
 };
+
+// One node of that BVH8 as the device reads it: 16 quads.  Planes of the eight children per axis, then the child words:
+// >= 0 a node, < 0 the complement of a primitive's place in SceneView::leaf, kEmbreeNoChild for an unused slot
+// (whose planes are +inf / -inf: no ray enters it -- AABBNode::clear, vendored embree kernels/bvh/bvh_node_aabb.h:97-101).
+struct EmbreeNode {
+  float lo[3][8];
+  float hi[3][8];
+  int child[8];
+  int count, pad[7];
+};
+static_assert(sizeof(EmbreeNode) == 256, "EmbreeNode is read as 16 quads");
+constexpr int kEmbreeNoChild = -2147483647 - 1;
+constexpr int kEmbreeStackEntries = 96;  // per-ray stack of scene_traverse_embree (the host checks the tree against it)
 
 // What the traversal and shading code reads.  In the F_LDS_SCENE specialisation every pointer is
 // derived from the workgroup's LDS copy of the blob (so the loads are ds_read, ~64-cycle latency,
@@ -125,8 +139,12 @@ struct SceneView {
   int lds_node_count;
   const uint2* lds_tri_entries;   // DeviceScene::tri_packets in LDS (null: triangles are read from tri_leaf)
   const float4* lds_tri_verts;
-  const float4* top_boxes;        // F_NEAREST variants: DeviceScene::off_top_boxes (null otherwise)
-  int num_top;
+  // F_NEAREST variants (PINE_GPU_FLAG_ORDER_EMBREE): DeviceScene::off_etree / etree_root / off_emesh / off_rcpps
+  const EmbreeNode* etree;
+  int etree_root;
+  const int* emesh;
+  int num_emesh;
+  const unsigned* rcpps;
 };
 
 // One BVH node into registers.  F_LDS_TOP: from the workgroup's LDS copy when the index is below the cached
@@ -294,36 +312,33 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
   return hit;
 }
 
-// Order mode "nearest" (PINE_GPU_FLAG_ORDER_NEAREST, F_NEAREST variants; SURVEY.md Appendix A3's second traversal order):
-// closest-hit queries test the top-level primitives in the order of their OWN bounding boxes' entry distances (ties: the
-// reference's listing order), and stop at the first box that is entered beyond the closest hit so far.  That is the order a
-// nearest-first traversal of a bounding-volume hierarchy with one primitive per leaf produces whatever the hierarchy's shape --
-// the reference's EmbreeAccel is one (embree.cpp:101-143: one user primitive per shape; Embree's object leaves hold one
-// primitive, children are visited in tNear order) -- so the one order-dependent shape, the scaled Box(AABB, mat4)
-// (bbox.cpp:149-171), is tested before a farther wall has shortened ray.tmax, as under Embree: the golden films of the real
-// reference built with EmbreeAccel are reproduced bit for bit (tests/test_gpu_parity.py).  No hierarchy is walked: every
-// round scans the boxes for the next one in (entry distance, index) order -- O(primitives x tests), which is why the mode is
-// limited to 64 top-level primitives (a mesh counts as one; its own BVH keeps pine's order -- triangles are not order
-// dependent).  Any-hit queries are order independent and stay with the BVH.
+// PINE_GPU_FLAG_ORDER_EMBREE (F_NEAREST variants): closest-hit queries hand the non-mesh shapes to their tests in the order the
+// reference's DEFAULT accel does -- BVHNIntersector1<8, BVH_AN1, false, ...>::intersect of the vendored Embree 4.3.1
+// (src/contrib/embree/kernels/bvh/bvh_intersector1.cpp:30-107) over the BVH8 of pine_embree_order.h, as an AVX2 x86 host runs it:
+//   * the ray: rdir = rcp_safe(dir) -- one fused Newton step on the RCPPS estimate (common/math/vec3fa.h:122-172; the estimates
+//     are the table of pine_amd/data/rcpps_table.h) -- and org_rdir = org * rdir (kernels/bvh/node_intersector1.h:26-60);
+//   * a node: per child fused plane * rdir - org_rdir, maximum / minimum over the float words compared as INTEGERS, entered when
+//     not tNear > tFar (node_intersector1.h:484-530);
+//   * its hit children, in slot order: one -> descend; two -> the nearer first (equal: the second); three / four -> the sorting
+//     networks of common/stack_item.h:54-84; more -> the stable descending insertion sort (:88-104); the nearest is descended
+//     into, the others wait on the stack with their distances (kernels/bvh/bvh_traverser1.h:310-385);
+//   * a popped entry whose distance lies beyond the closest hit so far is dropped (bvh_intersector1.cpp:77-79).
+// Meshes are Embree triangle geometry with Embree's own intersector, which is not restated: they are tested FIRST (the
+// triangle accel precedes the user-geometry accel, kernels/common/scene.cpp:741-755) with pine's triangle tests.  Any-hit
+// queries are order independent and stay with pine's BVH.  tests/test_embree_order.py, tests/test_gpu_parity.py: the films of
+// the real reference built with EmbreeAccel, bit for bit.
+__device__ __forceinline__ float embree_rcp_safe(const unsigned* table, float a) {
+  if (fabsf(a) < 1e-18f) a = 1e-18f;  // zero_fix: min_rcp_input
+  const unsigned u = __float_as_uint(a);
+  const unsigned t = table[(u >> 12) & 0x7ffu];  // the estimate for the mantissa in [1, 2): in (0.5, 1]
+  const float r = __uint_as_float((u & 0x80000000u) | ((((t >> 23) & 0xffu) + 127u - ((u >> 23) & 0xffu)) << 23) | (t & 0x7fffffu));
+  return __fmaf_rn(r, __fmaf_rn(-a, r, 1.0f), r);
+}
 template <unsigned F, int STRIDE, class StackT>
-__device__ __forceinline__ bool scene_traverse_nearest(const SceneView& S, DRay& ray, StackT* stack, int& geom_out, int& prim_out, TravLog* log) {
-  const DRayOct oct = make_oct(ray);
-  float last_t = -1.0f;  // (entry distances are >= tmin >= 0)
-  int last_i = -1;
+__device__ __forceinline__ bool scene_traverse_embree(const SceneView& S, DRay& ray, StackT* stack, int& geom_out, int& prim_out, TravLog* log) {
   bool hit = false;
-  for (int round = 0; round < S.num_top; round++) {
-    float best_t = 0.0f;
-    int best_i = -1;
-    for (int i = 0; i < S.num_top; i++) {
-      const float4 a = S.top_boxes[2 * i], b = S.top_boxes[2 * i + 1];
-      float tn;
-      if (!box_entry_oct(&a.x, &b.x, oct, ray.tmin, ray.tmax, tn)) continue;
-      const bool after = tn > last_t || (tn == last_t && i > last_i);
-      if (after && (best_i < 0 || tn < best_t)) best_t = tn, best_i = i;  // (strict <: among equal distances the first index)
-    }
-    if (best_i < 0) break;
-    last_t = best_t, last_i = best_i;
-    const DShape* sh = &S.leaf[__float_as_int(S.top_boxes[2 * best_i].w)];
+  auto test_leaf = [&](int place) {
+    const DShape* sh = &S.leaf[place];
     DShape rec;
     {
       const uint4* src = reinterpret_cast<const uint4*>(sh);
@@ -339,6 +354,7 @@ __device__ __forceinline__ bool scene_traverse_nearest(const SceneView& S, DRay&
     if (log) log->put(unsigned(word & kPrimIndexMask));
     if (is_mesh) {
       if constexpr (F & F_MESH) {
+        const DRayOct oct = make_oct(ray);
         int prim = 0;
         if (mesh_traverse<false, STRIDE, F>(S, S.bvhs[as_int(sh->f[2])], ray, oct, stack, S.stack_top, prim, log)) {
           hit = true;
@@ -350,6 +366,69 @@ __device__ __forceinline__ bool scene_traverse_nearest(const SceneView& S, DRay&
       hit = true;
       geom_out = word;
     }
+  };
+  if constexpr (F & F_MESH)
+    for (int k = 0; k < S.num_emesh; k++) test_leaf(S.emesh[k]);
+  if (S.etree_root == kEmbreeNoChild) return hit;
+  const float rdx = embree_rcp_safe(S.rcpps, ray.d.x), rdy = embree_rcp_safe(S.rcpps, ray.d.y), rdz = embree_rcp_safe(S.rcpps, ray.d.z);
+  const float ordx = ray.o.x * rdx, ordy = ray.o.y * rdy, ordz = ray.o.z * rdz;
+  // (near plane: the lower one where rdir >= 0)
+  const int nx = rdx >= 0.0f ? 0 : 24, ny = rdy >= 0.0f ? 0 : 24, nz = rdz >= 0.0f ? 0 : 24;
+  const int tnear = __float_as_int(fmaxf(ray.tmin, 0.0f));
+  int tfar = __float_as_int(fmaxf(ray.tmax, 0.0f));
+  int2 items[kEmbreeStackEntries];  // (child word, distance word)
+  int sp = 1;
+  items[0] = int2{S.etree_root, int(0xff800000u)};  // (distance -inf)
+  while (sp > 0) {
+    sp--;
+    int cur = items[sp].x;
+    if (__int_as_float(items[sp].y) > ray.tmax) continue;
+    bool dropped = false;
+    while (cur >= 0) {
+      const float* nd = reinterpret_cast<const float*>(&S.etree[cur]);
+      const int count = reinterpret_cast<const int*>(nd)[56];
+      const int first = sp;
+      for (int i = 0; i < count; i++) {  // (unused slots are never entered: their planes are infinite)
+        const int tn = max(max(__float_as_int(__fmaf_rn(nd[nx + i], rdx, -ordx)), __float_as_int(__fmaf_rn(nd[8 + ny + i], rdy, -ordy))),
+                           max(__float_as_int(__fmaf_rn(nd[16 + nz + i], rdz, -ordz)), tnear));
+        const int tf = min(min(__float_as_int(__fmaf_rn(nd[(nx ^ 24) + i], rdx, -ordx)), __float_as_int(__fmaf_rn(nd[8 + (ny ^ 24) + i], rdy, -ordy))),
+                           min(__float_as_int(__fmaf_rn(nd[16 + (nz ^ 24) + i], rdz, -ordz)), tfar));
+        if (!(tn > tf)) items[sp++] = int2{reinterpret_cast<const int*>(nd)[48 + i], tn};
+      }
+      const int hits = sp - first;
+      if (hits == 0) {
+        dropped = true;
+        break;
+      }
+      auto order = [&](int a, int b) {  // cmp_xchg: items[a] <= items[b] afterwards
+        if (items[b].y < items[a].y) {
+          const int2 t = items[a];
+          items[a] = items[b], items[b] = t;
+        }
+      };
+      int2* h = items + first;
+      if (hits == 2) {
+        if (unsigned(h[0].y) < unsigned(h[1].y)) {
+          const int2 t = h[0];
+          h[0] = h[1], h[1] = t;
+        }
+      } else if (hits == 3) {
+        order(first + 1, first), order(first + 2, first + 1), order(first + 1, first);
+      } else if (hits == 4) {
+        order(first + 1, first), order(first + 3, first + 2), order(first + 2, first), order(first + 3, first + 1), order(first + 2, first + 1);
+      } else if (hits > 4) {
+        for (int i = 1; i < hits; i++) {
+          const int2 item = h[i];
+          int j = i;
+          while (j > 0 && unsigned(h[j - 1].y) < unsigned(item.y)) h[j] = h[j - 1], j--;
+          h[j] = item;
+        }
+      }
+      cur = items[--sp].x;  // the nearest; the others wait
+    }
+    if (dropped) continue;
+    test_leaf(~cur);  // an Object leaf: the user callback (embree.cpp:24-40)
+    tfar = __float_as_int(ray.tmax);
   }
   return hit;
 }
@@ -361,7 +440,7 @@ template <bool ANY, unsigned F, int STRIDE = kBlock, class StackT = int>
 __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, StackT* stack, int& geom_out,
                                                int& prim_out, TravLog* log = nullptr) {
   if (S.num_shapes == 0) return false;
-  if constexpr ((F & F_NEAREST) != 0 && !ANY) return scene_traverse_nearest<F, STRIDE>(S, ray, stack, geom_out, prim_out, log);
+  if constexpr ((F & F_NEAREST) != 0 && !ANY) return scene_traverse_embree<F, STRIDE>(S, ray, stack, geom_out, prim_out, log);
   const DRayOct oct = make_oct(ray);
   const DBvh top = S.bvhs[0];
   bool hit = false;
@@ -641,7 +720,9 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
   V.lds_tri_verts = nullptr;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
-  V.num_top = S.num_top;
+  V.etree_root = S.etree_root;
+  V.num_emesh = S.num_emesh;
+  V.rcpps = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(S.blob) + S.off_rcpps);
   if constexpr (F & F_LDS_SCENE) {
     uint4* dst = reinterpret_cast<uint4*>(lds_raw + kOffStack + S.stack_total * kBlock);
     const int n16 = S.blob_bytes >> 4;
@@ -656,10 +737,12 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
-    V.top_boxes = reinterpret_cast<const float4*>(base + S.off_top_boxes);
+    V.etree = reinterpret_cast<const EmbreeNode*>(base + S.off_etree);
+    V.emesh = reinterpret_cast<const int*>(base + S.off_emesh);
   } else {
     __syncthreads();  // Sobol rows staged above
-    V.top_boxes = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.blob) + S.off_top_boxes);
+    V.etree = reinterpret_cast<const EmbreeNode*>(reinterpret_cast<const char*>(S.blob) + S.off_etree);
+    V.emesh = reinterpret_cast<const int*>(reinterpret_cast<const char*>(S.blob) + S.off_emesh);
     V.leaf = S.leaf;
     V.nodes = S.nodes;
     V.shapes = S.shapes;

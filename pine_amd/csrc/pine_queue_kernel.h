@@ -171,8 +171,12 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
   V.lds_tri_verts = nullptr;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
-  V.num_top = S.num_top;
-  V.top_boxes = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.blob) + S.off_top_boxes);  // (F_NEAREST variants read it)
+  // (F_NEAREST variants read these; the hierarchy and the mesh list move with the blob when it is staged in LDS)
+  V.etree_root = S.etree_root;
+  V.num_emesh = S.num_emesh;
+  V.rcpps = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(S.blob) + S.off_rcpps);
+  V.etree = reinterpret_cast<const EmbreeNode*>(reinterpret_cast<const char*>(S.blob) + S.off_etree);
+  V.emesh = reinterpret_cast<const int*>(reinterpret_cast<const char*>(S.blob) + S.off_emesh);
   char* lds_after_stack = nullptr;
   if constexpr (F & F_LDS_TOP) {
     size_t stack_bytes = size_t(S.stack_total) * kQBlock * sizeof(StackT);
@@ -212,7 +216,8 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
-    V.top_boxes = reinterpret_cast<const float4*>(base + S.off_top_boxes);
+    V.etree = reinterpret_cast<const EmbreeNode*>(base + S.off_etree);
+    V.emesh = reinterpret_cast<const int*>(base + S.off_emesh);
   } else if constexpr (F & F_LDS_REST) {
     // blob = nodes | shapes | materials | node programs | bvhs | leaf records | lights: everything after the nodes
     size_t stack_bytes = size_t(S.stack_total) * kQBlock * sizeof(StackT);
@@ -230,7 +235,8 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
     V.lights = reinterpret_cast<const DLight*>(base + S.off_lights);
     V.node_ops = reinterpret_cast<const DNodeOp*>(base + S.off_node_ops);
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
-    V.top_boxes = reinterpret_cast<const float4*>(base + S.off_top_boxes);
+    V.etree = reinterpret_cast<const EmbreeNode*>(base + S.off_etree);
+    V.emesh = reinterpret_cast<const int*>(base + S.off_emesh);
   } else {
     V.leaf = S.leaf;
     V.nodes = S.nodes;

@@ -235,12 +235,14 @@ class PathIntegrator {
   // The scene's own path kernel (same film; pine_gpu.h): by default the library uses it when it is in its cache and compiles it
   // in the background otherwise.  specialize(true): wait for the compiler at render() and fail if the kernel cannot be built
   // (PINE_GPU_FLAG_SPECIALIZE); specialize(false): precompiled kernels only (PINE_GPU_FLAG_NO_SPECIALIZE).
-  // closest hits nearest bounds first -- the order of the reference's EmbreeAccel (PINE_GPU_FLAG_ORDER_NEAREST) -- instead of
-  // pine-BVH order (the default: Accel(BVH())); only a scene with a scaled Box(AABB, mat4) shows the difference
-  PathIntegrator& order_nearest(bool on = true) {
-    flags_ = on ? (flags_ | PINE_GPU_FLAG_ORDER_NEAREST) : (flags_ & ~PINE_GPU_FLAG_ORDER_NEAREST);
+  // closest hits in the order of the reference's default accel, EmbreeAccel (PINE_GPU_FLAG_ORDER_EMBREE), instead of pine-BVH
+  // order (the default: Accel(BVH())); only scenes with order-dependent shapes -- a scaled Box(AABB, mat4), Plane, Line,
+  // Cylinder -- show the difference
+  PathIntegrator& order_embree(bool on = true) {
+    flags_ = on ? (flags_ | PINE_GPU_FLAG_ORDER_EMBREE) : (flags_ & ~PINE_GPU_FLAG_ORDER_EMBREE);
     return *this;
   }
+  PathIntegrator& order_nearest(bool on = true) { return order_embree(on); }  // (former name)
   PathIntegrator& specialize(bool on = true) {
     flags_ &= ~(PINE_GPU_FLAG_SPECIALIZE | PINE_GPU_FLAG_NO_SPECIALIZE);
     flags_ |= on ? PINE_GPU_FLAG_SPECIALIZE : PINE_GPU_FLAG_NO_SPECIALIZE;

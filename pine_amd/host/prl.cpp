@@ -155,7 +155,7 @@ struct LightObj : Object {
 };
 struct IntegratorObj : Object {
   int spp = 0, depth = 0, sampler = 0;
-  int accel = 0;  // 0: the two-argument constructor's default; 1: Accel(BVH()) -- pine-BVH order; 2: Accel(Embree()) -- nearest bounds first
+  int accel = 0;  // 0: the two-argument constructor's default; 1: Accel(BVH()) -- pine-BVH order; 2: Accel(Embree()) -- EmbreeAccel's order
 };
 
 static Value mk_i32(int v) {
@@ -1893,9 +1893,9 @@ Interp::Interp() {
   // Accel / LightSampler and the four-argument constructor (program_context.cpp:47-52, 76-78).  The reference registers
   // `BVH()` and `Embree()` but lets only Embree convert to Accel (ctor_variant<EmbreeAccel>), so a script on real pine can
   // write PathIntegrator(Embree(), sampler, UniformLightSampler(), n) and nothing else; here BVH() converts as well (an
-  // extension: the explicit way to ask for pine-BVH order).  Embree() selects PINE_GPU_FLAG_ORDER_NEAREST -- closest hits
-  // nearest bounds first, which reproduces the EmbreeAccel films of the real reference bit for bit on cbox
-  // (tests/golden/film_embree_*); BVH() selects pine-BVH order, the parity oracle's.
+  // extension: the explicit way to ask for pine-BVH order).  Embree() selects PINE_GPU_FLAG_ORDER_EMBREE -- EmbreeAccel's own
+  // order, which reproduces the EmbreeAccel films of the real reference bit for bit (tests/golden/film_embree_*); BVH()
+  // selects pine-BVH order, the parity oracle's.
   r.def("BVH", {}, "BVH", [](Interp&, std::vector<Cell>&) { return retype(mk_i32(1), "BVH"); });
   r.def("Embree", {}, "Embree", [](Interp&, std::vector<Cell>&) { return retype(mk_i32(2), "Embree"); });
   r.convert("Embree", "Accel", [](const Value& v) { return retype(v, "Accel"); });
@@ -1938,13 +1938,15 @@ Interp::Interp() {
     prm.shard_rank = 0;
     prm.shard_world = 1;
     prm.sampler = p->sampler;
-    // The accel decides the ORDER closest hits are found in, which only the transformed Box(AABB, mat4) can see
-    // (bbox.cpp:149-171).  Embree(): nearest bounds first, as EmbreeAccel.  BVH(): pine-BVH order.  The two-argument
-    // constructor is `PathIntegrator(EmbreeAccel(), sampler, UniformLightSampler(), n)` in the reference
-    // (program_context.cpp:79-81), so a script that uses it -- scenes/cbox.pine does -- gets what it gets from real pine:
-    // nearest bounds first, wherever that order is implemented and reproduces it (at most 64 top-level primitives, no meshes);
-    // other scenes render in pine-BVH order and, if they have a transformed Box, say so once.  $PINE_PRL_ACCEL=bvh | embree (pine-mi355x --accel) decides
-    // for the two-argument form explicitly.
+    // The accel decides the ORDER closest hits are found in, which a few shapes can see (the scaled Box(AABB, mat4),
+    // bbox.cpp:149-171; Plane's finite bounds, Line, Cylinder).  Embree(): the order of the reference's EmbreeAccel, restated
+    // from the vendored Embree (PINE_GPU_FLAG_ORDER_EMBREE).  BVH(): pine-BVH order.  The two-argument constructor is
+    // `PathIntegrator(EmbreeAccel(), sampler, UniformLightSampler(), n)` in the reference (program_context.cpp:79-81), so a
+    // script that uses it -- scenes/cbox.pine does -- gets what it gets from real pine: EmbreeAccel's order, for every scene
+    // without meshes.  A scene WITH meshes renders in pine-BVH order: under real Embree a mesh's triangles go through Embree's
+    // own intersector, which nothing here restates, so there is no EmbreeAccel image to reproduce -- and the fixtures of the glTF
+    // import are the reference's BVH renders; if such a scene also has a transformed Box it says so once.
+    // $PINE_PRL_ACCEL=bvh | embree (pine-mi355x --accel) decides for the two-argument form explicitly.
     int accel = p->accel;
     if (accel == 0) {
       const char* e = getenv("PINE_PRL_ACCEL");
@@ -1952,23 +1954,18 @@ Interp::Interp() {
       else if (e && std::string(e) == "bvh") accel = 1;
       else {
         const std::string text = describe_scene(s->h);
-        size_t shapes = 0;
-        for (size_t at = text.find("shape "); at != std::string::npos; at = text.find("\nshape ", at + 1)) shapes++;
-        // (a scene with meshes keeps pine-BVH order: under real Embree a mesh's triangles go through Embree's own intersector,
-        //  which nothing here restates, so there is no EmbreeAccel image to reproduce -- and the fixtures of the glTF import are
-        //  the reference's BVH renders)
         const bool meshes = text.find("shape mesh") != std::string::npos;
-        accel = shapes <= 64 && !meshes ? 2 : 1;
+        accel = meshes ? 1 : 2;
         static bool said = false;
         if (accel == 1 && !said && text.find("shape obb ") != std::string::npos) {
           said = true;
           fprintf(stderr, "[pine-mi355x] note: this scene has a transformed Box(AABB, mat4), whose image depends on the accel's test order, and "
-                          "%s: PathIntegrator(sampler, n) renders it in pine-BVH order (Accel(BVH())), not in the nearest-bounds-first order "
-                          "of real pine's default EmbreeAccel.\n", meshes ? "meshes" : "more than 64 top-level primitives");
+                          "meshes: PathIntegrator(sampler, n) renders it in pine-BVH order (Accel(BVH())), not in the order of real pine's "
+                          "default EmbreeAccel.\n");
         }
       }
     }
-    if (accel == 2) prm.flags |= PINE_GPU_FLAG_ORDER_NEAREST;
+    if (accel == 2) prm.flags |= PINE_GPU_FLAG_ORDER_EMBREE;
     f->pixels.assign(size_t(f->w) * f->h * 4, 0.0f);
     // $PINE_GPU_DEVICES = "0,1,2,...": render on those devices of the node from this one process (pine-mi355x --devices)
     std::vector<int> devices;

@@ -41,6 +41,24 @@ def cbox(size=(640, 640), camera="committed", boxes=True, lamp=True):
     return scene
 
 
+def cbox_clutter(size=(48, 48), extra=24, seed=31):
+    """cbox (README camera) plus `extra` random primitives of the kinds whose image depends on the accel's test order --
+    rotated + scaled Boxes, Spheres, scaled Boxes (bbox.cpp:149-171): what separates pine-BVH order from EmbreeAccel's once a
+    scene has more primitives than one BVH8 node (tools/embree_order_distance.py, tests/golden/film_embree_clutter*)."""
+    rng = np.random.default_rng(seed)
+    scene = cbox(size, "readme")
+    for i in range(extra):
+        c = rng.uniform([-0.8, 0.1, 0.3], [0.8, 1.6, 1.8]).tolist()
+        if i % 3 == 0:
+            scene.add(Box(AABB([0, 0, 0], [1, 1, 1]),
+                          translate(c) * rotate_y(float(rng.uniform(-1, 1))) * scale(rng.uniform(0.1, 0.35, 3).tolist())), "floor")
+        elif i % 3 == 1:
+            scene.add(Sphere(c, float(rng.uniform(0.05, 0.2))), "red")
+        else:
+            scene.add(Box(AABB([0, 0, 0], [1, 1, 1]), translate(c) * scale(rng.uniform(0.1, 0.3, 3).tolist())), "green")
+    return scene
+
+
 def classic_cones(size=(720, 360), n=100, with_spheres=True, checker_floor=False):
     """Config C4: scenes/classic.pine:4-18 materials/shapes, plus n x n procedurally
     placed cones Cone([x,0,z], Y, 0.05, 0.05).  checker_floor=True keeps the script's node-graph floor

@@ -55,6 +55,24 @@ def film_distance(a, b):
 
 EMBREE_FILM_NAMES = ["embree_cbox_committed_64_s16_d4", "embree_cbox_readme_64_s16_d4", "embree_cbox_readme_64_s256_d8",
                      "embree_cbox_rect_readme_64_s64_d5"]
+# ... and films of the same build on scenes with more primitives than one BVH8 node, with the other order-dependent shapes
+# (Plane's finite bounds, Line, Cylinder), with many primitives: what PINE_GPU_FLAG_ORDER_EMBREE must render bit for bit
+EMBREE_MORE_FILM_NAMES = ["embree_clutter20_48_s16_d5", "embree_clutter63_48_s16_d5", "embree_xshapes_48_s16_d5",
+                          "embree_lights_zoo_48_s16_d6", "embree_classic_cones12_90x45_s16_d6"]
+
+
+def embree_scene(name):
+    """The scene a tests/golden/film_embree_* fixture was rendered from (tools/make_golden.py EMBREE_FILMS)."""
+    from pine_amd import scenes
+    return {"embree_cbox_readme_64_s16_d4": lambda: scenes.cbox((64, 64), "readme"),
+            "embree_cbox_committed_64_s16_d4": lambda: scenes.cbox((64, 64), "committed"),
+            "embree_cbox_readme_64_s256_d8": lambda: scenes.cbox((64, 64), "readme"),
+            "embree_cbox_rect_readme_64_s64_d5": lambda: scenes.cbox((64, 64), "readme", False),
+            "embree_clutter20_48_s16_d5": lambda: scenes.cbox_clutter((48, 48), 12, 19),
+            "embree_clutter63_48_s16_d5": lambda: scenes.cbox_clutter((48, 48), 55, 62),
+            "embree_xshapes_48_s16_d5": lambda: scenes.xshapes_zoo((48, 48)),
+            "embree_lights_zoo_48_s16_d6": lambda: scenes.lights_zoo((48, 48)),
+            "embree_classic_cones12_90x45_s16_d6": lambda: scenes.classic_cones((90, 45), 12)}[name]()
 # What separates pine's own BVH order (reproduced here bit for bit) from EmbreeAccel (the `.pine` default) on each of
 # those films: measured once with the two real reference builds (tools/make_golden.py --embree; DESIGN.md 1).  The
 # Rect-only scene has no order-dependent shape: the two accels agree to the last bit.

@@ -872,32 +872,31 @@ def test_device_bvh_build_produces_the_host_tree(oracle):
     assert_bit_equal(f, ref, "render on the device-built BVH")
 
 
-# ---- PINE_GPU_FLAG_ORDER_NEAREST (SURVEY.md Appendix A3's second traversal order) -----------------------------------------
-@pytest.mark.parametrize("name", ["embree_cbox_readme_64_s16_d4", "embree_cbox_committed_64_s16_d4", "embree_cbox_readme_64_s256_d8",
-                                  "embree_cbox_rect_readme_64_s64_d5"])
-def test_nearest_order_renders_the_embree_reference_films(name, path_kernel):
-    """With PINE_GPU_FLAG_ORDER_NEAREST the device tests a ray's primitives nearest bounds first -- the order of the reference's
-    EmbreeAccel, the accel a .pine script gets on real pine -- and renders the films of the REAL reference built with EmbreeAccel
-    (tests/golden/film_embree_*, tools/make_golden.py --embree) bit for bit, scaled boxes included; both path kernels."""
-    from pine_amd import scenes
+# ---- PINE_GPU_FLAG_ORDER_EMBREE (SURVEY.md Appendix A3's second traversal order: the reference's default accel's) ---------------
+from conftest import EMBREE_FILM_NAMES, EMBREE_MORE_FILM_NAMES, embree_scene  # noqa: E402
+
+
+@pytest.mark.parametrize("name", EMBREE_FILM_NAMES + EMBREE_MORE_FILM_NAMES)
+def test_embree_order_renders_the_embree_reference_films(name, path_kernel):
+    """With PINE_GPU_FLAG_ORDER_EMBREE the device hands a ray's shapes to their tests in the order of the reference's EmbreeAccel,
+    the accel a .pine script gets on real pine -- the vendored Embree's BVH8 builder and single-ray traverser restated -- and renders
+    the films of the REAL reference built with EmbreeAccel (tests/golden/film_embree_*, tools/make_golden.py --embree) bit for bit:
+    scaled boxes, planes, lines and cylinders, 8 to 155 primitives; both path kernels."""
     emb, ps, spp, depth = load_film(name)
-    sc = {"embree_cbox_readme_64_s16_d4": lambda: scenes.cbox((64, 64), "readme"),
-          "embree_cbox_committed_64_s16_d4": lambda: scenes.cbox((64, 64), "committed"),
-          "embree_cbox_readme_64_s256_d8": lambda: scenes.cbox((64, 64), "readme"),
-          "embree_cbox_rect_readme_64_s64_d5": lambda: scenes.cbox((64, 64), "readme", False)}[name]()
+    sc = embree_scene(name)
     assert sc.describe() == ps
-    film, st = _render(sc, spp, depth, order="nearest", specialize=False)
+    film, st = _render(sc, spp, depth, order="embree", specialize=False)
     assert st.kernel_features & (1 << 18), hex(st.kernel_features)  # F_NEAREST: a variant of the order mode ran
-    assert_bit_equal(film, emb, f"PINE_GPU_FLAG_ORDER_NEAREST vs O-gcc-embree, {name}")
-    if "rect" not in name:
+    assert_bit_equal(film, emb, f"PINE_GPU_FLAG_ORDER_EMBREE vs O-gcc-embree, {name}")
+    if "rect" not in name and "cones" not in name:
         pine_order, _ = _render(sc, spp, depth, specialize=False)
-        assert (pine_order.view(np.uint32) != film.view(np.uint32)).any(), "the two orders must differ on a scene with scaled boxes"
+        assert (pine_order.view(np.uint32) != film.view(np.uint32)).any(), "the two orders must differ on a scene with order-dependent shapes"
 
 
-def test_nearest_order_equals_the_oracle_on_other_scenes(oracle, path_kernel):
-    """... and equals the CPU restatement's nearest-bounds-first order on scenes beyond cbox: random rooms of every shape kind
-    (transformed boxes among them), every material and light, meshes (whose own BVH keeps pine's order) -- through the run-time
-    compiled feature-set kernel as well as the precompiled twins."""
+def test_embree_order_equals_the_oracle_on_other_scenes(oracle, path_kernel):
+    """... and equals the CPU restatement's order on scenes beyond the fixtures: random rooms of every shape kind (transformed
+    boxes among them), every material and light, meshes (tested first, with pine's triangle tests) -- through the run-time compiled
+    feature-set kernel as well as the precompiled twins -- and a scene of hundreds of primitives (the order mode has no size limit)."""
     from pine_amd import scenes
     done = 0
     for seed in (3003, 3007, 3011, 3019, 3021, 3030):
@@ -905,26 +904,28 @@ def test_nearest_order_equals_the_oracle_on_other_scenes(oracle, path_kernel):
         if sampler != "blue":
             continue
         w, h = sc.camera.film().size
-        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth, order="nearest")
-        film, st = _render(sc, spp, depth, order="nearest", specialize=False)
-        assert_bit_equal(film, ref, f"nearest order, random scene {seed}")
+        ref, _ = oracle.render(sc.describe(), (w, h), spp, depth, order="embree")
+        film, st = _render(sc, spp, depth, order="embree", specialize=False)
+        assert_bit_equal(film, ref, f"embree order, random scene {seed}")
         if path_kernel == "queue" and done == 0:
-            film2, st2 = _render(sc, spp, depth, order="nearest", specialize=True)
-            assert_bit_equal(film2, ref, f"nearest order, scene-specialised kernel, random scene {seed}")
+            film2, st2 = _render(sc, spp, depth, order="embree", specialize=True)
+            assert_bit_equal(film2, ref, f"embree order, scene-specialised kernel, random scene {seed}")
             assert st2.specialized in (0, 1)  # (never baked: a baked scene is pine's order as code)
         done += 1
     assert done >= 3
-    sc = scenes.sss((40, 40), 1)  # one Subsurface mesh in a room: the mesh is ONE top-level primitive
-    ref, _ = oracle.render(sc.describe(), (40, 40), 16, 6, order="nearest")
-    film, _ = _render(sc, 16, 6, order="nearest")
-    assert_bit_equal(film, ref, "nearest order, mesh scene")
+    sc = scenes.sss((40, 40), 1)  # one Subsurface mesh in a room
+    ref, _ = oracle.render(sc.describe(), (40, 40), 16, 6, order="embree")
+    film, _ = _render(sc, 16, 6, order="embree")
+    assert_bit_equal(film, ref, "embree order, mesh scene")
+    sc = scenes.classic_cones((96, 48), 20)  # 405 primitives
+    ref, _ = oracle.render(sc.describe(), (96, 48), 8, 5, order="embree")
+    film, _ = _render(sc, 8, 5, order="embree", specialize=False)
+    assert_bit_equal(film, ref, "embree order, 405 primitives")
 
 
-def test_nearest_order_has_a_size_limit_and_says_so():
+def test_the_order_argument_is_checked():
     import pine_amd as pa
     from pine_amd import scenes
-    with pytest.raises(pa.PineError, match="at most 64"):
-        pa.Plan(scenes.classic_cones((64, 32), 9), 4, 3, order="nearest")
     with pytest.raises(pa.PineError, match="unknown traversal order"):
         pa.Plan(scenes.cbox((32, 32)), 4, 3, order="sideways")
 

@@ -317,7 +317,7 @@ def test_lights_script_render_equals_oracle(oracle):
                                    'world.set(ThinLenCamera(Film([80, 60]), [0, 0.5, -5], [0, 0, 0], 0.5)); PathIntegrator(BlueSampler(16), 5).render(world);')
     ps, spp, depth = prl.scene_of_dry_run(prl.interpret(src, dry_run=True))
     prl.interpret(src)
-    ref, _ = oracle.render(ps, (80, 60), spp, depth, order="nearest")  # (two-argument PathIntegrator: the reference's default accel)
+    ref, _ = oracle.render(ps, (80, 60), spp, depth, order="embree")  # (two-argument PathIntegrator: the reference's default accel)
     assert_bit_equal(prl.last_film(), ref, "lights script through the front-end vs oracle")
 
 
@@ -352,8 +352,8 @@ def test_script_render_equals_oracle_of_the_scene_it_built(oracle):
     prl.interpret(src)
     film = prl.last_film()
     assert film is not None and film.shape == (56, 72, 4)
-    # (the two-argument PathIntegrator is PathIntegrator(EmbreeAccel(), ...) in the reference: nearest bounds first)
-    ref, _ = oracle.render(ps, (72, 56), spp, depth, order="nearest")
+    # (the two-argument PathIntegrator is PathIntegrator(EmbreeAccel(), ...) in the reference: EmbreeAccel's order)
+    ref, _ = oracle.render(ps, (72, 56), spp, depth, order="embree")
     assert_bit_equal(film, ref, "front-end render vs oracle of the same scene description")
 
 
@@ -371,14 +371,14 @@ def test_example_scripts_render_equal_the_oracle(oracle, script, save, sampler):
     prl.interpret(src)
     film = prl.last_film()
     assert film is not None and film.shape == (96, 96, 4)
-    ref, _ = oracle.render(ps, (96, 96), spp, depth, sampler=sampler, order="nearest")  # (two-argument PathIntegrator: the reference's default accel)
+    ref, _ = oracle.render(ps, (96, 96), spp, depth, sampler=sampler, order="embree")  # (two-argument PathIntegrator: the reference's default accel)
     assert_bit_equal(film, ref, script)
 
 
 def test_accel_and_light_sampler_names_of_the_reference():
     """program_context.cpp:47-52, 76-78: `BVH()`, `Embree()`, `Accel`, `UniformLightSampler()`, `LightSampler` and the
-    four-argument PathIntegrator a script on real pine can write; Embree() selects the nearest-bounds-first order (what
-    EmbreeAccel does), BVH() pine-BVH order; the two-argument form is unchanged."""
+    four-argument PathIntegrator a script on real pine can write; Embree() selects EmbreeAccel's own order, BVH() pine-BVH order; the
+    two-argument form is unchanged."""
     from pine_amd import prl
     src = _cornell((64, 64), 8, 4)
     four = src.replace("PathIntegrator(BlueSampler(spp), depth)", "PathIntegrator(Embree(), BlueSampler(spp), UniformLightSampler(), depth)")
@@ -396,24 +396,24 @@ def test_accel_and_light_sampler_names_of_the_reference():
 
 
 @pytest.mark.gpu
-def test_script_with_the_embree_accel_renders_the_nearest_order_film(oracle, monkeypatch):
-    """A script that names its accel: Embree() -> the film of the nearest-bounds-first order (== the real reference's
-    EmbreeAccel film on this scene class, tests/test_gpu_parity.py), BVH() -> pine-BVH order; the two-argument constructor is the
+def test_script_with_the_embree_accel_renders_the_embree_order_film(oracle, monkeypatch):
+    """A script that names its accel: Embree() -> the film of EmbreeAccel's order (== the real reference's EmbreeAccel film,
+    tests/test_gpu_parity.py), BVH() -> pine-BVH order; the two-argument constructor is the
     reference's PathIntegrator(EmbreeAccel(), ...) and renders like Embree(); $PINE_PRL_ACCEL=bvh moves it to pine-BVH order."""
     from pine_amd import prl
     src = _cornell((48, 40), 16, 4).replace('world.camera.film().save("cornell.png");', "")
     ps, spp, depth = prl.scene_of_dry_run(prl.interpret(src, dry_run=True))
-    near, _ = oracle.render(ps, (48, 40), spp, depth, order="nearest")
+    near, _ = oracle.render(ps, (48, 40), spp, depth, order="embree")
     pine, _ = oracle.render(ps, (48, 40), spp, depth)
     assert (near.view(np.uint32) != pine.view(np.uint32)).any()
     four = src.replace("PathIntegrator(BlueSampler(spp), depth)", "PathIntegrator(Embree(), BlueSampler(spp), UniformLightSampler(), depth)")
     prl.interpret(four)
-    assert_bit_equal(prl.last_film(), near, "PathIntegrator(Embree(), ...) vs the oracle's nearest order")
+    assert_bit_equal(prl.last_film(), near, "PathIntegrator(Embree(), ...) vs the oracle's embree order")
     prl.interpret(four.replace("Embree()", "BVH()"))
     assert_bit_equal(prl.last_film(), pine, "PathIntegrator(BVH(), ...) vs the oracle")
     monkeypatch.delenv("PINE_PRL_ACCEL", raising=False)
     prl.interpret(src)
-    assert_bit_equal(prl.last_film(), near, "PathIntegrator(sampler, n) vs the oracle's nearest order (the reference's default accel)")
+    assert_bit_equal(prl.last_film(), near, "PathIntegrator(sampler, n) vs the oracle's embree order (the reference's default accel)")
     monkeypatch.setenv("PINE_PRL_ACCEL", "bvh")
     prl.interpret(src)
     assert_bit_equal(prl.last_film(), pine, "PathIntegrator(sampler, n) with PINE_PRL_ACCEL=bvh")

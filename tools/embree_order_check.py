@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""usage (this container: needs oracle/_ref/embree_probe, see oracle/embree_probe.cpp): tools/embree_order_check.py [scenes] [rays]
+"""usage (this container: needs oracle/_ref/embree_probe, see oracle/embree_probe.cpp; `make -C oracle embree probe`):
+  tools/embree_order_check.py [scenes] [rays]     compare, print the count of differing rays
+  tools/embree_order_check.py --fixture           (re)write tests/golden/embree_order.npz: 14 box sets x 48 rays with REAL Embree's answers
 The order in which REAL Embree (the vendored 4.3.1, built here) calls the user callback against the order the restatement
 (oracle order mode "embree": builder + traverser) produces, ray by ray: random box sets of 1 .. 400 primitives, rays with and
 without reported hits.  Prints the number of rays whose call sequence, hit primitive or final tfar differ."""
@@ -44,7 +46,40 @@ def case(rng, n, m):
     return boxes, rays, hits
 
 
+def probe(boxes, rays, hits):
+    n, m = len(boxes), len(rays)
+    text = f"{n}\n" + "\n".join(hexf(b) for b in boxes) + f"\n{m}\n" + "\n".join(hexf(r) + " " + hexf(h) for r, h in zip(rays, hits)) + "\n"
+    out = subprocess.run([PROBE], input=text, capture_output=True, text=True, check=True).stdout.splitlines()
+    seqs, res = [], []
+    for k in range(m):
+        seq, tail = out[k].split("|")
+        wh, wt = tail.split()
+        seqs.append([int(x) for x in seq.split()])
+        res.append((int(wh), np.float32(float.fromhex(wt))))
+    return seqs, res
+
+
+def fixture():
+    rng = np.random.default_rng(11)
+    data = {}
+    for c, n in enumerate([1, 2, 3, 5, 8, 9, 10, 12, 16, 20, 33, 64, 100, 400]):
+        boxes, rays, hits = case(rng, n, 48)
+        seqs, res = probe(boxes, rays, hits)
+        flat = np.full((48, n + 1), -1, np.int32)
+        for k, sq in enumerate(seqs):
+            flat[k, 0] = len(sq)
+            flat[k, 1:1 + len(sq)] = sq
+        data[f"boxes{c}"], data[f"rays{c}"], data[f"hits{c}"], data[f"calls{c}"] = boxes, rays, hits, flat
+        data[f"hit{c}"] = np.array([r[0] for r in res], np.int32)
+        data[f"tfar{c}"] = np.array([r[1] for r in res], np.float32)
+    path = os.path.join(ROOT, "tests", "golden", "embree_order.npz")
+    np.savez_compressed(path, **data)
+    print(path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--fixture" in sys.argv:
+        return fixture()
     scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     rng = np.random.default_rng(5)

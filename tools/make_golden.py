@@ -149,6 +149,12 @@ EMBREE_FILMS = {
     "embree_cbox_readme_64_s16_d4": (lambda: scenes.cbox((64, 64), "readme"), 16, 4),
     "embree_cbox_readme_64_s256_d8": (lambda: scenes.cbox((64, 64), "readme"), 256, 8),
     "embree_cbox_rect_readme_64_s64_d5": (lambda: scenes.cbox((64, 64), "readme", False), 64, 5),
+    # more primitives than one BVH8 node; the other order-dependent shapes (Plane's finite bounds, Line, Cylinder); many primitives
+    "embree_clutter20_48_s16_d5": (lambda: scenes.cbox_clutter((48, 48), 12, 19), 16, 5),
+    "embree_clutter63_48_s16_d5": (lambda: scenes.cbox_clutter((48, 48), 55, 62), 16, 5),
+    "embree_xshapes_48_s16_d5": (lambda: scenes.xshapes_zoo((48, 48)), 16, 5),
+    "embree_lights_zoo_48_s16_d6": (lambda: scenes.lights_zoo((48, 48)), 16, 6),
+    "embree_classic_cones12_90x45_s16_d6": (lambda: scenes.classic_cones((90, 45), 12), 16, 6),
 }
 
 

@@ -68,6 +68,7 @@ int pine_gpu_test_sincos(int, const float*, int64_t, float*, float*) { return fa
 int pine_gpu_test_powlog(int, const float*, const float*, int64_t, float*, float*) { return fail(); }
 int pine_gpu_test_atan(int, const float*, const float*, int64_t, float*, float*) { return fail(); }
 int pine_gpu_test_traverse(pine_gpu_scene*, int, const float*, int64_t, int, int, uint32_t*) { return fail(); }
+int pine_gpu_test_embree_tree(const float*, int, int*, int) { return fail(); }
 int pine_gpu_test_shapes(pine_gpu_scene*, int, const float*, int64_t, float*, int64_t) { return fail(); }
 int pine_gpu_plan_test_traverse_baked(pine_gpu_plan*, const float*, int64_t, uint32_t*) { return fail(); }
 }
