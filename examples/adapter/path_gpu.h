@@ -24,13 +24,13 @@ namespace pine {
 
 struct GpuPathIntegrator {
   // PathIntegrator(Accel, Sampler, LightSampler, int) (program_context.cpp:76-78).  The accel decides the ORDER closest hits are
-  // found in, which one shape can see (the transformed Box, bbox.cpp:149-171): an Accel that holds an EmbreeAccel -- the only
-  // one a .pine script can construct, and what the two-argument constructor of program_context.cpp:79-81 passes -- renders
-  // nearest bounds first (PINE_GPU_FLAG_ORDER_EMBREE: the films of the reference's EmbreeAccel, bit for bit); a BVH, in
-  // pine-BVH order.  The light sampler has one alternative, UniformLightSampler: nothing to choose.
+  // found in, which a few shapes can see (the transformed Box, bbox.cpp:149-171; Plane, Line, Cylinder): an Accel that holds an
+  // EmbreeAccel -- the only one a .pine script can construct, and what the two-argument constructor of
+  // program_context.cpp:79-81 passes -- renders in EmbreeAccel's order (PINE_GPU_FLAG_ORDER_EMBREE: the films of the reference's
+  // EmbreeAccel, bit for bit); a BVH, in pine-BVH order.  The light sampler has one alternative, UniformLightSampler: nothing to choose.
   GpuPathIntegrator(const Accel& accel, Sampler sampler_, LightSampler, int max_path_length)
       : GpuPathIntegrator(MOVE(sampler_), max_path_length) {
-    order_nearest = accel.is<EmbreeAccel>();
+    order_embree = accel.is<EmbreeAccel>();
   }
   GpuPathIntegrator(Sampler sampler_, int max_path_length) : sampler(MOVE(sampler_)), max_path_length(max_path_length) {
     if (max_path_length <= 0)
@@ -109,7 +109,7 @@ struct GpuPathIntegrator {
     auto* s = mirror(scene);
     auto& film = scene.camera.film();
     pine_gpu_render_params prm{sampler.spp(), max_path_length, /*device*/ 0, /*rank*/ 0, /*world*/ 1, 0,
-                               (specialize ? PINE_GPU_FLAG_SPECIALIZE : 0) | (order_nearest ? PINE_GPU_FLAG_ORDER_EMBREE : 0),
+                               (specialize ? PINE_GPU_FLAG_SPECIALIZE : 0) | (order_embree ? PINE_GPU_FLAG_ORDER_EMBREE : 0),
                                sampler.is<SobolSampler>() ? PINE_GPU_SAMPLER_SOBOL : sampler.is<HaltonSampler>() ? PINE_GPU_SAMPLER_HALTON : PINE_GPU_SAMPLER_BLUE};
     // film.data() is Array2d<vec4>: W*H float4, row 0 first -- exactly the layout the ABI writes (array.h:51-55)
     const int rc = pine_gpu_path_render(s, &prm, &film.data()[0][0]);
@@ -124,8 +124,8 @@ struct GpuPathIntegrator {
   // library loads it from its on-disk cache, or compiles it in the background while the precompiled kernel renders this call;
   // true: wait for the compiler here (seconds of hipcc the first time a geometry is seen) and fail if it cannot be built
   bool specialize = false;
-  // closest hits nearest bounds first, as EmbreeAccel (set by the four-argument constructor from the Accel it is handed)
-  bool order_nearest = false;
+  // closest hits in EmbreeAccel's order (set by the four-argument constructor from the Accel it is handed)
+  bool order_embree = false;
 };
 
 }  // namespace pine

@@ -21,8 +21,9 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--devices") && i + 1 < argc) setenv("PINE_GPU_DEVICES", argv[++i], 1);  // e.g. 0,1,2,3,4,5,6,7
     else if (!strcmp(argv[i], "--tables") && i + 1 < argc) pine_gpu_set_table_path(argv[++i]);
-    // which accel the two-argument PathIntegrator(sampler, n) stands for: bvh (default: pine-BVH order, the bits of Accel(BVH()))
-    // or embree (nearest bounds first: what real pine's default EmbreeAccel renders; only a transformed Box can tell)
+    // which accel the two-argument PathIntegrator(sampler, n) stands for: embree (what real pine's default EmbreeAccel renders: the
+    // default for scenes without meshes) or bvh (pine-BVH order, the bits of Accel(BVH())); only order-dependent shapes -- a
+    // transformed Box, Plane, Line, Cylinder -- can tell
     else if (!strcmp(argv[i], "--accel") && i + 1 < argc) setenv("PINE_PRL_ACCEL", argv[++i], 1);
     else path = argv[i];
   }

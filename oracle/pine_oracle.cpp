@@ -2228,6 +2228,7 @@ struct BVHImpl {
   }
 };
 
+static thread_local bool t_trace_queries = false;  // $PINE_ORACLE_TRACE_PIXEL=x,y: every accel query of that pixel's paths on stderr (debugging aid)
 static int g_order_mode = 0;  // test-infrastructure switch (oracle_set_order): 0 pine's BVH order, 1 nearest bounds first, 2 EmbreeAccel's order
 
 // ------------------------------------------------------------------------------------------------
@@ -2523,6 +2524,44 @@ inline void traverse(const Tree& tree, Ray& ray, Leaf&& leaf) {
     tfar = ray.tmax;  // tray.tfar = ray.tfar
   }
 }
+// BVHNIntersector1<8, ...>::occluded (kernels/bvh/bvh_intersector1.cpp:117-195): every primitive whose box (and whose ancestors')
+// the ray enters within [tnear, tfar] is handed to `leaf` until one reports a hit.  The ORDER cannot change an any-hit answer;
+// WHICH primitives are asked can: a shape whose hit() succeeds where the ray misses its own bounds (Plane beyond its +-100 box,
+// geometry.cpp:52) is found by pine's BVH when it shares a leaf box with a neighbour, and never by Embree.
+template <class Leaf>
+inline bool occluded(const Tree& tree, const Ray& ray, Leaf&& leaf) {
+  if (tree.root == Tree::kEmpty) return false;
+  if (ray.tmax < 0.0f) return false;
+  const float org[3] = {ray.o.x, ray.o.y, ray.o.z}, dir[3] = {ray.d.x, ray.d.y, ray.d.z};
+  float rdir[3], org_rdir[3];
+  bool near_hi[3];
+  for (int d = 0; d < 3; d++) {
+    rdir[d] = rcp_safe(dir[d]);
+    org_rdir[d] = org[d] * rdir[d];
+    near_hi[d] = !(rdir[d] >= 0.0f);
+  }
+  auto as_int = [](float f) { return int32_t(f2u(f)); };
+  const int32_t tnear = as_int(std::max(ray.tmin, 0.0f)), tfar = as_int(std::max(ray.tmax, 0.0f));
+  std::vector<int> stack{tree.root};
+  while (!stack.empty()) {
+    const int cur = stack.back();
+    stack.pop_back();
+    if (cur < 0) {
+      if (leaf(~cur)) return true;
+      continue;
+    }
+    const Tree::Node& nd = tree.nodes[size_t(cur)];
+    for (int i = nd.n - 1; i >= 0; i--) {
+      int32_t tn = tnear, tf = tfar;
+      for (int d = 0; d < 3; d++) {
+        tn = std::max(tn, as_int(std::fmaf(near_hi[d] ? nd.hi[d][i] : nd.lo[d][i], rdir[d], -org_rdir[d])));
+        tf = std::min(tf, as_int(std::fmaf(near_hi[d] ? nd.lo[d][i] : nd.hi[d][i], rdir[d], -org_rdir[d])));
+      }
+      if (!(tn > tf)) stack.push_back(nd.child[i]);
+    }
+  }
+  return false;
+}
 }  // namespace embree_order
 
 struct Scene {
@@ -2604,7 +2643,19 @@ struct Scene {
   bool intersect_nearest(Ray& ray, SurfaceInteraction& it) const;
   bool intersect_embree(Ray& ray, SurfaceInteraction& it) const;
   bool hit(Ray ray) const {  // BVH::hit :497-511
+    if (t_trace_queries) fprintf(stderr, "Q any %a %a %a %a %a %a %a %a\n", ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tmin, ray.tmax);
     if (geometries.empty()) return false;
+    if (g_order_mode == 2) {  // EmbreeAccel::hit (embree.cpp:143-165): the meshes (Embree triangle geometry; pine's triangle tests stand in), then the user primitives
+      // `return ray_.tfar < 0` (embree.cpp:164) is also what a query that STARTS with a negative tfar answers -- rtcOccluded1 leaves such
+      // a ray alone (bvh_intersector1.cpp:128-129): "occluded", where pine's BVH finds nothing.  Light samples behind their own
+      // distance (a negative ls.distance) reach this.
+      if (ray.tmax < 0.0f) return true;
+      for (size_t li = 0; li < lbvh.size(); li++) {
+        const Mesh& m = geometries[indices[li]].as<Mesh>();
+        if (lbvh[li]->any_hit(ray, [&](const Ray& rr, int idx) { return m.hit(rr, idx); })) return true;
+      }
+      return embree_order::occluded(etree, ray, [&](int gi) { return geometries[size_t(gi)].hit(Ray(ray.o, ray.d, ray.tmin, ray.tmax)); });
+    }
     return tbvh.any_hit(ray, [&](const Ray& r, int li) {
       const Geometry& g = geometries[indices[li]];
       if (li < int(lbvh.size())) {
@@ -2615,6 +2666,7 @@ struct Scene {
     });
   }
   bool intersect(Ray& ray, SurfaceInteraction& it) const {  // BVH::intersect :513-548
+    if (t_trace_queries) fprintf(stderr, "Q closest %a %a %a %a %a %a %a %a\n", ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tmin, ray.tmax);
     if (geometries.empty()) return false;
     uint32_t geom_index = 0, prim_index = 0;
     if (g_order_mode == 1) return intersect_nearest(ray, it);
@@ -3346,6 +3398,11 @@ void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int dep
           if (tile % shard_world != shard_rank) continue;
         }
         sampler.start_pixel(px, py, 0);
+        {
+          int tx = -1, ty = -1;
+          const char* e = getenv("PINE_ORACLE_TRACE_PIXEL");
+          t_trace_queries = e && sscanf(e, "%d,%d", &tx, &ty) == 2 && tx == px && ty == py;
+        }
         vec3 L(0.0f);
         for (int si = 0; si < spp; si++, sampler.start_next_sample()) {
           // g++ right-to-left: lens sample first, then pixel jitter (path.cpp:35, Appendix A2)
@@ -3433,16 +3490,23 @@ int oracle_embree_tree(const float* boxes, int n, int* words, int cap) {
     for (int i = 0; i < 8; i++) words[k++] = nd.child[i];
   return k;
 }
-// test hook: the closest-hit query of order mode "embree" on a scene, ray by ray: per ray cap + 3 words -- [count, the geometry
-// indices handed to their tests in order ...] (cap words), hit, geometry, tmax bits (meshes: their word only)
+// test hook: the queries of order mode "embree" on a scene, ray by ray: per ray cap + 4 words -- [count, the geometry indices
+// handed to their tests in order ...] (cap words), hit, geometry, tmax bits of the closest-hit query (meshes: their word only),
+// the any-hit query's answer
 int oracle_embree_traverse(const char* pscene, const float* rays, int64_t nrays, int cap, uint32_t* out) {
   Scene scene;
   if (!parse_pscene(pscene, scene)) return 2;
   scene.build_accel();
   for (int64_t i = 0; i < nrays; i++) {
     const float* q = rays + i * 8;
-    uint32_t* o = out + i * (cap + 3);
+    uint32_t* o = out + i * (cap + 4);
     Ray ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
+    {
+      const int keep = g_order_mode;
+      g_order_mode = 2;
+      o[cap + 3] = scene.hit(ray) ? 1u : 0u;
+      g_order_mode = keep;
+    }
     int n = 0, hit_geom = -1;
     for (size_t li = 0; li < scene.lbvh.size(); li++) {
       if (1 + n < cap) o[1 + n] = uint32_t(scene.indices[li]);

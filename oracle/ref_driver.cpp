@@ -17,6 +17,9 @@
 //   pine_ref bvh     <scene.pscene> <rays.bin> <tree.bin> <trav.bin>   the reference's own BVH (bvh.cpp:30-147, 453-495) as a
 //                                        canonical pre-order stream, and for every ray the primitives BVH::intersect / BVH::hit
 //                                        test, in order, with the result (bvh.cpp:321-451, 497-548)
+//   pine_ref accelq  <scene.pscene> <rays.bin> <out.bin>   Accel::intersect and Accel::hit of the accel $PINE_REF_ACCEL names (bvh |
+//                                        embree: EmbreeAccel, pine_ref_embree only) for every ray: 4 words -- hit, geometry index,
+//                                        tmax bits, any-hit result.  The ray-level view of what a film is made of.
 //   pine_ref vertices <scene.pscene> <spp> <depth> <out.bin>   per-vertex terms of every path of the film (path.cpp:42-124):
 //                                        radiance() restated around the reference's OWN intersect / light sampler / bxdf
 //                                        objects with a log; the restated loop's film is checked against render()'s
@@ -618,6 +621,48 @@ int main(int argc, char** argv) {
     }
     write_file(argv[5], trav.data(), trav.size() * 4);
     printf("{\"bvhs\": %zu, \"tree_words\": %zu, \"rays\": %zu, \"trav_words\": %zu}\n", 1 + lbvh.size(), tree.size(), rays.size() / 8, trav.size());
+    return 0;
+  }
+  if (cmd == "accelq" && argc == 5) {
+    Loaded L;
+    load_pscene(argv[2], L);
+    const char* accel_env = getenv("PINE_REF_ACCEL");
+    const bool embree = accel_env && std::string(accel_env) == "embree";
+#ifndef PINE_REF_WITH_EMBREE
+    if (embree) {
+      fprintf(stderr, "this binary was built without Embree (make -C oracle embree)\n");
+      return 2;
+    }
+#endif
+    Accel accel =
+#ifdef PINE_REF_WITH_EMBREE
+        embree ? Accel(EmbreeAccel()) :
+#endif
+               Accel(BVH());
+    accel.build(&L.scene);
+    std::ifstream rf(argv[3], std::ios::binary);
+    rf.seekg(0, std::ios::end);
+    size_t nbytes = rf.tellg();
+    rf.seekg(0);
+    std::vector<float> rays(nbytes / 4);
+    rf.read((char*)rays.data(), nbytes);
+    std::vector<uint32_t> out;
+    for (size_t r = 0; r + 8 <= rays.size(); r += 8) {
+      const float* q = &rays[r];
+      Ray ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
+      SurfaceInteraction it;
+      const bool hit = accel.intersect(ray, it);
+      uint32_t geom = 0;
+      if (hit)
+        for (size_t g = 0; g < L.scene.geometries.size(); g++)
+          if (it.shape == &L.scene.geometries[g]->shape) geom = uint32_t(g);
+      uint32_t tb;
+      memcpy(&tb, &ray.tmax, 4);
+      const bool any = accel.hit(Ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]));
+      out.push_back(hit ? 1u : 0u), out.push_back(geom), out.push_back(tb), out.push_back(any ? 1u : 0u);
+    }
+    write_file(argv[4], out.data(), out.size() * 4);
+    printf("{\"rays\": %zu, \"accel\": \"%s\"}\n", rays.size() / 8, embree ? "embree" : "bvh");
     return 0;
   }
   if (cmd == "vertices" && argc == 6) {

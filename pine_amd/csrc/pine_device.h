@@ -38,8 +38,8 @@ enum : unsigned {
                           // variants only (pine_variants.h), chosen by PINE_GPU_FLAG_VERTEX_LOG; every other variant carries no trace of it
   F_BAKED = 1u << 17,     // scene-specialised builds (pine_specialize.h): the scene's BVH and primitive records are baked into the kernel
                           // (a -DPINE_BAKED_SCENE compile; the bit only makes such a kernel's name its own in profiles)
-  F_NEAREST = 1u << 18,   // PINE_GPU_FLAG_ORDER_NEAREST: closest-hit queries test the top-level primitives nearest bounds first (what a
-                          // nearest-first BVH with one primitive per leaf -- the reference's EmbreeAccel -- does) instead of in pine-BVH order;
+  F_EMBREE = 1u << 18,    // PINE_GPU_FLAG_ORDER_EMBREE: closest-hit queries hand the shapes to their tests in the order of the reference's
+                          // EmbreeAccel (scene_traverse_embree, pine_kernels_device.h) instead of in pine-BVH order;
                           // a few variants only (pine_variants.h), never chosen without the flag
   F_ALL = 0xffu | F_NODES | F_LIGHTS | F_XSHAPES | F_SOBOL,
 };
@@ -448,19 +448,6 @@ PINE_HD bool box_hit_oct(const float* lo, const float* hi, const DRayOct& r, flo
   tmin = __builtin_fmaxf(__builtin_fmaxf(tmin0, __builtin_fmaxf(tmin1, tmin2)), tmin);
   tmax = __builtin_fminf(__builtin_fminf(tmax0, __builtin_fminf(tmax1, tmax2)), tmax);
   return tmin <= tmax;
-}
-// ... the same test reporting the ENTRY distance as well (order mode "nearest": pine_kernels_device.h scene_traverse_nearest)
-PINE_HD bool box_entry_oct(const float* lo, const float* hi, const DRayOct& r, float tmin, float tmax, float& tnear) {
-  const bool nx = r.neg & 1, ny = r.neg & 2, nz = r.neg & 4;
-  const float tmin0 = (nx ? hi[0] : lo[0]) * r.dir_inv.x - r.org_div_dir.x;
-  const float tmin1 = (ny ? hi[1] : lo[1]) * r.dir_inv.y - r.org_div_dir.y;
-  const float tmin2 = (nz ? hi[2] : lo[2]) * r.dir_inv.z - r.org_div_dir.z;
-  const float tmax0 = (nx ? lo[0] : hi[0]) * r.dir_inv.x - r.org_div_dir.x;
-  const float tmax1 = (ny ? lo[1] : hi[1]) * r.dir_inv.y - r.org_div_dir.y;
-  const float tmax2 = (nz ? lo[2] : hi[2]) * r.dir_inv.z - r.org_div_dir.z;
-  tnear = __builtin_fmaxf(__builtin_fmaxf(tmin0, __builtin_fmaxf(tmin1, tmin2)), tmin);
-  const float tfar = __builtin_fminf(__builtin_fminf(tmax0, __builtin_fminf(tmax1, tmax2)), tmax);
-  return tnear <= tfar;
 }
 // AABB::intersect(o, d, tmin&, tmax&) bbox.cpp:94-111 (also the body of AABB::hit(Ray) :75-93)
 // Straight-line form (selects instead of the reference's early returns): in a wave some lane almost

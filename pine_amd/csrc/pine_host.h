@@ -89,7 +89,7 @@ struct FlatAccel {
   std::vector<float> tri_attrs;
   // the top-level primitives' own boxes in the reference's listing order (bvh.cpp:470-488: one per non-empty mesh, then the
   // other shapes, each in geometry order), 8 floats each: lower, geometry index (int bits), upper, 0 -- what
-  // PINE_GPU_FLAG_ORDER_NEAREST sorts by
+  // PINE_GPU_FLAG_ORDER_EMBREE builds its hierarchy from
   std::vector<float> top_boxes;
   bool built = false;
 };

@@ -288,7 +288,7 @@ __global__ void test_rng_kernel(unsigned long long* out) {
 template <int MODE>
 __global__ void __launch_bounds__(64) test_traverse_kernel(DeviceScene S, const float* rays, long long nrays, int cap, unsigned* out) {
   constexpr bool FLAT = MODE == 1;
-  constexpr unsigned F = FLAT ? (F_ALL | F_LDS_TOP) : MODE == 2 ? (F_ALL | F_NEAREST) : F_ALL;
+  constexpr unsigned F = FLAT ? (F_ALL | F_LDS_TOP) : MODE == 2 ? (F_ALL | F_EMBREE) : F_ALL;
   using StackT = typename std::conditional<FLAT, unsigned short, int>::type;
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   StackT* const stack = reinterpret_cast<StackT*>(lds_raw) + threadIdx.x;
@@ -862,8 +862,8 @@ static int plan_specialize(pine_gpu_plan* p, const FlatAccel& A, const std::vect
   const unsigned kLayout = F_LDS_SCENE | F_LDS_TOP | F_LDS_REST | F_XSTAGE | F_SSS;
   unsigned exact = (V.features & kLayout) | need;
   std::string baked;
-  // (a baked scene IS pine's visiting order as code: the nearest-bounds-first mode keeps to the feature-set level)
-  if (!(prm->flags & (PINE_GPU_FLAG_SPECIALIZE_NO_BAKE | PINE_GPU_FLAG_ORDER_NEAREST)) && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr) {
+  // (a baked scene IS pine's visiting order as code: the EmbreeAccel order mode keeps to the feature-set level)
+  if (!(prm->flags & (PINE_GPU_FLAG_SPECIALIZE_NO_BAKE | PINE_GPU_FLAG_ORDER_EMBREE)) && getenv("PINE_GPU_SPECIALIZE_NO_BAKE") == nullptr) {
     if (!(V.features & F_XSTAGE) && A.top_prim_begin == 0) baked = generate_baked_scene(A, shapes, packed_prims);
     // one mesh under a small top level, traversal stages (C5's class): the top level as code, the mesh left to the flat traversal
     else if ((V.features & F_XSTAGE) && A.bvhs.size() == 2 && getenv("PINE_GPU_SPECIALIZE_NO_TOP") == nullptr)
@@ -1256,11 +1256,11 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   S.off_lights = put(light_list.data(), light_list.size() * sizeof(DLight));
   // PINE_GPU_FLAG_ORDER_EMBREE: the hierarchy EmbreeAccel walks over the non-mesh shapes (pine_embree_order.h), the meshes' places
   // in `leaf` (tested first), and -- behind the part of the blob that scene-in-LDS variants copy -- the RCPPS estimates
-  const bool order_nearest = (prm->flags & PINE_GPU_FLAG_ORDER_EMBREE) != 0;
+  const bool order_embree = (prm->flags & PINE_GPU_FLAG_ORDER_EMBREE) != 0;
   S.off_etree = S.off_emesh = S.off_rcpps = 0;
   S.etree_root = kEmbreeNoChild;
   S.num_emesh = 0;
-  if (order_nearest) {
+  if (order_embree) {
     if (prm->flags & (PINE_GPU_FLAG_FAST | PINE_GPU_FLAG_VERTEX_LOG)) {
       set_error("PINE_GPU_FLAG_ORDER_EMBREE cannot be combined with PINE_GPU_FLAG_FAST / _VERTEX_LOG");
       return -1;
@@ -1298,7 +1298,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   blob.resize((blob.size() + 15) & ~size_t(15));
   S.blob_bytes = int(blob.size());
-  if (order_nearest) S.off_rcpps = put(kRcppsTable, sizeof(kRcppsTable));  // (global memory only: blob_bytes is what LDS variants stage)
+  if (order_embree) S.off_rcpps = put(kRcppsTable, sizeof(kRcppsTable));  // (global memory only: blob_bytes is what LDS variants stage)
   HIP_OK(POOL_ALLOC(p->d_blob, blob.size()));
   HIP_OK(hipMemcpy(p->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (upload(p->d_tri, A.tri_verts)) return -1;
@@ -1418,7 +1418,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
   }
   if (!node_ops.empty()) need |= F_NODES;
   if (sobol) need |= F_SOBOL;
-  if (order_nearest) need |= F_NEAREST;
+  if (order_embree) need |= F_EMBREE;
   // (SobolSampler / HaltonSampler with Subsurface: a BSSRDF walk draws from the sampler at every step and the sampler's dimension
   //  counter outgrows the packed path state -- the F_SSS | F_SOBOL variants keep it in a word of its own: kBigDim)
   for (auto& L : light_list)
@@ -1429,7 +1429,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     const unsigned F = kVariants[v].features;
     if ((F & need) != need) continue;
     if (((F & F_LDS_SCENE) != 0) != lds_ok) continue;
-    if (((F & F_NEAREST) != 0) != order_nearest) continue;  // (the order mode's twin variants: never without the flag)
+    if (((F & F_EMBREE) != 0) != order_embree) continue;  // (the order mode's twin variants: never without the flag)
     if (getenv("PINE_GPU_WPS") && atoi(getenv("PINE_GPU_WPS")) != kVariants[v].waves_per_simd) continue;
     p->variant = v;
     break;
@@ -1459,7 +1459,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
         const unsigned F = kQueueVariants[v].features;
         if ((F & need) != need) continue;
         if (((F & F_VLOG) != 0) != ((prm->flags & PINE_GPU_FLAG_VERTEX_LOG) != 0)) continue;  // (the test hook's twin variants)
-        if (((F & F_NEAREST) != 0) != order_nearest) continue;                                   // (the order mode's twin variants)
+        if (((F & F_EMBREE) != 0) != order_embree) continue;                                   // (the order mode's twin variants)
         if ((F & F_LDS_SCENE) && !lds_ok) continue;  // (a scene-in-global variant later in the table is the fallback when LDS is short)
         if ((F & F_LDS_TOP) && A.nodes.size() > 65535) continue;  // 16-bit stack entries
         const size_t rest_bytes = size_t(S.blob_bytes - S.off_shapes);

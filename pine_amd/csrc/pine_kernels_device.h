@@ -94,7 +94,7 @@ struct DeviceScene {
   const uint4* tri_packets;   // entries (tri_packet_entries x 8 bytes, padded to 16), then vertices (x 16 bytes)
   int tri_packet_entries, tri_packet_verts;
   int lds_tris;               // 1: every workgroup copies the packets to LDS and the traversal reads them there
-  // PINE_GPU_FLAG_ORDER_EMBREE (F_NEAREST variants): the BVH8 the reference's EmbreeAccel walks over the non-mesh shapes
+  // PINE_GPU_FLAG_ORDER_EMBREE (F_EMBREE variants): the BVH8 the reference's EmbreeAccel walks over the non-mesh shapes
   // (pine_embree_order.h) -- EmbreeNode records at off_etree of the blob, the root's child word (kEmbreeNoChild: no such
   // shape) -- the places in `leaf` of the meshes (num_emesh ints at off_emesh; tested first) and the 2048 RCPPS estimates
   // (off_rcpps: BEHIND blob_bytes, global memory only)
@@ -139,7 +139,7 @@ struct SceneView {
   int lds_node_count;
   const uint2* lds_tri_entries;   // DeviceScene::tri_packets in LDS (null: triangles are read from tri_leaf)
   const float4* lds_tri_verts;
-  // F_NEAREST variants (PINE_GPU_FLAG_ORDER_EMBREE): DeviceScene::off_etree / etree_root / off_emesh / off_rcpps
+  // F_EMBREE variants (PINE_GPU_FLAG_ORDER_EMBREE): DeviceScene::off_etree / etree_root / off_emesh / off_rcpps
   const EmbreeNode* etree;
   int etree_root;
   const int* emesh;
@@ -312,7 +312,7 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
   return hit;
 }
 
-// PINE_GPU_FLAG_ORDER_EMBREE (F_NEAREST variants): closest-hit queries hand the non-mesh shapes to their tests in the order the
+// PINE_GPU_FLAG_ORDER_EMBREE (F_EMBREE variants): closest-hit queries hand the non-mesh shapes to their tests in the order the
 // reference's DEFAULT accel does -- BVHNIntersector1<8, BVH_AN1, false, ...>::intersect of the vendored Embree 4.3.1
 // (src/contrib/embree/kernels/bvh/bvh_intersector1.cpp:30-107) over the BVH8 of pine_embree_order.h, as an AVX2 x86 host runs it:
 //   * the ray: rdir = rcp_safe(dir) -- one fused Newton step on the RCPPS estimate (common/math/vec3fa.h:122-172; the estimates
@@ -324,8 +324,8 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
 //     into, the others wait on the stack with their distances (kernels/bvh/bvh_traverser1.h:310-385);
 //   * a popped entry whose distance lies beyond the closest hit so far is dropped (bvh_intersector1.cpp:77-79).
 // Meshes are Embree triangle geometry with Embree's own intersector, which is not restated: they are tested FIRST (the
-// triangle accel precedes the user-geometry accel, kernels/common/scene.cpp:741-755) with pine's triangle tests.  Any-hit
-// queries are order independent and stay with pine's BVH.  tests/test_embree_order.py, tests/test_gpu_parity.py: the films of
+// triangle accel precedes the user-geometry accel, kernels/common/scene.cpp:741-755) with pine's triangle tests.
+// tests/test_embree_order.py, tests/test_gpu_parity.py: the films of
 // the real reference built with EmbreeAccel, bit for bit.
 __device__ __forceinline__ float embree_rcp_safe(const unsigned* table, float a) {
   if (fabsf(a) < 1e-18f) a = 1e-18f;  // zero_fix: min_rcp_input
@@ -433,6 +433,62 @@ __device__ __forceinline__ bool scene_traverse_embree(const SceneView& S, DRay& 
   return hit;
 }
 
+// ... and its any-hit query, EmbreeAccel::hit (embree.cpp:143-165) = BVHNIntersector1<8, ...>::occluded
+// (bvh_intersector1.cpp:117-195).  The order cannot change an any-hit answer; WHICH shapes are asked can: a shape is asked
+// exactly when the ray enters its own box (and its ancestors') within [tnear, tfar], where pine's BVH asks every shape of a
+// leaf whose UNION box is entered -- a Plane beyond its +-100 bounds (geometry.cpp:52) is found by the one and not by the other.
+// And a query that starts with a negative tfar is answered "occluded" (rtcOccluded1 leaves such a ray alone, and
+// embree.cpp:164 returns `tfar < 0`), where pine's BVH finds nothing: light samples with a negative distance reach this.
+template <unsigned F, int STRIDE, class StackT>
+__device__ __forceinline__ bool scene_occluded_embree(const SceneView& S, const DRay& ray_in, StackT* stack, TravLog* log) {
+  if (ray_in.tmax < 0.0f) return true;
+  DRay ray = ray_in;
+  if constexpr (F & F_MESH)
+    for (int k = 0; k < S.num_emesh; k++) {
+      const DShape* sh = &S.leaf[S.emesh[k]];
+      if (log) log->put(unsigned(sh->kind & kPrimIndexMask));
+      const DRayOct oct = make_oct(ray);
+      int prim = 0;
+      if (mesh_traverse<true, STRIDE, F>(S, S.bvhs[as_int(sh->f[2])], ray, oct, stack, S.stack_top, prim, log)) return true;
+    }
+  if (S.etree_root == kEmbreeNoChild) return false;
+  const float rdx = embree_rcp_safe(S.rcpps, ray.d.x), rdy = embree_rcp_safe(S.rcpps, ray.d.y), rdz = embree_rcp_safe(S.rcpps, ray.d.z);
+  const float ordx = ray.o.x * rdx, ordy = ray.o.y * rdy, ordz = ray.o.z * rdz;
+  const int nx = rdx >= 0.0f ? 0 : 24, ny = rdy >= 0.0f ? 0 : 24, nz = rdz >= 0.0f ? 0 : 24;
+  const int tnear = __float_as_int(fmaxf(ray.tmin, 0.0f)), tfar = __float_as_int(fmaxf(ray.tmax, 0.0f));
+  int items[kEmbreeStackEntries];
+  int sp = 1;
+  items[0] = S.etree_root;
+  while (sp > 0) {
+    const int cur = items[--sp];
+    if (cur < 0) {
+      const DShape* sh = &S.leaf[~cur];
+      DShape rec;
+      {
+        const uint4* src = reinterpret_cast<const uint4*>(sh);
+        uint4* dst = reinterpret_cast<uint4*>(&rec);
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = src[q];
+        sh = &rec;
+      }
+      const int word = sh->kind;
+      if (log) log->put(unsigned(word & kPrimIndexMask));
+      if (shape_hit<F>(word >> kPrimKindShift, sh, ray)) return true;
+      continue;
+    }
+    const float* nd = reinterpret_cast<const float*>(&S.etree[cur]);
+    const int count = reinterpret_cast<const int*>(nd)[56];
+    for (int i = count - 1; i >= 0; i--) {
+      const int tn = max(max(__float_as_int(__fmaf_rn(nd[nx + i], rdx, -ordx)), __float_as_int(__fmaf_rn(nd[8 + ny + i], rdy, -ordy))),
+                         max(__float_as_int(__fmaf_rn(nd[16 + nz + i], rdz, -ordz)), tnear));
+      const int tf = min(min(__float_as_int(__fmaf_rn(nd[(nx ^ 24) + i], rdx, -ordx)), __float_as_int(__fmaf_rn(nd[8 + (ny ^ 24) + i], rdy, -ordy))),
+                         min(__float_as_int(__fmaf_rn(nd[16 + (nz ^ 24) + i], rdz, -ordz)), tfar));
+      if (!(tn > tf)) items[sp++] = reinterpret_cast<const int*>(nd)[48 + i];
+    }
+  }
+  return false;
+}
+
 // ANY: BVH::hit (bvh.cpp:497-511).  !ANY: BVH::intersect (bvh.cpp:513-548) minus the final
 // compute_surface_info, which the caller does once for the winning primitive.
 // geom_out receives the winning primitive's PACKED word (index | emissive bit | kind).
@@ -440,7 +496,10 @@ template <bool ANY, unsigned F, int STRIDE = kBlock, class StackT = int>
 __device__ __forceinline__ bool scene_traverse(const SceneView& S, DRay& ray, StackT* stack, int& geom_out,
                                                int& prim_out, TravLog* log = nullptr) {
   if (S.num_shapes == 0) return false;
-  if constexpr ((F & F_NEAREST) != 0 && !ANY) return scene_traverse_embree<F, STRIDE>(S, ray, stack, geom_out, prim_out, log);
+  if constexpr ((F & F_EMBREE) != 0) {
+    if constexpr (ANY) return scene_occluded_embree<F, STRIDE>(S, ray, stack, log);
+    else return scene_traverse_embree<F, STRIDE>(S, ray, stack, geom_out, prim_out, log);
+  }
   const DRayOct oct = make_oct(ray);
   const DBvh top = S.bvhs[0];
   bool hit = false;

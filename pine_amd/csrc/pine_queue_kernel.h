@@ -104,7 +104,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
 #endif
   constexpr bool kFlat = kTop && !kBaked;  // rays are traced by the flat traversal (a specialised build: by the scene's own code)
   static_assert(!(F & F_LDS_REST) || kTop, "F_LDS_REST is an option of the F_LDS_TOP variants");
-  static_assert(!(F & F_NEAREST) || (!kTop && !kBaked), "the nearest-bounds-first order lives in scene_traverse: not in the flat traversal, not in baked scenes");
+  static_assert(!(F & F_EMBREE) || (!kTop && !kBaked), "EmbreeAccel's order lives in scene_traverse: not in the flat traversal, not in baked scenes");
   static_assert(!(F & F_XSTAGE) || kTop, "F_XSTAGE is an option of the F_LDS_TOP variants");
   constexpr int kQCtxGlobalDwords = q_ctx_global_dwords(F);
   constexpr int kQCtxTravOffset = q_ctx_trav_offset(F);
@@ -171,7 +171,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
   V.lds_tri_verts = nullptr;
   V.stack_top = S.stack_top;
   V.num_shapes = S.num_shapes;
-  // (F_NEAREST variants read these; the hierarchy and the mesh list move with the blob when it is staged in LDS)
+  // (F_EMBREE variants read these; the hierarchy and the mesh list move with the blob when it is staged in LDS)
   V.etree_root = S.etree_root;
   V.num_emesh = S.num_emesh;
   V.rcpps = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(S.blob) + S.off_rcpps);

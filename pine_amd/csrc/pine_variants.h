@@ -91,12 +91,12 @@ const PineKernelVariant* pine_gpu_fast_variants(int* count);
   PINE_Q(7, 16, F_OBB | F_LDS_SCENE | F_VLOG, PINE_QCTX, "queue: rect+transformed box/diffuse, scene in LDS, per-vertex log")                \
   PINE_Q(6, 17, (F_ALL & ~F_SSS) | F_LDS_REST | F_LDS_TOP | F_VLOG, 1024, "queue: all but SSS, 1024 contexts, BVH top + scene records in LDS, per-vertex log") \
   PINE_EXPERIMENT_VARIANTS(PINE_Q)                                                                                                           \
-  /* PINE_GPU_FLAG_ORDER_NEAREST: closest hits nearest bounds first (the order of the reference's EmbreeAccel); cbox-class scenes */ \
-  PINE_Q(7, 18, kFAnalytic | F_LDS_SCENE | F_NEAREST, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS, nearest-bounds-first order")         \
+  /* PINE_GPU_FLAG_ORDER_EMBREE: closest hits in the order of the reference's EmbreeAccel; cbox-class scenes */ \
+  PINE_Q(7, 18, kFAnalytic | F_LDS_SCENE | F_EMBREE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS, EmbreeAccel's order")         \
   PINE_M(0, 0, kFBoxes | F_LDS_SCENE, 4, "rect+box/diffuse, scene in LDS")                                                                  \
   PINE_M(6, 1, kFAnalytic | F_LDS_SCENE, 2, "analytic shapes/uber, scene in LDS")                                                           \
   PINE_M(6, 2, kFAnalytic, 2, "analytic shapes/uber")                                                                                       \
   PINE_M(7, 3, F_ALL | F_LDS_SCENE, 2, "all features, scene in LDS")                                                                        \
   PINE_M(7, 4, F_ALL, 2, "all features")                                                                                                    \
-  PINE_M(5, 5, F_ALL | F_LDS_SCENE | F_NEAREST, 2, "all features, scene in LDS, nearest-bounds-first order")                                \
-  PINE_M(3, 6, F_ALL | F_NEAREST, 2, "all features, nearest-bounds-first order")
+  PINE_M(5, 5, F_ALL | F_LDS_SCENE | F_EMBREE, 2, "all features, scene in LDS, EmbreeAccel's order")                                \
+  PINE_M(3, 6, F_ALL | F_EMBREE, 2, "all features, EmbreeAccel's order")

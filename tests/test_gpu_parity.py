@@ -886,7 +886,7 @@ def test_embree_order_renders_the_embree_reference_films(name, path_kernel):
     sc = embree_scene(name)
     assert sc.describe() == ps
     film, st = _render(sc, spp, depth, order="embree", specialize=False)
-    assert st.kernel_features & (1 << 18), hex(st.kernel_features)  # F_NEAREST: a variant of the order mode ran
+    assert st.kernel_features & (1 << 18), hex(st.kernel_features)  # F_EMBREE: a variant of the order mode ran
     assert_bit_equal(film, emb, f"PINE_GPU_FLAG_ORDER_EMBREE vs O-gcc-embree, {name}")
     if "rect" not in name and "cones" not in name:
         pine_order, _ = _render(sc, spp, depth, specialize=False)
