@@ -24,9 +24,10 @@
 #include <string>
 #include <vector>
 
+#include "pine_types.h"  // EmbreeNode, kEmbreeNoChild, kEmbreeStackEntries
+
 namespace pine_gpu {
 
-// (EmbreeNode, kEmbreeNoChild, kEmbreeStackEntries: pine_kernels_device.h, which the run-time compiled kernels share)
 
 struct EmbreeOrderTree {
   std::vector<EmbreeNode> nodes;

@@ -150,4 +150,19 @@ struct FoldEntry {
 };
 static_assert(sizeof(FoldEntry) == 32, "FoldEntry must be 32 bytes");
 
+// PINE_GPU_FLAG_ORDER_EMBREE: the BVH8 the reference's EmbreeAccel walks (built by pine_embree_order.h on the host, read by
+// scene_traverse_embree in the kernels).
+// One node of that BVH8 as the device reads it: 16 quads.  Planes of the eight children per axis, then the child words:
+// >= 0 a node, < 0 the complement of a primitive's place in SceneView::leaf, kEmbreeNoChild for an unused slot
+// (whose planes are +inf / -inf: no ray enters it -- AABBNode::clear, vendored embree kernels/bvh/bvh_node_aabb.h:97-101).
+struct EmbreeNode {
+  float lo[3][8];
+  float hi[3][8];
+  int child[8];
+  int count, pad[7];
+};
+static_assert(sizeof(EmbreeNode) == 256, "EmbreeNode is read as 16 quads");
+constexpr int kEmbreeNoChild = -2147483647 - 1;
+constexpr int kEmbreeStackEntries = 96;  // per-ray stack of scene_traverse_embree (the host checks the tree against it)
+
 }  // namespace pine_gpu

@@ -13,6 +13,7 @@
 #include "../../pine_amd/csrc/pine_host.h"
 
 #include "../../pine_amd/csrc/pine_specialize.h"
+#include "../../pine_amd/csrc/pine_embree_order.h"
 
 // (the structure sizes a run-time compiled kernel is checked against come from the device half of the library: none here --
 //  a kernel compiled through this build's pine_gpu_test_specialize_compile fails its static_assert, as it should)
@@ -68,7 +69,22 @@ int pine_gpu_test_sincos(int, const float*, int64_t, float*, float*) { return fa
 int pine_gpu_test_powlog(int, const float*, const float*, int64_t, float*, float*) { return fail(); }
 int pine_gpu_test_atan(int, const float*, const float*, int64_t, float*, float*) { return fail(); }
 int pine_gpu_test_traverse(pine_gpu_scene*, int, const float*, int64_t, int, int, uint32_t*) { return fail(); }
-int pine_gpu_test_embree_tree(const float*, int, int*, int) { return fail(); }
+// (host code: the real thing, so that the sanitizers see the hierarchy builder -- same body as in pine_kernels.hip)
+int pine_gpu_test_embree_tree(const float* boxes, int n, int* words, int cap) {
+  if (!boxes || !words || n < 0) return fail();
+  std::vector<float> bx(boxes, boxes + 6 * size_t(n));
+  std::vector<int> places(size_t(n), 0);
+  for (int i = 0; i < n; i++) places[size_t(i)] = i;
+  pine_gpu::EmbreeOrderTree tree;
+  std::string why;
+  if (!tree.build(bx, places, why)) return fail();
+  if (1 + 8 * int(tree.nodes.size()) > cap) return fail();
+  int k = 0;
+  words[k++] = tree.root;
+  for (const pine_gpu::EmbreeNode& nd : tree.nodes)
+    for (int i = 0; i < 8; i++) words[k++] = nd.child[i];
+  return k;
+}
 int pine_gpu_test_shapes(pine_gpu_scene*, int, const float*, int64_t, float*, int64_t) { return fail(); }
 int pine_gpu_plan_test_traverse_baked(pine_gpu_plan*, const float*, int64_t, uint32_t*) { return fail(); }
 }
