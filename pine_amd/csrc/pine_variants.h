@@ -60,7 +60,7 @@ const PineKernelVariant* pine_gpu_fast_variants(int* count);
 // (experiment builds, -DPINE_EXPERIMENT_C4X: the cone scene's kinds with traversal stages and 1536 / 1280 contexts)
 #ifdef PINE_EXPERIMENT_C4X
 #define PINE_EXPERIMENT_VARIANTS(PINE_Q)                                                                                       \
-  PINE_Q(1, 19, F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP | F_XSTAGE, PINE_EXPERIMENT_C4X, "experiment: classic.pine's kinds, traversal stages, more contexts")
+  PINE_Q(1, 20, F_SPHERE | F_DISK | F_CONE | F_UBER | F_LDS_TOP | F_XSTAGE, PINE_EXPERIMENT_C4X, "experiment: classic.pine's kinds, traversal stages, more contexts")
 #else
 #define PINE_EXPERIMENT_VARIANTS(PINE_Q)
 #endif
@@ -93,6 +93,7 @@ const PineKernelVariant* pine_gpu_fast_variants(int* count);
   PINE_EXPERIMENT_VARIANTS(PINE_Q)                                                                                                           \
   /* PINE_GPU_FLAG_ORDER_EMBREE: closest hits in the order of the reference's EmbreeAccel; cbox-class scenes */ \
   PINE_Q(7, 18, kFAnalytic | F_LDS_SCENE | F_EMBREE, PINE_QCTX, "queue: analytic shapes/uber, scene in LDS, EmbreeAccel's order")         \
+  PINE_Q(2, 19, F_ALL | F_EMBREE, 1024, "queue: all features, walk stage, 1024 contexts, EmbreeAccel's order")                              \
   PINE_M(0, 0, kFBoxes | F_LDS_SCENE, 4, "rect+box/diffuse, scene in LDS")                                                                  \
   PINE_M(6, 1, kFAnalytic | F_LDS_SCENE, 2, "analytic shapes/uber, scene in LDS")                                                           \
   PINE_M(6, 2, kFAnalytic, 2, "analytic shapes/uber")                                                                                       \
