@@ -2249,9 +2249,12 @@ inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 // common/math/vec3fa.h:122-144 (AVX2 branch): r = RCPPS(a); r + r * (1 - a * r), both steps fused
 inline float rcp_nr(float a) {
   const uint32_t u = f2u(a);
-  const int e = int((u >> 23) & 0xffu);                                            // (zero_fix keeps |a| >= 1e-18: normal numbers only)
+  const int e = int((u >> 23) & 0xffu);                                            // (zero_fix keeps |a| >= 1e-18; the triangle test's |den| may be anything)
   const uint32_t t = kRcppsTable[(u >> 12) & 0x7ffu];                              // estimate for the mantissa in [1, 2): in (0.5, 1]
-  const float r = u2f((u & 0x80000000u) | ((((t >> 23) & 0xffu) + 127u - uint32_t(e)) << 23) | (t & 0x7fffffu));
+  const int re = int((t >> 23) & 0xffu) + 127 - e;
+  const float r = e == 0 || re >= 255 ? std::copysign(kInf, a)                     // RCPPS: zero and denormal operands give infinity,
+                  : re <= 0           ? std::copysign(0.0f, a)                     //        results below the normal range are flushed to zero
+                                      : u2f((u & 0x80000000u) | (uint32_t(re) << 23) | (t & 0x7fffffu));
   const float h = std::fmaf(-a, r, 1.0f);
   return std::fmaf(r, h, r);
 }
@@ -2438,6 +2441,41 @@ struct Tree {
     root = recurse(all, 1);
   }
 };
+// Meshes are Embree TRIANGLE geometry (embree.cpp:76-87): a BVH8 of Triangle4 blocks (kernels/common/scene.cpp:205-214, build
+// quality HIGH) tested by TriangleMIntersector1Moeller<4, true> -- MoellerTrumboreIntersector1<4>::intersectEdge + finalize
+// (kernels/geometry/triangle_intersector_moeller.h:66-140, :29-37; Triangle4 keeps v0, e1 = v0 - v1, e2 = v2 - v0,
+// geometry/triangle.h) -- as the AVX2 build computes it: fused cross / dot products (common/math/vec3.h), the same RCPPS Newton
+// step for 1 / |den|.  The four lanes of a block are independent; this is one lane.  Which triangles Embree's own hierarchy
+// (spatial splits: not restated) hands to the test cannot change the closest hit: only an exact tie in t is decided by it.
+struct TriHit {
+  float t, u, v;
+  float ng[3];
+};
+inline bool tri_test(const Ray& ray, vec3 a, vec3 b, vec3 c, float tnear, float tfar, TriHit& h) {
+  auto cross_f = [](const float* x, const float* y, float* r) {  // (msub(a.y, b.z, a.z * b.y), msub(a.z, b.x, a.x * b.z), msub(a.x, b.y, a.y * b.x))
+    r[0] = std::fmaf(x[1], y[2], -(x[2] * y[1]));
+    r[1] = std::fmaf(x[2], y[0], -(x[0] * y[2]));
+    r[2] = std::fmaf(x[0], y[1], -(x[1] * y[0]));
+  };
+  auto dot_f = [](const float* x, const float* y) { return std::fmaf(x[0], y[0], std::fmaf(x[1], y[1], x[2] * y[2])); };
+  const float v0[3] = {a.x, a.y, a.z}, e1[3] = {a.x - b.x, a.y - b.y, a.z - b.z}, e2[3] = {c.x - a.x, c.y - a.y, c.z - a.z};
+  const float O[3] = {ray.o.x, ray.o.y, ray.o.z}, D[3] = {ray.d.x, ray.d.y, ray.d.z};
+  float ng[3], R[3];
+  cross_f(e2, e1, ng);
+  const float C[3] = {v0[0] - O[0], v0[1] - O[1], v0[2] - O[2]};
+  cross_f(C, D, R);
+  const float den = dot_f(ng, D), abs_den = std::fabs(den);
+  const uint32_t sgn = f2u(den) & 0x80000000u;
+  const float U = u2f(f2u(dot_f(R, e2)) ^ sgn), V = u2f(f2u(dot_f(R, e1)) ^ sgn);
+  if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= abs_den)) return false;
+  const float T = u2f(f2u(dot_f(ng, C)) ^ sgn);
+  if (!(abs_den * tnear < T && T <= abs_den * tfar)) return false;
+  const float r = rcp_nr(abs_den);
+  h.t = T * r, h.u = U * r, h.v = V * r;
+  h.ng[0] = ng[0], h.ng[1] = ng[1], h.ng[2] = ng[2];
+  return true;
+}
+
 // BVHNIntersector1<8, BVH_AN1, false, ...>::intersect (kernels/bvh/bvh_intersector1.cpp:30-107): `leaf(geometry index)` is
 // the user callback; it reads and may shorten ray.tmax.
 template <class Leaf>
@@ -2652,7 +2690,13 @@ struct Scene {
       if (ray.tmax < 0.0f) return true;
       for (size_t li = 0; li < lbvh.size(); li++) {
         const Mesh& m = geometries[indices[li]].as<Mesh>();
-        if (lbvh[li]->any_hit(ray, [&](const Ray& rr, int idx) { return m.hit(rr, idx); })) return true;
+        if (lbvh[li]->any_hit(ray, [&](const Ray& rr, int idx) {
+              vec3 a, b, c;
+              m.face(size_t(idx), a, b, c);
+              embree_order::TriHit h;
+              return embree_order::tri_test(rr, a, b, c, std::max(rr.tmin, 0.0f), rr.tmax, h);
+            }))
+          return true;
       }
       return embree_order::occluded(etree, ray, [&](int gi) { return geometries[size_t(gi)].hit(Ray(ray.o, ray.d, ray.tmin, ray.tmax)); });
     }
@@ -2765,12 +2809,19 @@ bool Scene::intersect_embree(Ray& ray, SurfaceInteraction& it) const {
   using namespace embree_order;
   uint32_t geom_index = 0, prim_index = 0;
   bool hit = false;
+  TriHit th{};
+  const float tnear = std::max(ray.tmin, 0.0f);
   for (size_t li = 0; li < lbvh.size(); li++) {
     const Mesh& mm = geometries[indices[li]].as<Mesh>();
-    if (lbvh[li]->closest(ray, [&](Ray& rr, int idx) {
-          bool hh = mm.intersect(rr, idx);
-          if (hh) prim_index = idx;
-          return hh;
+    if (lbvh[li]->closest(ray, [&](Ray& rr, int idx) {  // (pine's per-mesh BVH only decides which triangles are looked at)
+          vec3 a, b, c;
+          mm.face(size_t(idx), a, b, c);
+          TriHit h;
+          if (!tri_test(rr, a, b, c, tnear, rr.tmax, h)) return false;
+          rr.tmax = h.t;
+          th = h;
+          prim_index = uint32_t(idx);
+          return true;
         }))
       geom_index = indices[li], hit = true;
   }
@@ -2785,8 +2836,23 @@ bool Scene::intersect_embree(Ray& ray, SurfaceInteraction& it) const {
   if (hit) {
     const Geometry& g = geometries[geom_index];
     it.geom = int(geom_index);
-    if (g.kind == S_MESH) g.as<Mesh>().compute_surface_info(ray(), it, prim_index);
-    else g.compute_surface_info(ray(), it);
+    if (g.kind == S_MESH) {  // embree.cpp:233-247: position, normal and texcoord from Embree's barycentrics and geometric normal
+      const Mesh& m = g.as<Mesh>();
+      vec3 v0, v1, v2;
+      m.face(prim_index, v0, v1, v2);
+      it.p = lerp3(th.u, th.v, v0, v1, v2);
+      const uint32_t i0 = m.indices[3 * prim_index], i1 = m.indices[3 * prim_index + 1], i2 = m.indices[3 * prim_index + 2];
+      if (!m.normals.empty()) it.n = normalize(lerp3(th.u, th.v, m.normals[i0], m.normals[i1], m.normals[i2]));
+      else it.n = normalize(vec3(th.ng[0], th.ng[1], th.ng[2]));
+      if (!m.texcoords.empty()) {
+        const vec2 a = m.texcoords[i0], b = m.texcoords[i1], c = m.texcoords[i2];
+        it.uv = vec2((1.0f - th.u - th.v) * a.x + th.u * b.x + th.v * c.x, (1.0f - th.u - th.v) * a.y + th.u * b.y + th.v * c.y);
+      } else {
+        it.uv = vec2(th.u, th.v);
+      }
+    } else {
+      g.compute_surface_info(ray(), it);
+    }
   }
   return hit;
 }
@@ -3476,6 +3542,24 @@ int oracle_embree_order(const float* boxes, int n, const float* ray8, const floa
   *tfar = ray.tmax;
   return calls;
 }
+// test hook (tests/test_embree_order.py): Embree's triangle test as restated, over a triangle list in index order (closest hit; the
+// fixture tests/golden/embree_triangles.npz holds the REAL Embree's answers): per ray 7 floats -- prim (-1: miss), t, u, v, Ng
+int oracle_embree_triangles(const float* verts, const uint32_t* idx, int nt, const float* rays, int64_t nrays, float* out) {
+  for (int64_t i = 0; i < nrays; i++) {
+    const float* q = rays + i * 8;
+    Ray ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
+    embree_order::TriHit best{};
+    int prim = -1;
+    for (int t = 0; t < nt; t++) {
+      auto vtx = [&](uint32_t k) { return vec3(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2]); };
+      embree_order::TriHit h;
+      if (embree_order::tri_test(ray, vtx(idx[3 * t]), vtx(idx[3 * t + 1]), vtx(idx[3 * t + 2]), std::max(ray.tmin, 0.0f), ray.tmax, h)) ray.tmax = h.t, best = h, prim = t;
+    }
+    float* o = out + i * 7;
+    o[0] = float(prim), o[1] = ray.tmax, o[2] = best.u, o[3] = best.v, o[4] = best.ng[0], o[5] = best.ng[1], o[6] = best.ng[2];
+  }
+  return 0;
+}
 // test hook: the hierarchy of order mode "embree" over n boxes, one line of 8 child words per node in creation order (>= 0 a node,
 // < 0 the complement of a box index, INT32_MIN unused), preceded by the root's child word -> words written, -1 when cap is too small
 int oracle_embree_tree(const float* boxes, int n, int* words, int cap) {
@@ -3508,18 +3592,39 @@ int oracle_embree_traverse(const char* pscene, const float* rays, int64_t nrays,
       g_order_mode = keep;
     }
     int n = 0, hit_geom = -1;
-    for (size_t li = 0; li < scene.lbvh.size(); li++) {
-      if (1 + n < cap) o[1 + n] = uint32_t(scene.indices[li]);
-      n++;
-      const Mesh& mm = scene.geometries[size_t(scene.indices[li])].as<Mesh>();
-      if (scene.lbvh[li]->closest(ray, [&](Ray& rr, int idx) { return mm.intersect(rr, idx); })) hit_geom = scene.indices[li];
+    {  // the answer: Scene::intersect in this order mode (meshes through Embree's triangle test)
+      const int keep = g_order_mode;
+      g_order_mode = 2;
+      Ray r2 = ray;
+      SurfaceInteraction it;
+      if (scene.intersect(r2, it)) hit_geom = it.geom;
+      g_order_mode = keep;
+      // ... and the order of the calls: the meshes, then the user primitives as the hierarchy hands them over
+      for (size_t li = 0; li < scene.lbvh.size(); li++) {
+        if (1 + n < cap) o[1 + n] = uint32_t(scene.indices[li]);
+        n++;
+      }
+      Ray r3 = ray;  // (replay with the log)
+      embree_order::TriHit th;
+      const float tnear = std::max(r3.tmin, 0.0f);
+      for (size_t li = 0; li < scene.lbvh.size(); li++) {
+        const Mesh& mm = scene.geometries[size_t(scene.indices[li])].as<Mesh>();
+        scene.lbvh[li]->closest(r3, [&](Ray& rr, int idx) {
+          vec3 a, b, c;
+          mm.face(size_t(idx), a, b, c);
+          if (!embree_order::tri_test(rr, a, b, c, tnear, rr.tmax, th)) return false;
+          rr.tmax = th.t;
+          return true;
+        });
+      }
+      embree_order::traverse(scene.etree, r3, [&](int gi) {
+        if (1 + n < cap) o[1 + n] = uint32_t(gi);
+        n++;
+        Ray r(r3.o, r3.d, r3.tmin, r3.tmax);
+        if (scene.geometries[size_t(gi)].intersect(r)) r3.tmax = r.tmax;
+      });
+      ray.tmax = r2.tmax;
     }
-    embree_order::traverse(scene.etree, ray, [&](int gi) {
-      if (1 + n < cap) o[1 + n] = uint32_t(gi);
-      n++;
-      Ray r(ray.o, ray.d, ray.tmin, ray.tmax);
-      if (scene.geometries[size_t(gi)].intersect(r)) ray.tmax = r.tmax, hit_geom = gi;
-    });
     o[0] = uint32_t(n);
     o[cap] = hit_geom >= 0 ? 1u : 0u;
     o[cap + 1] = hit_geom >= 0 ? uint32_t(hit_geom) : 0u;

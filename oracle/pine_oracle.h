@@ -41,6 +41,8 @@ void oracle_set_order(int mode);
 int oracle_embree_order(const float* boxes, int n, const float* ray8, const float* hit_t, int* ids, int cap, int* hit_id, float* tfar);
 /* ... that hierarchy itself (root word, then 8 child words per node), and the closest-hit query of mode 2 on a scene's rays */
 int oracle_embree_tree(const float* boxes, int n, int* words, int cap);
+/* ... and Embree's triangle test as restated over a triangle list (closest hit): per ray prim (-1: miss), t, u, v, Ng */
+int oracle_embree_triangles(const float* verts, const uint32_t* idx, int nt, const float* rays, int64_t nrays, float* out);
 int oracle_embree_traverse(const char* pscene, const float* rays, int64_t nrays, int cap, uint32_t* out);
 
 /* Render only the pixels of this shard (8x8 tiles dealt round-robin, the product's multi-GPU

@@ -833,7 +833,20 @@ int main(int argc, char** argv) {
     Scene scene = load_scene(argv[2]);
     int spp = atoi(argv[3]), depth = atoi(argv[4]);
     scene.camera.film().clear();
-    auto integ = PathIntegrator(Accel(BVH()), Sampler(BlueSobolSampler(spp)), UniformLightSampler(), depth);
+    const char* accel_env = getenv("PINE_REF_ACCEL");  // embree (pine_ref_embree only): the accel a .pine script's load() + PathIntegrator(sampler, n) gets
+    const bool embree = accel_env && std::string(accel_env) == "embree";
+#ifndef PINE_REF_WITH_EMBREE
+    if (embree) {
+      fprintf(stderr, "this binary was built without Embree (make -C oracle embree)\n");
+      return 2;
+    }
+#endif
+    auto integ = PathIntegrator(
+#ifdef PINE_REF_WITH_EMBREE
+        embree ? Accel(EmbreeAccel()) :
+#endif
+               Accel(BVH()),
+        Sampler(BlueSobolSampler(spp)), UniformLightSampler(), depth);
     auto t0 = std::chrono::steady_clock::now();
     integ.render(scene);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -238,7 +238,65 @@ struct TravLog {
     n++;
   }
 };
-template <bool ANY, int STRIDE = kBlock, unsigned F = 0, class StackT = int>
+// ---- PINE_GPU_FLAG_ORDER_EMBREE: arithmetic of the vendored Embree 4.3.1 as an AVX2 x86 host runs it (see scene_traverse_embree) ----
+// rcp(a) (common/math/vec3fa.h:122-144, common/simd/vfloat4_sse2.h:304-318): one fused Newton step on the RCPPS estimate, which is
+// the table's entry for the operand's top 11 mantissa bits scaled by its exponent (infinity for zero / denormal operands and
+// results beyond the range, zero for results below the normal range)
+__device__ __forceinline__ float embree_rcp(const unsigned* table, float a) {
+  const unsigned u = __float_as_uint(a);
+  const int e = int((u >> 23) & 0xffu);
+  const unsigned t = table[(u >> 12) & 0x7ffu];  // the estimate for the mantissa in [1, 2): in (0.5, 1]
+  const int re = int((t >> 23) & 0xffu) + 127 - e;
+  const unsigned sign = u & 0x80000000u;
+  const float r = __uint_as_float(e == 0 || re >= 255 ? (sign | 0x7f800000u) : re <= 0 ? sign : (sign | (unsigned(re) << 23) | (t & 0x7fffffu)));
+  return __fmaf_rn(r, __fmaf_rn(-a, r, 1.0f), r);
+}
+__device__ __forceinline__ float embree_rcp_safe(const unsigned* table, float a) {
+  return embree_rcp(table, fabsf(a) < 1e-18f ? 1e-18f : a);  // zero_fix: min_rcp_input (vec3fa.h:167-172)
+}
+// One lane of TriangleMIntersector1Moeller<4, true> (kernels/geometry/triangle_intersector_moeller.h:66-140, :29-37): meshes
+// are Embree TRIANGLE geometry under EmbreeAccel (embree.cpp:76-87), Triangle4 blocks keeping v0, e1 = v0 - v1, e2 = v2 - v0
+// (geometry/triangle.h); cross and dot products fused as common/math/vec3.h does.  -> t, the barycentrics and the geometric
+// normal EmbreeAccel::intersect builds the surface point from (embree.cpp:233-247).  Which triangles Embree's own hierarchy
+// hands to the test (spatial splits: not restated) cannot change the closest hit; only an exact tie in t is decided by it.
+__device__ __forceinline__ bool embree_tri_test(const unsigned* table, const float* v, f3 o, f3 d, float tnear, float tfar, float& t, f2& uv, f3& ng) {
+  const f3 v0 = ld3(v), e1 = v0 - ld3(v + 3), e2 = ld3(v + 6) - v0;
+  auto crossf = [](f3 a, f3 b) { return f3{__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x))}; };
+  auto dotf = [](f3 a, f3 b) { return __fmaf_rn(a.x, b.x, __fmaf_rn(a.y, b.y, a.z * b.z)); };
+  ng = crossf(e2, e1);
+  const f3 C = v0 - o, R = crossf(C, d);
+  const float den = dotf(ng, d), abs_den = fabsf(den);
+  const unsigned sgn = __float_as_uint(den) & 0x80000000u;
+  const float U = __uint_as_float(__float_as_uint(dotf(R, e2)) ^ sgn), V = __uint_as_float(__float_as_uint(dotf(R, e1)) ^ sgn);
+  if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= abs_den)) return false;
+  const float T = __uint_as_float(__float_as_uint(dotf(ng, C)) ^ sgn);
+  if (!(abs_den * tnear < T && T <= abs_den * tfar)) return false;
+  const float r = embree_rcp(table, abs_den);
+  t = T * r;
+  uv = f2{U * r, V * r};
+  return true;
+}
+// EmbreeAccel::intersect's surface point on a mesh (embree.cpp:233-247): position, normal and texcoord from Embree's barycentrics
+// and geometric normal of the winning triangle -- recomputed here from the ray (they do not depend on tfar)
+__device__ __forceinline__ void mesh_surface_info_embree(const unsigned* table, const float* tri_verts, const float* tri_attrs, int flags, int prim, f3 o, f3 d, DSurface& it) {
+  const float* v = tri_verts + size_t(prim) * 9;
+  float t = 0.0f;
+  f2 bary{0.0f, 0.0f};
+  f3 ng = mk3(0.0f);
+  (void)embree_tri_test(table, v, o, d, -1.0f, __uint_as_float(0x7f800000u), t, bary, ng);  // (the hit exists: every t passes)
+  it.p = lerp3(bary.x, bary.y, ld3(v), ld3(v + 3), ld3(v + 6));
+  it.n = normalize(ng);
+  it.uv = bary;
+  if (flags != 0) {
+    const float* a = tri_attrs + size_t(prim) * 16;
+    if (flags & 1) it.n = normalize(lerp3(bary.x, bary.y, ld3(a), ld3(a + 3), ld3(a + 6)));
+    if (flags & 2) it.uv = (1.0f - bary.x - bary.y) * f2{a[9], a[10]} + bary.x * f2{a[11], a[12]} + bary.y * f2{a[13], a[14]};
+  }
+}
+
+// (EMB: Embree's triangle test instead of pine's -- the scene queries of the F_EMBREE variants; the BSSRDF walk's queries against
+//  the mesh's own ShapeBVH are pine's whatever the accel)
+template <bool ANY, int STRIDE = kBlock, unsigned F = 0, class StackT = int, bool EMB = false>
 __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh, DRay& ray,
                                               const DRayOct& oct, StackT* stack, int sp0, int& prim_out, TravLog* log = nullptr) {
   bool hit = false;
@@ -249,7 +307,17 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
       int tri;
       fetch_triangle<F>(S, i, v, tri);
       if (log) log->put(0x40000000u | unsigned(tri - bvh.prim_base));  // (the index within its mesh, as the reference counts)
-      if (ANY) {
+      if constexpr (EMB) {
+        float t;
+        f2 uv;
+        f3 ng;
+        if (embree_tri_test(S.rcpps, v, ray.o, ray.d, fmaxf(ray.tmin, 0.0f), ray.tmax, t, uv, ng)) {
+          if (ANY) return true;
+          ray.tmax = t;
+          hit = true;
+          prim_out = tri;
+        }
+      } else if (ANY) {
         if (tri_hit(v, ray)) return true;
       } else if (tri_intersect(v, ray)) {
         hit = true;
@@ -316,13 +384,6 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
 // triangle accel precedes the user-geometry accel, kernels/common/scene.cpp:741-755) with pine's triangle tests.
 // tests/test_embree_order.py, tests/test_gpu_parity.py: the films of
 // the real reference built with EmbreeAccel, bit for bit.
-__device__ __forceinline__ float embree_rcp_safe(const unsigned* table, float a) {
-  if (fabsf(a) < 1e-18f) a = 1e-18f;  // zero_fix: min_rcp_input
-  const unsigned u = __float_as_uint(a);
-  const unsigned t = table[(u >> 12) & 0x7ffu];  // the estimate for the mantissa in [1, 2): in (0.5, 1]
-  const float r = __uint_as_float((u & 0x80000000u) | ((((t >> 23) & 0xffu) + 127u - ((u >> 23) & 0xffu)) << 23) | (t & 0x7fffffu));
-  return __fmaf_rn(r, __fmaf_rn(-a, r, 1.0f), r);
-}
 template <unsigned F, int STRIDE, class StackT>
 __device__ __forceinline__ bool scene_traverse_embree(const SceneView& S, DRay& ray, StackT* stack, int& geom_out, int& prim_out, TravLog* log) {
   bool hit = false;
@@ -345,7 +406,7 @@ __device__ __forceinline__ bool scene_traverse_embree(const SceneView& S, DRay& 
       if constexpr (F & F_MESH) {
         const DRayOct oct = make_oct(ray);
         int prim = 0;
-        if (mesh_traverse<false, STRIDE, F>(S, S.bvhs[as_int(sh->f[2])], ray, oct, stack, S.stack_top, prim, log)) {
+        if (mesh_traverse<false, STRIDE, F, StackT, true>(S, S.bvhs[as_int(sh->f[2])], ray, oct, stack, S.stack_top, prim, log)) {
           hit = true;
           geom_out = word;
           prim_out = prim;
@@ -438,7 +499,7 @@ __device__ __forceinline__ bool scene_occluded_embree(const SceneView& S, const 
       if (log) log->put(unsigned(sh->kind & kPrimIndexMask));
       const DRayOct oct = make_oct(ray);
       int prim = 0;
-      if (mesh_traverse<true, STRIDE, F>(S, S.bvhs[as_int(sh->f[2])], ray, oct, stack, S.stack_top, prim, log)) return true;
+      if (mesh_traverse<true, STRIDE, F, StackT, true>(S, S.bvhs[as_int(sh->f[2])], ray, oct, stack, S.stack_top, prim, log)) return true;
     }
   if (S.etree_root == kEmbreeNoChild) return false;
   const float rdx = embree_rcp_safe(S.rcpps, ray.d.x), rdy = embree_rcp_safe(S.rcpps, ray.d.y), rdz = embree_rcp_safe(S.rcpps, ray.d.z);
@@ -1007,8 +1068,10 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
       const f3 ph = ray_o + ray_tmax * ray_d;
       bool on_mesh = false;
       if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
-      if (on_mesh) mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), prim, ph, it);
-      else shape_surface_info<F>(shape, ph, it);
+      if (on_mesh) {
+        if constexpr (F & F_EMBREE) mesh_surface_info_embree(V.rcpps, V.tri_verts, V.tri_attrs, as_int(shape->f[4]), prim, ray_o, ray_d, it);
+        else mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), prim, ph, it);
+      } else shape_surface_info<F>(shape, ph, it);
       if (mat->kind == MAT_EMISSIVE) {  // path.cpp:83-87
         Lo = mk3(1.0f) * material_le(mat, it.n, -ray_d);
         if (!st.is_delta()) {

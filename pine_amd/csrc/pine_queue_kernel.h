@@ -860,8 +860,10 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
           const f3 ph = ray_o + ray_tmax * ray_d;
           bool on_mesh = false;
           if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
-          if (on_mesh) mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), prim, ph, it);
-          else shape_surface_info<F>(shape, ph, it);
+          if (on_mesh) {
+            if constexpr (F & F_EMBREE) mesh_surface_info_embree(V.rcpps, V.tri_verts, V.tri_attrs, as_int(shape->f[4]), prim, ray_o, ray_d, it);
+            else mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), prim, ph, it);
+          } else shape_surface_info<F>(shape, ph, it);
         }
         const f3 wi = -ray_d;
         m3 l2w = coordinate_system(it.n);
@@ -1359,8 +1361,10 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
               const f3 ph = ray_o + ray_tmax * ray_d;
               bool on_mesh = false;
               if constexpr (F & F_MESH) on_mesh = shape->kind == SHAPE_MESH;
-              if (on_mesh) mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), int(cstu[CF_PRIM * kQCtx + id]), ph, it);
-              else shape_surface_info<F>(shape, ph, it);
+              if (on_mesh) {
+                if constexpr (F & F_EMBREE) mesh_surface_info_embree(V.rcpps, V.tri_verts, V.tri_attrs, as_int(shape->f[4]), int(cstu[CF_PRIM * kQCtx + id]), ray_o, ray_d, it);
+                else mesh_surface_info(V.tri_verts, V.tri_attrs, as_int(shape->f[4]), int(cstu[CF_PRIM * kQCtx + id]), ph, it);
+              } else shape_surface_info<F>(shape, ph, it);
               Lo = mk3(1.0f) * material_le(mat, it.n, -ray_d);
               if (!st.is_delta()) {
                 lp_valid = true;

@@ -1938,32 +1938,16 @@ Interp::Interp() {
     prm.shard_rank = 0;
     prm.shard_world = 1;
     prm.sampler = p->sampler;
-    // The accel decides the ORDER closest hits are found in, which a few shapes can see (the scaled Box(AABB, mat4),
-    // bbox.cpp:149-171; Plane's finite bounds, Line, Cylinder).  Embree(): the order of the reference's EmbreeAccel, restated
-    // from the vendored Embree (PINE_GPU_FLAG_ORDER_EMBREE).  BVH(): pine-BVH order.  The two-argument constructor is
-    // `PathIntegrator(EmbreeAccel(), sampler, UniformLightSampler(), n)` in the reference (program_context.cpp:79-81), so a
-    // script that uses it -- scenes/cbox.pine does -- gets what it gets from real pine: EmbreeAccel's order, for every scene
-    // without meshes.  A scene WITH meshes renders in pine-BVH order: under real Embree a mesh's triangles go through Embree's
-    // own intersector, which nothing here restates, so there is no EmbreeAccel image to reproduce -- and the fixtures of the glTF
-    // import are the reference's BVH renders; if such a scene also has a transformed Box it says so once.
-    // $PINE_PRL_ACCEL=bvh | embree (pine-mi355x --accel) decides for the two-argument form explicitly.
+    // The accel decides WHICH shapes a query asks, in which ORDER and with which arithmetic for triangles -- which a few shapes
+    // can see (the scaled Box(AABB, mat4), bbox.cpp:149-171; Plane's finite bounds, Line, Cylinder) and every mesh does (Embree's
+    // own triangle test).  Embree(): the reference's EmbreeAccel, restated from the vendored Embree (PINE_GPU_FLAG_ORDER_EMBREE).
+    // BVH(): pine's own BVH.  The two-argument constructor is `PathIntegrator(EmbreeAccel(), sampler, UniformLightSampler(), n)`
+    // in the reference (program_context.cpp:79-81), so a script that uses it -- scenes/cbox.pine does -- gets what it gets from
+    // real pine.  $PINE_PRL_ACCEL=bvh | embree (pine-mi355x --accel) decides for the two-argument form explicitly.
     int accel = p->accel;
     if (accel == 0) {
       const char* e = getenv("PINE_PRL_ACCEL");
-      if (e && std::string(e) == "embree") accel = 2;
-      else if (e && std::string(e) == "bvh") accel = 1;
-      else {
-        const std::string text = describe_scene(s->h);
-        const bool meshes = text.find("shape mesh") != std::string::npos;
-        accel = meshes ? 1 : 2;
-        static bool said = false;
-        if (accel == 1 && !said && text.find("shape obb ") != std::string::npos) {
-          said = true;
-          fprintf(stderr, "[pine-mi355x] note: this scene has a transformed Box(AABB, mat4), whose image depends on the accel's test order, and "
-                          "meshes: PathIntegrator(sampler, n) renders it in pine-BVH order (Accel(BVH())), not in the order of real pine's "
-                          "default EmbreeAccel.\n");
-        }
-      }
+      accel = e && std::string(e) == "bvh" ? 1 : 2;
     }
     if (accel == 2) prm.flags |= PINE_GPU_FLAG_ORDER_EMBREE;
     f->pixels.assign(size_t(f->w) * f->h * 4, 0.0f);

@@ -58,13 +58,17 @@ EMBREE_FILM_NAMES = ["embree_cbox_committed_64_s16_d4", "embree_cbox_readme_64_s
 # ... and films of the same build on scenes with more primitives than one BVH8 node, with the other order-dependent shapes
 # (Plane's finite bounds, Line, Cylinder), with many primitives: what PINE_GPU_FLAG_ORDER_EMBREE must render bit for bit
 EMBREE_MORE_FILM_NAMES = ["embree_clutter20_48_s16_d5", "embree_clutter63_48_s16_d5", "embree_xshapes_48_s16_d5",
-                          "embree_lights_zoo_48_s16_d6", "embree_classic_cones12_90x45_s16_d6"]
+                          "embree_lights_zoo_48_s16_d6", "embree_classic_cones12_90x45_s16_d6",
+                          "embree_sss_48_s32_d8", "embree_mesh_glossy_48_s32_d6"]  # (meshes: Embree's own triangle test)
 
 
 def embree_scene(name):
     """The scene a tests/golden/film_embree_* fixture was rendered from (tools/make_golden.py EMBREE_FILMS)."""
+    import pine_amd as pa
     from pine_amd import scenes
-    return {"embree_cbox_readme_64_s16_d4": lambda: scenes.cbox((64, 64), "readme"),
+    return {"embree_sss_48_s32_d8": lambda: scenes.sss((48, 48), 1),
+            "embree_mesh_glossy_48_s32_d6": lambda: scenes.sss((48, 48), 2, skin=pa.Glossy([0.9, 0.5, 0.3], 0.15), emissive_mesh=True),
+            "embree_cbox_readme_64_s16_d4": lambda: scenes.cbox((64, 64), "readme"),
             "embree_cbox_committed_64_s16_d4": lambda: scenes.cbox((64, 64), "committed"),
             "embree_cbox_readme_64_s256_d8": lambda: scenes.cbox((64, 64), "readme"),
             "embree_cbox_rect_readme_64_s64_d5": lambda: scenes.cbox((64, 64), "readme", False),

@@ -76,8 +76,27 @@ def test_product_hierarchy_is_the_oracles(oracle):
     assert leaves == [0, 2], leaves  # the infinite and the inverted box are not in the hierarchy
 
 
+@pytest.mark.parametrize("c", range(3))
+def test_restated_triangle_test_equals_the_real_embree(oracle, c):
+    """Meshes are Embree triangle geometry under EmbreeAccel: tests/golden/embree_triangles.npz holds the REAL Embree's closest hit --
+    primitive, t, barycentrics, geometric normal -- for 200 rays on each of an icosphere, a soup of random triangles with slivers,
+    and large far-away triangles (tools/embree_order_check.py --triangles: 60 000 rays, 0 differ; oracle/embree_tri_probe.cpp)."""
+    z = np.load(os.path.join(GOLDEN, "embree_triangles.npz"))
+    verts, idx, rays, want = z[f"verts{c}"], z[f"idx{c}"], z[f"rays{c}"], z[f"want{c}"]
+    lib = oracle.lib()
+    lib.oracle_embree_triangles.restype = C.c_int
+    got = np.zeros((len(rays), 7), np.float32)
+    lib.oracle_embree_triangles(np.ascontiguousarray(verts, np.float32).ctypes.data_as(C.c_void_p), np.ascontiguousarray(idx, np.uint32).ctypes.data_as(C.c_void_p),
+                                len(idx), np.ascontiguousarray(rays, np.float32).ctypes.data_as(C.c_void_p), C.c_int64(len(rays)), got.ctypes.data_as(C.c_void_p))
+    hit = want[:, 0] >= 0
+    assert hit.sum() >= 100
+    assert (got[:, 0] == want[:, 0]).all()
+    assert (got[:, 1].view(np.uint32) == want[:, 1].view(np.uint32)).all()  # tfar
+    assert (got[hit][:, 2:].view(np.uint32) == want[hit][:, 2:].view(np.uint32)).all()  # u, v, Ng
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["clutter63", "xshapes", "cones12", "cbox"])
+@pytest.mark.parametrize("which", ["clutter63", "xshapes", "cones12", "cbox", "mesh"])
 def test_device_traversal_hands_the_shapes_over_in_the_oracles_order(oracle, which):
     """The device's closest-hit query in EmbreeAccel's order, ray by ray, against the oracle's: the geometry indices handed to their
     tests, the winner and its distance -- 1500 camera-like, scene-crossing and short rays per scene."""
@@ -86,7 +105,8 @@ def test_device_traversal_hands_the_shapes_over_in_the_oracles_order(oracle, whi
     from pine_amd import scenes, _lib
     from make_golden import bvh_rays
     sc = {"clutter63": lambda: scenes.cbox_clutter((48, 48), 55, 62), "xshapes": lambda: scenes.xshapes_zoo((48, 48)),
-          "cones12": lambda: scenes.classic_cones((90, 45), 12), "cbox": lambda: scenes.cbox((64, 64), "readme")}[which]()
+          "cones12": lambda: scenes.classic_cones((90, 45), 12), "cbox": lambda: scenes.cbox((64, 64), "readme"),
+          "mesh": lambda: scenes.sss((48, 48), 2, emissive_mesh=True)}[which]()
     rays = np.ascontiguousarray(bvh_rays(sc, 1500, 5), np.float32)
     cap = 200
     n = len(rays)

@@ -2,6 +2,8 @@
 """usage (this container: needs oracle/_ref/embree_probe, see oracle/embree_probe.cpp; `make -C oracle embree probe`):
   tools/embree_order_check.py [scenes] [rays]     compare, print the count of differing rays
   tools/embree_order_check.py --fixture           (re)write tests/golden/embree_order.npz: 14 box sets x 48 rays with REAL Embree's answers
+  tools/embree_order_check.py --triangles [n]     Embree's triangle test (oracle/embree_tri_probe.cpp) against the restated one on n rays
+                                                  per mesh, and (re)write tests/golden/embree_triangles.npz (600 rays of it)
 The order in which REAL Embree (the vendored 4.3.1, built here) calls the user callback against the order the restatement
 (oracle order mode "embree": builder + traverser) produces, ray by ray: random box sets of 1 .. 400 primitives, rays with and
 without reported hits.  Prints the number of rays whose call sequence, hit primitive or final tfar differ."""
@@ -77,9 +79,66 @@ def fixture():
     print(path, os.path.getsize(path), "bytes")
 
 
+def tri_probe(verts, idx, rays):
+    text = f"{len(verts)}\n" + "\n".join(hexf(v) for v in verts) + f"\n{len(idx)}\n" + "\n".join(" ".join(str(int(i)) for i in t) for t in idx) + \
+           f"\n{len(rays)}\n" + "\n".join(hexf(r) for r in rays) + "\n"
+    out = subprocess.run([PROBE.replace("embree_probe", "embree_tri_probe")], input=text, capture_output=True, text=True, check=True).stdout.splitlines()
+    return np.array([[float(int(l.split()[0]))] + [float.fromhex(x) for x in l.split()[1:7]] for l in out], np.float32)
+
+
+def tri_mine(verts, idx, rays):
+    lib = oracle.lib()
+    lib.oracle_embree_triangles.restype = C.c_int
+    out = np.zeros((len(rays), 7), np.float32)
+    idx32 = np.ascontiguousarray(idx, np.uint32)
+    lib.oracle_embree_triangles(np.ascontiguousarray(verts, np.float32).ctypes.data_as(C.c_void_p), idx32.ctypes.data_as(C.c_void_p), len(idx),
+                                np.ascontiguousarray(rays, np.float32).ctypes.data_as(C.c_void_p), C.c_int64(len(rays)), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def triangles():
+    from pine_amd import scenes
+    n = int(sys.argv[sys.argv.index("--triangles") + 1]) if len(sys.argv) > sys.argv.index("--triangles") + 1 else 20000
+    rng = np.random.default_rng(21)
+    data, bad = {}, 0
+    for c in range(3):
+        if c == 0:    # an icosphere: shared edges and vertices
+            v, f = scenes.icosphere(2, 0.8, (0.0, 0.0, 0.0))
+            verts, idx = np.asarray(v, np.float32).reshape(-1, 3), np.asarray(f).reshape(-1, 3)
+        elif c == 1:  # a soup of random triangles, slivers among them
+            verts = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+            verts[::7] *= np.float32(1e-3)
+            idx = rng.integers(0, 300, (200, 3))
+            idx = idx[(idx[:, 0] != idx[:, 1]) & (idx[:, 1] != idx[:, 2]) & (idx[:, 0] != idx[:, 2])]
+        else:         # large and far: big coordinates, tiny denominators
+            verts = (rng.uniform(-1, 1, (120, 3)) * [100, 1e-2, 100] + [0, 5, 0]).astype(np.float32)
+            idx = rng.integers(0, 120, (80, 3))
+            idx = idx[(idx[:, 0] != idx[:, 1]) & (idx[:, 1] != idx[:, 2]) & (idx[:, 0] != idx[:, 2])]
+        o = rng.uniform(-2, 2, (n, 3)) * ([1, 1, 1] if c < 2 else [50, 1, 50]) + ([0, 0, 0] if c < 2 else [0, 8, 0])
+        t = rng.uniform(-1, 1, (n, 3)) * ([0.8, 0.8, 0.8] if c < 2 else [100, 0.01, 100]) + ([0, 0, 0] if c < 2 else [0, 5, 0])
+        d = t - o
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([o, d, np.zeros((n, 1)), np.where(rng.uniform(size=(n, 1)) < 0.3, rng.uniform(0.5, 3.0, (n, 1)), 3.4028235e38)], 1).astype(np.float32)
+        a, b = tri_probe(verts, idx, rays), tri_mine(verts, idx, rays)
+        hit = a[:, 0] >= 0
+        diff = (a[:, 0] != b[:, 0]) | (a[:, 1].view(np.uint32) != b[:, 1].view(np.uint32)) | (hit & (a[:, 2:].view(np.uint32) != b[:, 2:].view(np.uint32)).any(axis=1))
+        print(f"mesh {c}: {len(idx)} triangles, {n} rays, {int(hit.sum())} hits, {int(diff.sum())} differ", flush=True)
+        for k in np.argwhere(diff)[:3, 0]:
+            print("  ", rays[k].tolist(), a[k].tolist(), b[k].tolist())
+        bad += int(diff.sum())
+        keep = np.concatenate([np.argwhere(hit)[:150, 0], np.argwhere(~hit)[:50, 0]])
+        data[f"verts{c}"], data[f"idx{c}"], data[f"rays{c}"], data[f"want{c}"] = verts, idx.astype(np.uint32), rays[keep], a[keep]
+    path = os.path.join(ROOT, "tests", "golden", "embree_triangles.npz")
+    np.savez_compressed(path, **data)
+    print(path, os.path.getsize(path), "bytes;", bad, "rays differ")
+    return 1 if bad else 0
+
+
 def main():
     if "--fixture" in sys.argv:
         return fixture()
+    if "--triangles" in sys.argv:
+        return triangles()
     scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     rng = np.random.default_rng(5)

@@ -2,8 +2,8 @@
    python tools/fuzz_scenes.py ref N   -- here (CPU): the oracle restatement against the real reference binary
    python tools/fuzz_scenes.py gpu N   -- on the GPU box: the HIP path against the oracle
    optional: VARIETY (1 | 2), the first SEED, and ORDER ("pine" | "embree": EmbreeAccel's order -- `ref`: the oracle's order mode
-   "embree" against the real reference built WITH Embree (oracle/_ref/pine_ref_embree; scenes with meshes are skipped: Embree's own
-   triangle intersector is not restated); `gpu`: PINE_GPU_FLAG_ORDER_EMBREE against the oracle's)
+   "embree" against the real reference built WITH Embree (oracle/_ref/pine_ref_embree); `gpu`: PINE_GPU_FLAG_ORDER_EMBREE against
+   the oracle's)
 Every film must match bit for bit."""
 import sys, os, subprocess, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,9 +32,6 @@ def main():
             print(seed, "scene rejected:", str(e)[:60])
             continue
         ps = sc.describe()
-        if mode == "ref" and order == "embree" and "\nshape mesh" in ps:
-            print(seed, "skipped: meshes")
-            continue
         w, h = sc.camera.film().size
         ref, _ = oracle.render(ps, (w, h), spp, depth, sampler=sampler, order=order)
         if mode == "ref":
