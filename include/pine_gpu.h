@@ -273,9 +273,10 @@ typedef struct {
                                     restated from the vendored Embree 4.3.1's BVH8 builder and single-ray traverser as an AVX2 x86 host runs
                                     them (pine_amd/csrc/pine_embree_order.h, scene_traverse_embree); the films of the real reference built
                                     with EmbreeAccel are reproduced bit for bit (tests/golden/film_embree_*, any number of shapes), without
-                                    the flag (the default, and the parity gate) those of Accel(BVH()).  Meshes are Embree's own triangle
-                                    geometry there, whose intersector is NOT restated: they are tested first, with pine's triangle tests.
-                                    Not with _FAST. */
+                                    the flag (the default, and the parity gate) those of Accel(BVH()).  Meshes are Embree triangle
+                                    geometry there: they are asked first, through Embree's own Moeller-Trumbore test and barycentrics
+                                    (restated too); only an exact tie in t between coplanar triangles of different meshes is decided by
+                                    Embree's own triangle hierarchy, which is not.  Not with _FAST. */
 #define PINE_GPU_FLAG_ORDER_NEAREST PINE_GPU_FLAG_ORDER_EMBREE /* (the name of this flag before the order was Embree's own for any shape count) */
 #define PINE_GPU_FLAG_VERTEX_LOG 0x200 /* test hook: choose the kernel variant compiled with the per-vertex log (pine_gpu_plan_vertex_log) */
 

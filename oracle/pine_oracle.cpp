@@ -2803,8 +2803,8 @@ bool Scene::intersect_nearest(Ray& ray, SurfaceInteraction& it) const {
 }
 
 // Order mode "embree": BVHNIntersector1<8, BVH_AN1, false, ...>::intersect (kernels/bvh/bvh_intersector1.cpp:30-107) over the
-// tree above.  Meshes are Embree triangle geometry with Embree's own intersector, which is NOT restated: they are tested first
-// (the triangle accel precedes the user-geometry accel, kernels/common/scene.cpp:741-755) through pine's triangle tests.
+// tree above.  Meshes are Embree triangle geometry: they are asked first (the triangle accel precedes the user-geometry accel,
+// kernels/common/scene.cpp:741-755) through Embree's own triangle test (tri_test above).
 bool Scene::intersect_embree(Ray& ray, SurfaceInteraction& it) const {
   using namespace embree_order;
   uint32_t geom_index = 0, prim_index = 0;

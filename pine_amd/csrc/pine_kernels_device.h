@@ -380,10 +380,10 @@ __device__ __forceinline__ bool mesh_traverse(const SceneView& S, const DBvh bvh
 //     networks of common/stack_item.h:54-84; more -> the stable descending insertion sort (:88-104); the nearest is descended
 //     into, the others wait on the stack with their distances (kernels/bvh/bvh_traverser1.h:310-385);
 //   * a popped entry whose distance lies beyond the closest hit so far is dropped (bvh_intersector1.cpp:77-79).
-// Meshes are Embree triangle geometry with Embree's own intersector, which is not restated: they are tested FIRST (the
-// triangle accel precedes the user-geometry accel, kernels/common/scene.cpp:741-755) with pine's triangle tests.
-// tests/test_embree_order.py, tests/test_gpu_parity.py: the films of
-// the real reference built with EmbreeAccel, bit for bit.
+// Meshes are Embree triangle geometry: they are asked FIRST (the triangle accel precedes the user-geometry accel,
+// kernels/common/scene.cpp:741-755), through Embree's own triangle test (embree_tri_test above; pine's per-mesh BVH only decides
+// which triangles are looked at).  tests/test_embree_order.py, tests/test_gpu_parity.py: the films of the real reference built
+// with EmbreeAccel, bit for bit.
 template <unsigned F, int STRIDE, class StackT>
 __device__ __forceinline__ bool scene_traverse_embree(const SceneView& S, DRay& ray, StackT* stack, int& geom_out, int& prim_out, TravLog* log) {
   bool hit = false;

@@ -119,7 +119,9 @@ def test_device_traversal_hands_the_shapes_over_in_the_oracles_order(oracle, whi
     assert (got[:, 0] < cap).all() and (want[:, 0] < cap).all()
     for k in range(n):
         cnt = int(want[k, 0])
-        assert got[k, 0] == cnt and (got[k, 1:1 + cnt] == want[k, 1:1 + cnt]).all(), (k, got[k, :cnt + 1], want[k, :cnt + 1])
+        words = got[k, 1:1 + int(got[k, 0])]
+        words = words[(words & 0x40000000) == 0]  # (the device also logs the triangles it tests inside a mesh)
+        assert len(words) == cnt and (words == want[k, 1:1 + cnt]).all(), (k, words, want[k, :cnt + 1])
     assert (got[:, cap] == want[:, cap]).all()  # hit
     hitm = want[:, cap] == 1
     assert (got[hitm, cap + 1] == want[hitm, cap + 1]).all()  # geometry
