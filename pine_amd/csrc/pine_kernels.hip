@@ -1296,9 +1296,13 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
     S.num_emesh = int(mesh_places.size());
     S.off_emesh = put(mesh_places.data(), mesh_places.size() * sizeof(int));
   }
+  // (the RCPPS estimates ride in the part of the blob that scene-in-LDS variants stage when the scene is small enough to stay one
+  //  of theirs with them -- three lookups per ray from LDS instead of L2 -- and behind it, in global memory only, otherwise)
+  const bool table_in_lds = order_embree && blob.size() + sizeof(kRcppsTable) + 64 <= 32 * 1024;
+  if (table_in_lds) S.off_rcpps = put(kRcppsTable, sizeof(kRcppsTable));
   blob.resize((blob.size() + 15) & ~size_t(15));
   S.blob_bytes = int(blob.size());
-  if (order_embree) S.off_rcpps = put(kRcppsTable, sizeof(kRcppsTable));  // (global memory only: blob_bytes is what LDS variants stage)
+  if (order_embree && !table_in_lds) S.off_rcpps = put(kRcppsTable, sizeof(kRcppsTable));
   HIP_OK(POOL_ALLOC(p->d_blob, blob.size()));
   HIP_OK(hipMemcpy(p->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (upload(p->d_tri, A.tri_verts)) return -1;

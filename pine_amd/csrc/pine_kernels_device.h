@@ -438,12 +438,25 @@ __device__ __forceinline__ bool scene_traverse_embree(const SceneView& S, DRay& 
       const float* nd = reinterpret_cast<const float*>(&S.etree[cur]);
       const int count = reinterpret_cast<const int*>(nd)[56];
       const int first = sp;
-      for (int i = 0; i < count; i++) {  // (unused slots are never entered: their planes are infinite)
-        const int tn = max(max(__float_as_int(__fmaf_rn(nd[nx + i], rdx, -ordx)), __float_as_int(__fmaf_rn(nd[8 + ny + i], rdy, -ordy))),
-                           max(__float_as_int(__fmaf_rn(nd[16 + nz + i], rdz, -ordz)), tnear));
-        const int tf = min(min(__float_as_int(__fmaf_rn(nd[(nx ^ 24) + i], rdx, -ordx)), __float_as_int(__fmaf_rn(nd[8 + (ny ^ 24) + i], rdy, -ordy))),
-                           min(__float_as_int(__fmaf_rn(nd[16 + (nz ^ 24) + i], rdz, -ordz)), tfar));
-        if (!(tn > tf)) items[sp++] = int2{reinterpret_cast<const int*>(nd)[48 + i], tn};
+      // four children at a time: the six planes of each as quads (near / far side chosen by the quad's address), the child words
+      // as one more; unused slots are never entered -- their planes are infinite -- and a second half without children is skipped
+      for (int half = 0; half < 8 && half < count; half += 4) {
+        const float4 nxq = *reinterpret_cast<const float4*>(nd + nx + half), nyq = *reinterpret_cast<const float4*>(nd + 8 + ny + half),
+                     nzq = *reinterpret_cast<const float4*>(nd + 16 + nz + half);
+        const float4 fxq = *reinterpret_cast<const float4*>(nd + (nx ^ 24) + half), fyq = *reinterpret_cast<const float4*>(nd + 8 + (ny ^ 24) + half),
+                     fzq = *reinterpret_cast<const float4*>(nd + 16 + (nz ^ 24) + half);
+        const int4 ch = *reinterpret_cast<const int4*>(nd + 48 + half);
+        auto one = [&](float px, float py, float pz, float qx, float qy, float qz, int child) {
+          const int tn = max(max(__float_as_int(__fmaf_rn(px, rdx, -ordx)), __float_as_int(__fmaf_rn(py, rdy, -ordy))),
+                             max(__float_as_int(__fmaf_rn(pz, rdz, -ordz)), tnear));
+          const int tf = min(min(__float_as_int(__fmaf_rn(qx, rdx, -ordx)), __float_as_int(__fmaf_rn(qy, rdy, -ordy))),
+                             min(__float_as_int(__fmaf_rn(qz, rdz, -ordz)), tfar));
+          if (!(tn > tf)) items[sp++] = int2{child, tn};
+        };
+        one(nxq.x, nyq.x, nzq.x, fxq.x, fyq.x, fzq.x, ch.x);
+        one(nxq.y, nyq.y, nzq.y, fxq.y, fyq.y, fzq.y, ch.y);
+        one(nxq.z, nyq.z, nzq.z, fxq.z, fyq.z, fzq.z, ch.z);
+        one(nxq.w, nyq.w, nzq.w, fxq.w, fyq.w, fzq.w, ch.w);
       }
       const int hits = sp - first;
       if (hits == 0) {
@@ -528,12 +541,23 @@ __device__ __forceinline__ bool scene_occluded_embree(const SceneView& S, const 
     }
     const float* nd = reinterpret_cast<const float*>(&S.etree[cur]);
     const int count = reinterpret_cast<const int*>(nd)[56];
-    for (int i = count - 1; i >= 0; i--) {
-      const int tn = max(max(__float_as_int(__fmaf_rn(nd[nx + i], rdx, -ordx)), __float_as_int(__fmaf_rn(nd[8 + ny + i], rdy, -ordy))),
-                         max(__float_as_int(__fmaf_rn(nd[16 + nz + i], rdz, -ordz)), tnear));
-      const int tf = min(min(__float_as_int(__fmaf_rn(nd[(nx ^ 24) + i], rdx, -ordx)), __float_as_int(__fmaf_rn(nd[8 + (ny ^ 24) + i], rdy, -ordy))),
-                         min(__float_as_int(__fmaf_rn(nd[16 + (nz ^ 24) + i], rdz, -ordz)), tfar));
-      if (!(tn > tf)) items[sp++] = reinterpret_cast<const int*>(nd)[48 + i];
+    for (int half = 0; half < 8 && half < count; half += 4) {  // (quads of planes, as in the closest-hit query)
+      const float4 nxq = *reinterpret_cast<const float4*>(nd + nx + half), nyq = *reinterpret_cast<const float4*>(nd + 8 + ny + half),
+                   nzq = *reinterpret_cast<const float4*>(nd + 16 + nz + half);
+      const float4 fxq = *reinterpret_cast<const float4*>(nd + (nx ^ 24) + half), fyq = *reinterpret_cast<const float4*>(nd + 8 + (ny ^ 24) + half),
+                   fzq = *reinterpret_cast<const float4*>(nd + 16 + (nz ^ 24) + half);
+      const int4 ch = *reinterpret_cast<const int4*>(nd + 48 + half);
+      auto one = [&](float px, float py, float pz, float qx, float qy, float qz, int child) {
+        const int tn = max(max(__float_as_int(__fmaf_rn(px, rdx, -ordx)), __float_as_int(__fmaf_rn(py, rdy, -ordy))),
+                           max(__float_as_int(__fmaf_rn(pz, rdz, -ordz)), tnear));
+        const int tf = min(min(__float_as_int(__fmaf_rn(qx, rdx, -ordx)), __float_as_int(__fmaf_rn(qy, rdy, -ordy))),
+                           min(__float_as_int(__fmaf_rn(qz, rdz, -ordz)), tfar));
+        if (!(tn > tf)) items[sp++] = child;
+      };
+      one(nxq.x, nyq.x, nzq.x, fxq.x, fyq.x, fzq.x, ch.x);
+      one(nxq.y, nyq.y, nzq.y, fxq.y, fyq.y, fzq.y, ch.y);
+      one(nxq.z, nyq.z, nzq.z, fxq.z, fyq.z, fzq.z, ch.z);
+      one(nxq.w, nyq.w, nzq.w, fxq.w, fyq.w, fzq.w, ch.w);
     }
   }
   return false;
@@ -848,6 +872,7 @@ path_trace_kernel(DeviceScene S, WorkParams W, const ulonglong2* __restrict__ ck
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
     V.etree = reinterpret_cast<const EmbreeNode*>(base + S.off_etree);
     V.emesh = reinterpret_cast<const int*>(base + S.off_emesh);
+    if (S.off_rcpps < S.blob_bytes) V.rcpps = reinterpret_cast<const unsigned*>(base + S.off_rcpps);
   } else {
     __syncthreads();  // Sobol rows staged above
     V.etree = reinterpret_cast<const EmbreeNode*>(reinterpret_cast<const char*>(S.blob) + S.off_etree);

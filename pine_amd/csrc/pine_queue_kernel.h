@@ -218,6 +218,7 @@ __device__ __forceinline__ void path_queue_body(const DeviceScene& S, const Work
     V.leaf = reinterpret_cast<const DShape*>(base + S.off_leaf) - S.top_prim_begin;
     V.etree = reinterpret_cast<const EmbreeNode*>(base + S.off_etree);
     V.emesh = reinterpret_cast<const int*>(base + S.off_emesh);
+    if (S.off_rcpps < S.blob_bytes) V.rcpps = reinterpret_cast<const unsigned*>(base + S.off_rcpps);
   } else if constexpr (F & F_LDS_REST) {
     // blob = nodes | shapes | materials | node programs | bvhs | leaf records | lights: everything after the nodes
     size_t stack_bytes = size_t(S.stack_total) * kQBlock * sizeof(StackT);
