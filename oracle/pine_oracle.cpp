@@ -3442,6 +3442,9 @@ void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int dep
     y1 = H;
   }
   int first = y0 * W, n_items = (y1 - y0) * W;
+  int trace_x = -1, trace_y = -1;  // $PINE_ORACLE_TRACE_PIXEL=x,y (tools/embree_trace_pixel.py): that pixel's accel queries on stderr
+  if (const char* e = getenv("PINE_ORACLE_TRACE_PIXEL"))
+    if (sscanf(e, "%d,%d", &trace_x, &trace_y) != 2) trace_x = trace_y = -1;
   int batch_count = std::max(threads, n_items / 64);
   int batch_size = std::max(n_items / batch_count, 1);
   std::atomic<int> global_index{0};
@@ -3464,11 +3467,7 @@ void render_impl(const Scene& scene, const uint8_t* tables, int spp_req, int dep
           if (tile % shard_world != shard_rank) continue;
         }
         sampler.start_pixel(px, py, 0);
-        {
-          int tx = -1, ty = -1;
-          const char* e = getenv("PINE_ORACLE_TRACE_PIXEL");
-          t_trace_queries = e && sscanf(e, "%d,%d", &tx, &ty) == 2 && tx == px && ty == py;
-        }
+        t_trace_queries = px == trace_x && py == trace_y;
         vec3 L(0.0f);
         for (int si = 0; si < spp; si++, sampler.start_next_sample()) {
           // g++ right-to-left: lens sample first, then pixel jitter (path.cpp:35, Appendix A2)

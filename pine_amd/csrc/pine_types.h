@@ -163,6 +163,6 @@ struct EmbreeNode {
 };
 static_assert(sizeof(EmbreeNode) == 256, "EmbreeNode is read as 16 quads");
 constexpr int kEmbreeNoChild = -2147483647 - 1;
-constexpr int kEmbreeStackEntries = 96;  // per-ray stack of scene_traverse_embree (the host checks the tree against it)
+constexpr int kEmbreeStackEntries = 192;  // per-ray stack of scene_traverse_embree (the host checks the tree against it)
 
 }  // namespace pine_gpu

@@ -64,6 +64,8 @@ def test_product_hierarchy_is_the_oracles(oracle):
     sets.append(flat)
     bad = np.array([[0, 0, 0, 1, 1, 1], [0, 0, 0, np.inf, 1, 1], [2, 0, 0, 3, 1, 1], [1, 2, 3, 0, 2, 3]], np.float32)  # infinite, inverted
     sets.append(bad)
+    x = (2.0 ** (np.arange(2000) * 0.05)).astype(np.float32)  # a geometric progression: the deepest hierarchy float32 boxes give (116 stack entries per ray)
+    sets.append(np.stack([x, x * 0, x * 0, x * np.float32(1.01), x * 0 + 1, x * 0 + 1], 1).astype(np.float32))
     rng = np.random.default_rng(77)
     for n in (7, 8, 9, 17, 65, 300, 2000):
         c = rng.uniform(-5, 5, (n, 3))
