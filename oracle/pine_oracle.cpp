@@ -3573,16 +3573,16 @@ int oracle_embree_tree(const float* boxes, int n, int* words, int cap) {
     for (int i = 0; i < 8; i++) words[k++] = nd.child[i];
   return k;
 }
-// test hook: the queries of order mode "embree" on a scene, ray by ray: per ray cap + 4 words -- [count, the geometry indices
+// test hook: the queries of order mode "embree" on a scene, ray by ray: per ray cap + 10 words -- [count, the geometry indices
 // handed to their tests in order ...] (cap words), hit, geometry, tmax bits of the closest-hit query (meshes: their word only),
-// the any-hit query's answer
+// the any-hit query's answer, the surface point and normal (bits; zero on a miss)
 int oracle_embree_traverse(const char* pscene, const float* rays, int64_t nrays, int cap, uint32_t* out) {
   Scene scene;
   if (!parse_pscene(pscene, scene)) return 2;
   scene.build_accel();
   for (int64_t i = 0; i < nrays; i++) {
     const float* q = rays + i * 8;
-    uint32_t* o = out + i * (cap + 4);
+    uint32_t* o = out + i * (cap + 10);
     Ray ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]);
     {
       const int keep = g_order_mode;
@@ -3598,6 +3598,8 @@ int oracle_embree_traverse(const char* pscene, const float* rays, int64_t nrays,
       SurfaceInteraction it;
       if (scene.intersect(r2, it)) hit_geom = it.geom;
       g_order_mode = keep;
+      const float pn[6] = {it.p.x, it.p.y, it.p.z, it.n.x, it.n.y, it.n.z};
+      for (int k = 0; k < 6; k++) o[cap + 4 + k] = hit_geom >= 0 ? embree_order::f2u(pn[k]) : 0u;
       // ... and the order of the calls: the meshes, then the user primitives as the hierarchy hands them over
       for (size_t li = 0; li < scene.lbvh.size(); li++) {
         if (1 + n < cap) o[1 + n] = uint32_t(scene.indices[li]);

@@ -18,8 +18,8 @@
 //                                        canonical pre-order stream, and for every ray the primitives BVH::intersect / BVH::hit
 //                                        test, in order, with the result (bvh.cpp:321-451, 497-548)
 //   pine_ref accelq  <scene.pscene> <rays.bin> <out.bin>   Accel::intersect and Accel::hit of the accel $PINE_REF_ACCEL names (bvh |
-//                                        embree: EmbreeAccel, pine_ref_embree only) for every ray: 4 words -- hit, geometry index,
-//                                        tmax bits, any-hit result.  The ray-level view of what a film is made of.
+//                                        embree: EmbreeAccel, pine_ref_embree only) for every ray: 10 words -- hit, geometry index,
+//                                        tmax bits, any-hit result, the surface point and normal (bits).  The ray-level view of what a film is made of.
 //   pine_ref vertices <scene.pscene> <spp> <depth> <out.bin>   per-vertex terms of every path of the film (path.cpp:42-124):
 //                                        radiance() restated around the reference's OWN intersect / light sampler / bxdf
 //                                        objects with a log; the restated loop's film is checked against render()'s
@@ -660,6 +660,12 @@ int main(int argc, char** argv) {
       memcpy(&tb, &ray.tmax, 4);
       const bool any = accel.hit(Ray(vec3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]), q[6], q[7]));
       out.push_back(hit ? 1u : 0u), out.push_back(geom), out.push_back(tb), out.push_back(any ? 1u : 0u);
+      const float pn[6] = {it.p.x, it.p.y, it.p.z, it.n.x, it.n.y, it.n.z};  // (zero on a miss)
+      for (float f : pn) {
+        uint32_t w;
+        memcpy(&w, &f, 4);
+        out.push_back(hit ? w : 0u);
+      }
     }
     write_file(argv[4], out.data(), out.size() * 4);
     printf("{\"rays\": %zu, \"accel\": \"%s\"}\n", rays.size() / 8, embree ? "embree" : "bvh");

@@ -114,7 +114,7 @@ def test_device_traversal_hands_the_shapes_over_in_the_oracles_order(oracle, whi
     n = len(rays)
     olib = oracle.lib()
     olib.oracle_embree_traverse.restype = C.c_int
-    want = np.zeros((n, cap + 4), np.uint32)
+    want = np.zeros((n, cap + 10), np.uint32)
     assert olib.oracle_embree_traverse(sc.describe().encode(), rays.ctypes.data_as(C.c_void_p), C.c_int64(n), cap, want.ctypes.data_as(C.c_void_p)) == 0
     got = np.zeros((n, 2 * cap + 5), np.uint32)
     _lib.check(_lib.lib.pine_gpu_test_traverse(sc._h, 0, rays.ctypes.data_as(_lib.c_f_p), n, 2, cap, got.ctypes.data_as(C.POINTER(C.c_uint32))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage (this container: needs oracle/_ref/pine_ref_embree): tools/embree_trace_pixel.py <fuzz-seed | gltf> <x> <y> [depth] [variety]
+"""usage (this container: needs oracle/_ref/pine_ref_embree): tools/embree_trace_pixel.py <fuzz-seed | gltf | c5_320> <x> <y> [depth] [variety]
 Where does a pixel of the restated EmbreeAccel mode part from the REAL reference built with Embree?  The oracle renders the pixel's
 row with $PINE_ORACLE_TRACE_PIXEL=x,y -- every accel query of the pixel's paths goes to stderr -- and exactly those rays are put to
 the reference's own EmbreeAccel::intersect / hit (`pine_ref_embree accelq`): the first query whose answers differ is the cause.
@@ -24,8 +24,10 @@ def scene_of(spec, variety):
         from pine_amd import gltf
         sc = gltf.load(os.path.join(ROOT, "tests", "golden", "import_test.glb"))
         return sc, 4, 5, "blue"
-    from pine_amd.scenes import random_scene
-    return random_scene(int(spec), variety=variety)
+    from pine_amd import scenes
+    if spec == "c5_320":  # BASELINE's Subsurface icosphere at a quarter of the film
+        return scenes.sss((320, 320), 3), 512, 8, "blue"
+    return scenes.random_scene(int(spec), variety=variety)
 
 
 def accelq(ps, rays):
@@ -34,15 +36,15 @@ def accelq(ps, rays):
         open(sp, "w").write(ps)
         rays.tofile(rp)
         subprocess.run([REF, "accelq", sp, rp, op], check=True, capture_output=True, env=dict(os.environ, PINE_REF_ACCEL="embree"))
-        return np.fromfile(op, np.uint32).reshape(-1, 4)
+        return np.fromfile(op, np.uint32).reshape(-1, 10)
 
 
 def mine(ps, rays, cap=64):
     lib = oracle.lib()
     lib.oracle_embree_traverse.restype = C.c_int
-    out = np.zeros((len(rays), cap + 4), np.uint32)
+    out = np.zeros((len(rays), cap + 10), np.uint32)
     assert lib.oracle_embree_traverse(ps.encode(), rays.ctypes.data_as(C.c_void_p), C.c_int64(len(rays)), cap, out.ctypes.data_as(C.c_void_p)) == 0
-    return out[:, cap:cap + 4]
+    return out[:, cap:cap + 10]
 
 
 def main():
@@ -66,9 +68,10 @@ def main():
     a, b = accelq(ps, rays), mine(ps, rays)
     bad = 0
     for k, q in enumerate(qs):
-        same = (a[k, 0] == b[k, 0] and a[k, 3] == b[k, 3] and (a[k, 0] == 0 or (a[k, 1:3] == b[k, 1:3]).all()))
+        same = (a[k, 0] == b[k, 0] and a[k, 3] == b[k, 3] and (a[k, 0] == 0 or ((a[k, 1:3] == b[k, 1:3]).all() and (a[k, 4:] == b[k, 4:]).all())))
         bad += not same
-        print(q[1], " ".join(float(v).hex() for v in rays[k]), "| embree (hit, geometry, tmax bits, any-hit)", a[k].tolist(), "| restated", b[k].tolist(), "" if same else "  <<<< differs")
+        if not same or len(qs) <= 64:
+            print(q[1], " ".join(float(v).hex() for v in rays[k]), "| embree (hit, geometry, tmax bits, any-hit, p, n)", a[k].tolist(), "| restated", b[k].tolist(), "" if same else "  <<<< differs")
     print(f"{len(qs)} queries, {bad} differ")
     return 0
 

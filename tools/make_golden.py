@@ -302,6 +302,40 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             embree_fixtures(tmp)
         return
+    if "--embree-full" in sys.argv:  # tests/golden/stats_640_embree.json: the BASELINE configs at full size by the build with EmbreeAccel
+        global REF
+        exe = os.path.join(ROOT, "oracle", "_ref", "pine_ref_embree")
+        if not os.access(exe, os.X_OK):
+            raise SystemExit("oracle/_ref/pine_ref_embree missing: make -C oracle embree")
+        REF = exe
+        os.environ["PINE_REF_ACCEL"] = "embree"
+        out = {}
+        with tempfile.TemporaryDirectory() as tmp:
+            for name, build, spp, depth in (("C1_cbox_640_s16_d4_committed", lambda: scenes.cbox((640, 640), "committed"), 16, 4),
+                                            ("C2_cbox_640_s256_d8_committed", lambda: scenes.cbox((640, 640), "committed"), 256, 8),
+                                            ("C2_cbox_640_s256_d8_readme", lambda: scenes.cbox((640, 640), "readme"), 256, 8),
+                                            ("C3_cbox_1920x1080_s1024_d8", lambda: scenes.cbox((1920, 1080), "committed"), 1024, 8),
+                                            ("C4_classic_10k_cones_720x360_s64_d6", lambda: scenes.classic_cones((720, 360), 100), 64, 6),
+                                            ("C5_sss_320_s512_d8", lambda: scenes.sss((320, 320), 3), 512, 8),
+                                            ("C5_sss_640_s512_d8", lambda: scenes.sss((640, 640), 3), 512, 8)):
+                ps, film, info = ref_film(build(), spp, depth, tmp)
+                out[name] = {"spp": spp, "depth": depth, "md5": hashlib.md5(film.tobytes()).hexdigest(),
+                             "mean_rgb": [float(x) for x in film[..., :3].mean(axis=(0, 1), dtype=np.float64)],
+                             "ref_seconds": info["seconds"], "ref_threads": info["threads"], "tie_pixels": []}
+                if name.startswith("C5"):
+                    # A closed mesh has rays through SHARED EDGES: where two triangles report the very same t, Embree's own triangle
+                    # hierarchy -- not restated -- decides which one it is (another normal, the same distance).  One query in 10^8; the
+                    # fixture carries the reference's values at the pixels where the restated mode (oracle, order "embree") differs,
+                    # as tests/golden/gltf_import.json does for its coplanar faces.
+                    from oracle import oracle
+                    mine, _ = oracle.render(ps, (film.shape[1], film.shape[0]), spp, depth, order="embree")
+                    ties = np.argwhere((mine.view(np.uint32) != film.view(np.uint32)).any(axis=2))
+                    if len(ties) > 8:
+                        raise SystemExit(f"{name}: {len(ties)} pixels differ from the Embree build: more than shared-edge ties explain")
+                    out[name]["tie_pixels"] = [[int(y), int(x)] + [float(v).hex() for v in film[y, x]] for y, x in ties]
+                print(name, {k: v for k, v in out[name].items() if k != "tie_pixels"}, "tie pixels:", len(out[name]["tie_pixels"]), flush=True)
+        json.dump(out, open(os.path.join(OUT, "stats_640_embree.json"), "w"), indent=1)
+        return
     if "--finalize-only" in sys.argv:
         with tempfile.TemporaryDirectory() as tmp:
             finalize_fixture(tmp)
