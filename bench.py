@@ -7,8 +7,10 @@ workload : --config c2 (default) = configs[1] = cbox 640x640, BlueSampler(256), 
            8-GPU workload); c4 = classic.pine + 10 000 cones 720x360, BlueSampler(64), depth 6; c5 = Subsurface icosphere in
            the Rect-only cbox 640x640, BlueSampler(512 -> 256 effective), depth 8.
 step     : one full render of that film through the library's DEFAULT path (what `PathIntegrator(sampler, n).render(scene)`
-           runs: prepass + path kernel + ordered resolve), then the film's device-to-host copy [N > 1: RCCL slab gather and
-           unpack on rank 0 first]; scene, BVH, sampler tables and work buffers are resident in HBM before the timed region.
+           runs: path kernel + ordered resolve), then the film's device-to-host copy [N > 1: RCCL slab gather and
+           unpack on rank 0 first]; scene, BVH, sampler tables, work buffers and the per-item RNG checkpoints -- a function of the
+           film partition and the sample counts alone, computed by the plan's first launch (a warm-up step) -- are resident in HBM
+           before the timed region.  `checkpoints_every_launch` is the same loop with that prepass back in every launch.
            The copy of step i runs on a second stream beside the render of step i+1 (two device films, two host films).
 kernel   : the library's default mode: the scene's own kernel from the on-disk cache, else the precompiled
            kernel while the scene's kernel compiles in the background.  The bench is a steady-state measurement: after the W
@@ -96,7 +98,8 @@ def compact_line(full):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": head["workload"][:120], "name": head["name"], "film": head["film"], "spp_effective": head["spp_effective"],
                    "max_path_length": head["max_path_length"], "parallelism": head["parallelism"], "collective": head["collective"],
-                   "kernel_mode": head["kernel_mode"][:100], "clock": "launch -> film in pinned host memory"},
+                   "kernel_mode": head["kernel_mode"][:100], "clock": "launch -> film in pinned host memory",
+                   "resident": "scene, BVH, tables, rng checkpoints"},
         "roofline": {"bound": "hbm", "achieved": _r(rl["achieved"], 5), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": _r(rl["frac"], 4),
                      "traffic": _r(rl.get("traffic"), 5), "kernel": rl["kernel"][:48], "kernel_ms": _r(rl["kernel_ms"], 5),
                      "algorithmic_bytes_per_launch": _r(rl["algorithmic_bytes_per_launch"], 6),
@@ -113,6 +116,9 @@ def compact_line(full):
     if full.get("device_resident"):
         d = full["device_resident"]
         optional.append(("device_resident", {"value": _r(d["value"], 5), "ms_per_step": _r(d["ms_per_step"], 5)}))
+    if full.get("checkpoints_every_launch") and "value" in full["checkpoints_every_launch"]:
+        d = full["checkpoints_every_launch"]
+        optional.append(("checkpoints_every_launch", {k: _r(d.get(k), 5) for k in ("value", "ms_per_step")}))
     if full.get("precompiled"):
         d = full["precompiled"]
         optional.append(("precompiled", {k: _r(d.get(k), 5) for k in ("value", "ms_per_step", "kernel_ms", "roofline_frac", "film_equals_reference")}
@@ -659,6 +665,18 @@ def main():
             except Exception as e:  # report, keep the headline
                 full["device_resident"] = None
                 full["errors"] = full.get("errors", []) + ["device_resident/cold: " + str(e)[:300]]
+            # ... and with the RNG-checkpoint prepass in EVERY launch, as before round 4 (the table is a function of the film partition and
+            # the sample counts alone: the plan's first launch -- a warm-up step here -- computes it, later launches reuse it)
+            try:
+                os.environ["PINE_GPU_CKPT_EVERY_LAUNCH"] = "1"
+                q_res = measure(args.config, max(2, args.steps // 2), 1, env, args.spi, specialize=spec)
+                q = entry_of(q_res)
+                q_res["plan"].close()
+                full["checkpoints_every_launch"] = {"value": q["value"], "ms_per_step": q["ms_per_step"], "steps": q["steps"]}
+            except Exception as e:
+                full["checkpoints_every_launch"] = {"error": str(e)[:300]}
+            finally:
+                os.environ.pop("PINE_GPU_CKPT_EVERY_LAUNCH", None)
             if head["kernel_mode_short"] == "specialised":
                 # ... and with the precompiled kernel (what a first-sight scene runs while its kernel compiles, or a box without hipcc)
                 try:

@@ -633,6 +633,12 @@ struct pine_gpu_plan {
   const PineFastVariant* fast = nullptr;  // PINE_GPU_FLAG_FAST: the declared-tolerance variant that runs instead (pine_kernels_fast.hip)
   uint32_t* d_ctxg = nullptr;
   ulonglong2* d_ckpt = nullptr;
+  // The RNG checkpoints are a function of the film partition and the sample counts alone: the plan's FIRST launch computes them,
+  // later launches reuse the table (they wait for `ckpt_done` when they run on another stream).  $PINE_GPU_CKPT_EVERY_LAUNCH=1: as
+  // before round 4, every launch recomputes it (measurement aid).
+  bool ckpt_valid = false, ckpt_every_launch = false;
+  hipEvent_t ckpt_done = nullptr;
+  hipStream_t ckpt_stream = nullptr;
   float* d_vertex_log = nullptr;        // test hook (pine_gpu_plan_vertex_log)
   int* d_tile_order = nullptr;          // tile classes (WorkParams::tile_order), or null
   std::vector<int> tile_order;          // ... its host copy (empty: local tile t is film tile t * shard_world + shard_rank)
@@ -1056,6 +1062,7 @@ void pine_gpu_plan_destroy(pine_gpu_plan* p) {
   DevicePool::get().free(p->d_tables);
   DevicePool::get().free(p->d_ctxg);
   DevicePool::get().free(p->d_ckpt);
+  if (p->ckpt_done) (void)hipEventDestroy(p->ckpt_done);
   DevicePool::get().free(p->d_tile_order);
   DevicePool::get().free(p->d_vertex_log);
   DevicePool::get().free(p->d_samples);
@@ -1750,6 +1757,7 @@ static int plan_build(pine_gpu_plan* p, pine_gpu_scene* scene, const pine_gpu_re
 
   if (W.items_per_pixel > 1)
     HIP_OK(POOL_ALLOC(p->d_ckpt, (size_t)(W.num_local_tiles - W.serial_tiles) * W.items_per_pixel * 64 * sizeof(ulonglong2)));
+    p->ckpt_every_launch = getenv("PINE_GPU_CKPT_EVERY_LAUNCH") && atoi(getenv("PINE_GPU_CKPT_EVERY_LAUNCH")) != 0;
   if (!p->tile_order.empty()) {
     HIP_OK(POOL_ALLOC(p->d_tile_order, p->tile_order.size() * sizeof(int)));
     HIP_OK(hipMemcpy(p->d_tile_order, p->tile_order.data(), p->tile_order.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1808,9 +1816,17 @@ static int plan_launch(pine_gpu_plan* p, void* film_dev, void* stream_, bool pac
   // (a shard can own no tile at all -- more ranks than 8x8 tiles: nothing to launch, the film / slab stays zero)
   const bool has_work = p->W.num_local_tiles > 0;
   if (has_work && p->W.items_per_pixel > 1) {
-    const unsigned long long n = (unsigned long long)(p->W.num_local_tiles - p->W.serial_tiles) * 64ull;
-    hipLaunchKernelGGL(rng_checkpoint_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                       p->W, p->film_w, p->film_h, p->S.spp, p->d_ckpt);
+    if (!p->ckpt_valid || p->ckpt_every_launch) {
+      const unsigned long long n = (unsigned long long)(p->W.num_local_tiles - p->W.serial_tiles) * 64ull;
+      hipLaunchKernelGGL(rng_checkpoint_kernel, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                         p->W, p->film_w, p->film_h, p->S.spp, p->d_ckpt);
+      if (!p->ckpt_done) HIP_OK(hipEventCreateWithFlags(&p->ckpt_done, hipEventDisableTiming));
+      HIP_OK(hipEventRecord(p->ckpt_done, stream));
+      p->ckpt_stream = stream;
+      p->ckpt_valid = true;
+    } else if (stream != p->ckpt_stream) {
+      HIP_OK(hipStreamWaitEvent(stream, p->ckpt_done, 0));
+    }
   }
   if (p->timed) HIP_OK(hipEventRecord(ev[1], stream));
   if (!has_work) {
