@@ -65,11 +65,19 @@ def _configs():
         "c5": (lambda: scenes.sss((640, 640), 3), 512, 8,
                "Subsurface icosphere (1280 triangles) + emissive Rect in the Rect-only cbox 640x640 BlueSampler(512) = 256 effective spp depth=8",
                "C5_sss_640_s512_d8"),
+        # the same workloads as a `.pine` script renders them on real pine: EmbreeAccel (PINE_GPU_FLAG_ORDER_EMBREE; the md5 is that of the
+        # reference built WITH Embree, tests/golden/stats_640_embree.json) -- side figures, never the headline
+        "c2e": (lambda: scenes.cbox((640, 640), "committed"), 256, 8,
+                "cbox 640x640 256spp depth=8, as-committed camera, BlueSampler, EmbreeAccel's order (the .pine default)", "embree:C2_cbox_640_s256_d8_committed"),
+        "c4e": (lambda: scenes.classic_cones((720, 360), 100), 64, 6,
+                "classic.pine + 10 000 cones 720x360 64spp depth=6, EmbreeAccel's order (the .pine default)", "embree:C4_classic_10k_cones_720x360_s64_d6"),
     }
 
 
 def golden_md5(key):
     try:
+        if key.startswith("embree:"):
+            return json.load(open(os.path.join(ROOT, "tests", "golden", "stats_640_embree.json")))[key[7:]]["md5"]
         return json.load(open(os.path.join(ROOT, "tests", "golden", "stats_640.json")))[key]["md5"]
     except Exception:
         return None
@@ -331,7 +339,7 @@ def measure(name, steps, warmup, env, spi=0, specialize=None, host_copy=True):
     scene = build()
     W, H = scene.camera.film().size
     plan = pine_amd.Plan(scene, SPP, DEPTH, device=local_rank, shard_rank=rank, shard_world=world, samples_per_item=spi, timing=True,
-                         specialize=specialize)
+                         specialize=specialize, order="embree" if stats_key.startswith("embree:") else "pine")
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
     # N > 1: every rank writes only its own tiles, tile-major, into a slab (1/N of the film); the slabs are gathered to rank 0
@@ -692,7 +700,7 @@ def main():
                 res["plan"].close()
                 res["plan"] = None
             full["fast_mode"] = []
-            for name, k in (("c2r", 5), ("c3", 3), ("c4", 5), ("c5", 2)):
+            for name, k in (("c2r", 5), ("c3", 3), ("c4", 5), ("c5", 2), ("c2e", 5), ("c4e", 5)):
                 try:
                     r2 = measure(name, k, 1, env, args.spi, specialize=spec)
                     e = entry_of(r2)
@@ -700,7 +708,7 @@ def main():
                     del r2
                     torch.cuda.empty_cache()
                     full["configs"].append(e)
-                    if e["kernel_mode_short"] == "specialised":
+                    if e["kernel_mode_short"] == "specialised" and not name.endswith("e"):
                         r3 = measure(name, max(2, k // 2), 1, env, args.spi, specialize=False)
                         e3 = entry_of(r3)
                         r3["plan"].close()
