@@ -700,7 +700,7 @@ def main():
                 res["plan"].close()
                 res["plan"] = None
             full["fast_mode"] = []
-            for name, k in (("c2r", 5), ("c3", 3), ("c4", 5), ("c5", 2), ("c2e", 5), ("c4e", 5)):
+            for name, k in (("c2r", 5), ("c3", 3), ("c4", 10), ("c5", 2), ("c2e", 5), ("c4e", 10)):
                 try:
                     r2 = measure(name, k, 1, env, args.spi, specialize=spec)
                     e = entry_of(r2)
