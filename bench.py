@@ -133,6 +133,8 @@ def compact_line(full):
                          if "error" not in d else {"error": d["error"][:80]}))
     side = []
     for e in full.get("configs", []):
+        if str(e.get("config", "")).endswith("e"):  # (the EmbreeAccel-mode side figures, c2e / c4e, stay in the detail file)
+            continue
         if "error" in e:
             side.append({"name": e.get("config"), "error": e["error"][:60]})
         else:
